@@ -1,0 +1,150 @@
+/* yolact_amd.h — C ABI of libyolact_amd.so, the MI355X (gfx950) YOLACT inference hot path.
+ *
+ * Every entry point: plain pointers + sizes, an explicit hipStream_t (passed as void*), returns
+ *   0 = ok, negative = argument/shape error (YMI_E*), positive = hipError_t of the launch.
+ * The library never allocates or frees device memory: the caller owns every input, output and
+ * workspace buffer (SURVEY §8(b) "ownership").  All tensors are float32 unless stated, device
+ * pointers, densely packed in the layout named in the comment.  Activations are NHWC.
+ *
+ * Each function cites the reference interface (file:line under dbolya/yolact) it replaces.
+ */
+#ifndef YOLACT_AMD_H
+#define YOLACT_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YMI_ABI_VERSION 1
+
+/* activation codes (epilogue) */
+enum { YMI_ACT_NONE = 0, YMI_ACT_RELU = 1, YMI_ACT_LEAKY01 = 2, YMI_ACT_TANH = 3, YMI_ACT_SIGMOID = 4 };
+/* residual modes */
+enum { YMI_RES_NONE = 0, YMI_RES_ADD = 1, YMI_RES_BILINEAR = 2 };
+
+/* One output segment of a convolution: output channels [n0,n1) of pixel (b,pix) go to
+ *   ptr + b*batch_stride + pix*row_stride + (n - n0)      (element units)
+ * so a single GEMM can scatter to several tensors (the three shared prediction-head convs,
+ * yolact.py:169-173, become one GEMM with Cout = A*4 + A*81 + A*32) and can write straight
+ * into the level-concatenated [B, P, k] tensors (yolact.py:633-634) without a torch.cat. */
+typedef struct {
+  int32_t n0, n1;
+  int32_t act;          /* YMI_ACT_* applied to this segment */
+  int32_t row_stride;   /* elements between consecutive output pixels */
+  int64_t batch_stride; /* elements between consecutive images */
+  float *ptr;
+} ymi_conv_seg;
+
+/* Fused convolution descriptor.
+ * Replaces nn.Conv2d [+ BatchNorm2d (eval)] [+ residual add | FPN top-down bilinear add] [+ activation]:
+ *   backbone.py:37-57 (Bottleneck), :126-139 (stem), :222-236 (darknet unit), yolact.py:319-361 (FPN),
+ *   utils/functions.py:163-213 (make_net convs), yolact.py:146-193 (prediction heads).
+ * y[b,oy,ox,n] = act( scale[n] * sum_{ky,kx,c} x[b, oy*s-p+ky, ox*s-p+kx, c] * w[n,ky,kx,c] + bias[n]  (+ res) )
+ * computed with v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate). */
+typedef struct {
+  const float *x;       /* [B,H,W,ldx] NHWC; channels [0,Cin) of each pixel are used */
+  const float *w;       /* packed [CoutPad][Kpad], k = (ky*kw+kx)*Cin + c; CoutPad % 128 == 0, Kpad % 32 == 0, zero padded */
+  const float *scale;   /* [Cout] or NULL (=1)  — folded BatchNorm gamma/sqrt(var+eps) */
+  const float *bias;    /* [Cout] or NULL (=0)  — conv bias or folded BatchNorm shift */
+  const float *res;     /* residual source or NULL */
+  int32_t B, H, W, Cin, ldx;
+  int32_t Ho, Wo, Cout;
+  int32_t kh, kw, stride, pad;
+  int32_t Kpad;
+  int32_t res_mode;     /* YMI_RES_* */
+  int32_t res_ld;       /* channel stride of res pixels */
+  int32_t res_H, res_W; /* source size for YMI_RES_BILINEAR (res is [B,res_H,res_W,res_ld]) */
+  int32_t res_after_act;/* 1: y = act(conv) + res (darknet block, backbone.py:214-215); 0: y = act(conv + res) */
+  int32_t nseg;         /* 1..3 */
+  int32_t tile;         /* 0 = auto; else YMI_TILE_* override (tests / tuning) */
+  ymi_conv_seg seg[3];
+} ymi_conv_desc;
+
+enum { YMI_TILE_AUTO = 0, YMI_TILE_128x128 = 1, YMI_TILE_128x64 = 2, YMI_TILE_64x64 = 3, YMI_TILE_128x32 = 4,
+       YMI_TILE_64x128 = 5 };
+
+int ymi_abi_version(void);
+const char *ymi_strerror(int code);
+
+/* -- convolution engine ---------------------------------------------------------------- */
+int ymi_conv2d_nhwc_f32(const ymi_conv_desc *d, void *stream);
+/* algorithmic FLOPs (2*MACs) of a descriptor — used by bench.py's roofline accounting */
+double ymi_conv_flops(const ymi_conv_desc *d);
+/* which tile the auto heuristic picks (YMI_TILE_*) */
+int ymi_conv_pick_tile(const ymi_conv_desc *d);
+
+/* -- layout / pooling / resize ---------------------------------------------------------- */
+/* x [B,C,H,W] (C<=4) -> y [B,H,W,4], zero-filled channels C..3.  Entry of Yolact.forward (yolact.py:564). */
+int ymi_nchw_to_nhwc4_f32(const float *x, float *y, int B, int C, int H, int W, void *stream);
+/* y [B,H,W,C] NHWC -> x [B,C,H,W] (returning NCHW tensors to callers that expect them) */
+int ymi_nhwc_to_nchw_f32(const float *x, float *y, int B, int C, int H, int W, void *stream);
+/* nn.MaxPool2d(3, stride 2, pad 1) on NHWC, C % 4 == 0 (backbone.py:80,131). */
+int ymi_maxpool3x3s2_nhwc_f32(const float *x, float *y, int B, int H, int W, int C, int Ho, int Wo, void *stream);
+/* F.interpolate(mode='bilinear', align_corners=False) on NHWC, C % 4 == 0, optional ReLU
+ * (layers/interpolate.py:4-17; utils/functions.py:194). scale_h/scale_w: the 1/scale_factor torch would
+ * use (pass 0 to derive in/out like the size= form). */
+int ymi_bilinear_nhwc_f32(const float *x, float *y, int B, int Hi, int Wi, int C, int Ho, int Wo,
+                          float scale_h, float scale_w, int relu, void *stream);
+
+/* -- Detect: softmax + decode + Fast NMS (layers/functions/detection.py:32-180) ---------- */
+typedef struct {
+  const float *conf;    /* [B,P,C] raw class logits if conf_is_logits else post-softmax scores */
+  const float *loc;     /* [B,P,4] */
+  const float *coef;    /* [B,P,D] mask coefficients (post-tanh) */
+  const float *priors;  /* [P,4] cx,cy,w,h */
+  int32_t B, P, C, D;   /* C includes background class 0; D = mask_dim */
+  int32_t conf_is_logits;
+  int32_t top_k;        /* cfg.nms_top_k (200), <= 256 */
+  int32_t max_det;      /* cfg.max_num_detections (100), <= 256 */
+  float conf_thresh;    /* 0.05 */
+  float nms_thresh;     /* 0.5 */
+  int32_t cross_class;  /* detection.py:111-135 variant */
+  /* workspaces (caller-allocated) */
+  float *scores_t;      /* [B,C-1,P] class-major foreground scores */
+  int32_t *keep;        /* [B,P] 1 if max fg score > conf_thresh */
+  int32_t *num_keep;    /* [B] K */
+  float *maxsc;         /* [B,P] max foreground score per prior */
+  int32_t *argmax;      /* [B,P] its class (0-based foreground index) */
+  float *cand_score;    /* [B,(C-1)*top_k] per-class survivors, -1 where empty */
+  int32_t *cand_prior;  /* [B,(C-1)*top_k] */
+  /* outputs, fixed capacity cap = cross_class ? top_k : max_det */
+  int32_t *out_count;   /* [B] */
+  float *out_box;       /* [B,cap,4] x1,y1,x2,y2 relative */
+  float *out_score;     /* [B,cap] */
+  int64_t *out_class;   /* [B,cap] */
+  float *out_coef;      /* [B,cap,D] */
+  int32_t *out_prior;   /* [B,cap] index of the source prior (parity checks) */
+} ymi_detect_desc;
+int ymi_detect_f32(const ymi_detect_desc *d, void *stream);
+
+/* -- postprocess: mask assembly (layers/output_utils.py:69-99, layers/box_utils.py:327-373) */
+/* masks_lo[n,y,x] = crop(sigmoid(sum_k proto[y,x,k]*coef[n,k]), box[n]);  proto [ph,pw,D], coef [N,D], box [N,4] */
+int ymi_lincomb_crop_f32(const float *proto, const float *coef, const float *box, float *masks_lo,
+                         int ph, int pw, int D, int N, int crop, void *stream);
+/* out[n,y,x] = bilinear(masks_lo[n], (h,w))[y,x] > thresh ? 1 : 0 (float32) ; thresh<0 -> no binarise */
+int ymi_mask_upsample_f32(const float *masks_lo, float *out, int N, int ph, int pw, int h, int w,
+                          float thresh, void *stream);
+/* boxes [N,4] relative -> int64 absolute pixels via sanitize_coordinates(cast=False) then truncation */
+int ymi_boxes_to_pixels(const float *box, int64_t *out, int N, int w, int h, void *stream);
+
+/* -- DCNv2 forward (external/DCNv2/src/vision.cpp:5, dcn_v2.h:9-39, dcn_v2_cuda.cu:42-172) ---- */
+typedef struct {
+  ymi_conv_desc conv;    /* main 3x3 conv: x, packed w, bias, epilogue, outputs (kh=kw=3, pad=1) */
+  const float *offmask;  /* [B,Ho,Wo,ldo] NHWC output of conv_offset_mask: ch 2k=dh_k, 2k+1=dw_k, 18+k=mask logit */
+  int32_t ldo;           /* channel stride of offmask pixels (>= 27) */
+} ymi_dcn_desc;
+int ymi_dcn_v2_forward_f32(const ymi_dcn_desc *d, void *stream);
+
+/* -- profiling hooks -------------------------------------------------------------------- */
+/* When enabled, every conv launch is bracketed by hipEvents on its stream; ymi_prof_read returns
+ * (after synchronising) per-launch milliseconds, flops and tile ids. Used by bench.py roofline. */
+int ymi_prof_enable(int on);
+int ymi_prof_count(void);
+int ymi_prof_read(int i, float *ms, double *flops, int32_t *tile, int32_t *kind);
+int ymi_prof_reset(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,411 @@
+// NHWC implicit-GEMM convolution on the fp32 matrix cores of gfx950 (v_mfma_f32_32x32x2_f32).
+//
+// GEMM view:  M = B*Ho*Wo output pixels, N = Cout, K = kh*kw*Cin with k = (ky*kw+kx)*Cin + c.
+//   A[m,k]  gathered on the fly from the NHWC input (zero for padding / m >= M / k >= K)
+//   B[k,n]  packed weights, stored [n][k] (k contiguous) so A and B tiles have the same LDS image
+// Block = 256 threads = 4 wave64; block tile BM x BN, K step 32.  Each wave owns TM x TN MFMA tiles of
+// 32x32.  LDS image of both operands: [row][36] floats (32 k-values + 4 pad): the 144-byte row stride
+// makes both the ds_write_b128 staging stores and the ds_read_b128 fragment loads bank-conflict free
+// (9 sixteen-byte slots per row; 9 is odd so the 16 rows of any ds_read_b128 lane group cover all 16
+// slots of the 256-byte bank row).
+//
+// Fragment trick: the MFMA consumes k in pairs {lanes 0-31: k0, lanes 32-63: k1}.  The K order of a
+// dot product is free as long as A and B agree, so lane-half h loads k = 8g+4h .. 8g+4h+3 with ONE
+// 16-byte LDS read and MFMA step j pairs (8g+j, 8g+4+j).  4 MFMAs (256 cycles/SIMD) per ds_read_b128 pair.
+//
+// Pipeline: LDS double buffer; the global loads of chunk kc+1 are issued into registers before the
+// MFMAs of chunk kc and written to the other LDS buffer afterwards: one barrier per K step, HBM/L2
+// latency hidden under 64*TM*TN*... MFMA cycles; 2 blocks/CU co-reside for the rest.
+//
+// Epilogue (fused): folded-BN scale/bias, residual add (plain or bilinear-upsampled source = FPN
+// top-down path), activation, scatter to up to 3 output segments with independent strides.
+#include "common.h"
+#include "../../include/yolact_amd.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDS_LD = 36;  // floats per LDS row
+
+struct KParams {
+  ymi_conv_desc d;
+  int M, HoWo, tiles_n, nk, cpt;  // cpt = chunks per tap (Cin/32) for the C32 loader
+  const float *offmask;           // DCN only
+  int ldo;
+};
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  switch (act) {
+    case YMI_ACT_RELU: return v > 0.f ? v : 0.f;
+    case YMI_ACT_LEAKY01: return v > 0.f ? v : 0.1f * v;
+    case YMI_ACT_TANH: return tanhf(v);
+    case YMI_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+    default: return v;
+  }
+}
+
+// torch's area_pixel_compute_source_index for align_corners=False (fp32 arithmetic on purpose,
+// see SURVEY appendix A5): src = max(scale*(dst+0.5)-0.5, 0)
+__device__ __forceinline__ void bilin_coord(int dst, float scale, int in_size, int &i0, int &i1, float &l1) {
+  float src = scale * ((float)dst + 0.5f) - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  i0 = (int)src;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+  l1 = src - (float)i0;
+}
+
+// LOADER: 0 = Cin % 32 == 0 (a K chunk lies inside one filter tap; tap is block-uniform)
+//         1 = Cin == 4 (stem; a K chunk = 8 taps x 4 channels; tap is per-thread)
+//         2 = DCNv2 modulated deformable gather (Cin % 32 == 0, 3x3, pad 1)
+template <int WM, int WN, int TM, int TN, int LOADER>
+__global__ __launch_bounds__(256) void conv_igemm_f32(const KParams p) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int RA = BM / 32, RB = BN / 32;  // float4 rows per thread for the A / B tile
+  static_assert(WM * WN == 4, "4 waves per block");
+  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDS_LD];
+
+  const ymi_conv_desc &d = p.d;
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int kq = t & 7, r0 = t >> 3;
+
+  const int logical = ymi_xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = logical % p.tiles_n, tile_m = logical / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // ---- per-thread A-row bookkeeping (fixed over the K loop) ---------------------------------
+  int a_iy0[RA], a_ix0[RA], a_base[RA];
+#pragma unroll
+  for (int i = 0; i < RA; ++i) {
+    const int m = m0 + r0 + 32 * i;
+    if (m < p.M) {
+      const int b = m / p.HoWo, pix = m - b * p.HoWo;
+      const int oy = pix / d.Wo, ox = pix - oy * d.Wo;
+      a_iy0[i] = oy * d.stride - d.pad;
+      a_ix0[i] = ox * d.stride - d.pad;
+      a_base[i] = ((b * d.H + a_iy0[i]) * d.W + a_ix0[i]) * d.ldx;
+      if (LOADER == 2) a_base[i] = m;  // DCN: remember the output pixel, geometry recomputed per tap
+    } else {
+      a_iy0[i] = -(1 << 28);  // never valid
+      a_ix0[i] = -(1 << 28);
+      a_base[i] = 0;
+    }
+  }
+  const float *wrow[RB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i) wrow[i] = d.w + (size_t)(n0 + r0 + 32 * i) * d.Kpad + 4 * kq;
+
+  f32x4 ra[RA], rb[RB];
+  unsigned amask = 0;  // bit i: ra[i] holds real data (else it must be stored as zeros)
+
+  auto load_tiles = [&](int kc) {
+    amask = 0;
+    if (LOADER == 0) {
+      const int tap = kc / p.cpt, c = (kc - tap * p.cpt) * 32 + 4 * kq;
+      const int ky = tap / d.kw, kx = tap - ky * d.kw;
+      const int koff = (ky * d.W + kx) * d.ldx + c;
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        const bool ok = (unsigned)(a_iy0[i] + ky) < (unsigned)d.H && (unsigned)(a_ix0[i] + kx) < (unsigned)d.W;
+        // unconditional load from a clamped address + select: no branch, loads stay in flight together
+        ra[i] = *reinterpret_cast<const f32x4 *>(d.x + (ok ? (a_base[i] + koff) : 0));
+        amask |= (ok ? 1u : 0u) << i;  // zeroing is applied at store_lds time so the wait sits after the MFMAs
+      }
+    } else if (LOADER == 1) {
+      const int tap = kc * 8 + kq;
+      const int ky = tap / d.kw, kx = tap - ky * d.kw;
+      const bool tap_ok = tap < d.kh * d.kw;
+      const int koff = (ky * d.W + kx) * d.ldx;
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        const bool ok = tap_ok && (unsigned)(a_iy0[i] + ky) < (unsigned)d.H &&
+                        (unsigned)(a_ix0[i] + kx) < (unsigned)d.W;
+        // unconditional load from a clamped address + select: no branch, loads stay in flight together
+        ra[i] = *reinterpret_cast<const f32x4 *>(d.x + (ok ? (a_base[i] + koff) : 0));
+        amask |= (ok ? 1u : 0u) << i;  // zeroing is applied at store_lds time so the wait sits after the MFMAs
+      }
+    } else {
+      // DCNv2 (dcn_v2_im2col_cuda.cu:143-193): sample point = (oy*s - p + ky + dh, ox*s - p + kx + dw),
+      // zero unless -1 < h < H and -1 < w < W; zero-padded bilinear; times sigmoid(mask logit).
+      const int tap = kc / p.cpt, c = (kc - tap * p.cpt) * 32 + 4 * kq;
+      const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (a_iy0[i] > -(1 << 27)) {
+          const int m = a_base[i];
+          const float *om = p.offmask + (size_t)m * p.ldo;
+          const float dh = om[2 * tap], dw = om[2 * tap + 1];
+          const float mk = 1.f / (1.f + expf(-om[18 + tap]));
+          const float h = (float)(a_iy0[i] + ky) + dh, w = (float)(a_ix0[i] + kx) + dw;
+          if (h > -1.f && w > -1.f && h < (float)d.H && w < (float)d.W) {
+            const int hl = (int)floorf(h), wl = (int)floorf(w);
+            const int hh = hl + 1, wh = wl + 1;
+            const float lh = h - (float)hl, lw = w - (float)wl, uh = 1.f - lh, uw = 1.f - lw;
+            const int b = m / p.HoWo;
+            const float *img = d.x + (size_t)b * d.H * d.W * d.ldx + c;
+            f32x4 v1 = {0.f, 0.f, 0.f, 0.f}, v2 = v1, v3 = v1, v4 = v1;
+            if (hl >= 0 && wl >= 0) v1 = *reinterpret_cast<const f32x4 *>(img + (hl * d.W + wl) * d.ldx);
+            if (hl >= 0 && wh <= d.W - 1) v2 = *reinterpret_cast<const f32x4 *>(img + (hl * d.W + wh) * d.ldx);
+            if (hh <= d.H - 1 && wl >= 0) v3 = *reinterpret_cast<const f32x4 *>(img + (hh * d.W + wl) * d.ldx);
+            if (hh <= d.H - 1 && wh <= d.W - 1) v4 = *reinterpret_cast<const f32x4 *>(img + (hh * d.W + wh) * d.ldx);
+            const float w1 = uh * uw, w2 = uh * lw, w3 = lh * uw, w4 = lh * lw;
+            v = (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4) * mk;
+          }
+        }
+        ra[i] = v;
+      }
+      amask = 0xffffffffu;
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) rb[i] = *reinterpret_cast<const f32x4 *>(wrow[i] + kc * BK);
+  };
+
+  auto store_lds = [&](int buf) {
+    float *As = lds + buf * (BM + BN) * LDS_LD;
+    float *Bs = As + BM * LDS_LD;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4 *>(As + (r0 + 32 * i) * LDS_LD + 4 * kq) = ((amask >> i) & 1u) ? ra[i] : z;
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4 *>(Bs + (r0 + 32 * i) * LDS_LD + 4 * kq) = rb[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frag_off = (lane & 31) * LDS_LD + 4 * (lane >> 5);
+
+  auto compute = [&](int buf) {
+    const float *As = lds + buf * (BM + BN) * LDS_LD + (wm * TM * 32) * LDS_LD + frag_off;
+    const float *Bs = lds + buf * (BM + BN) * LDS_LD + BM * LDS_LD + (wn * TN * 32) * LDS_LD + frag_off;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4 *>(As + i * 32 * LDS_LD + g * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4 *>(Bs + j * 32 * LDS_LD + g * 8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // ---- main loop ---------------------------------------------------------------------------
+  load_tiles(0);
+  store_lds(0);
+  __syncthreads();
+  for (int kc = 0; kc < p.nk; ++kc) {
+    const int cur = kc & 1;
+    const bool more = (kc + 1) < p.nk;
+    if (more) load_tiles(kc + 1);
+    compute(cur);
+    if (more) store_lds(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ----------------------------------------------------------------------------
+  // C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)
+  const int ncol = lane & 31;
+  float rscale_h = 0.f, rscale_w = 0.f;
+  if (d.res_mode == YMI_RES_BILINEAR) {
+    rscale_h = (float)d.res_H / (float)d.Ho;
+    rscale_w = (float)d.res_W / (float)d.Wo;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + (wn * TN + j) * 32 + ncol;
+    const bool n_ok = n < d.Cout;
+    float sc = 1.f, bi = 0.f;
+    int sact = 0, srow = 0, sn0 = 0;
+    int64_t sbatch = 0;
+    float *sptr = nullptr;
+    if (n_ok) {
+      if (d.scale) sc = d.scale[n];
+      if (d.bias) bi = d.bias[n];
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        if (s < d.nseg && n >= d.seg[s].n0 && n < d.seg[s].n1) {
+          sact = d.seg[s].act; srow = d.seg[s].row_stride; sn0 = d.seg[s].n0;
+          sbatch = d.seg[s].batch_stride; sptr = d.seg[s].ptr;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (n_ok && sptr && m < p.M) {
+          const int b = m / p.HoWo, pix = m - b * p.HoWo;
+          float v = acc[i][j][r] * sc + bi;
+          float rv = 0.f;
+          if (d.res_mode == YMI_RES_ADD) {
+            rv = d.res[(size_t)m * d.res_ld + n];
+          } else if (d.res_mode == YMI_RES_BILINEAR) {
+            const int oy = pix / d.Wo, ox = pix - oy * d.Wo;
+            int y0, y1, x0, x1; float ly, lx;
+            bilin_coord(oy, rscale_h, d.res_H, y0, y1, ly);
+            bilin_coord(ox, rscale_w, d.res_W, x0, x1, lx);
+            const float *rb_ = d.res + (size_t)b * d.res_H * d.res_W * d.res_ld + n;
+            const float v00 = rb_[(y0 * d.res_W + x0) * d.res_ld], v01 = rb_[(y0 * d.res_W + x1) * d.res_ld];
+            const float v10 = rb_[(y1 * d.res_W + x0) * d.res_ld], v11 = rb_[(y1 * d.res_W + x1) * d.res_ld];
+            rv = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+          }
+          if (d.res_after_act) v = act_apply(v, sact) + rv;
+          else v = act_apply(v + rv, sact);
+          sptr[(size_t)b * sbatch + (size_t)pix * srow + (n - sn0)] = v;
+        }
+      }
+    }
+  }
+}
+
+// ---- host side --------------------------------------------------------------------------------
+struct ProfRec { hipEvent_t e0, e1; double flops; int tile; int kind; };
+constexpr int PROF_MAX = 4096;
+ProfRec g_prof[PROF_MAX];
+int g_prof_n = 0, g_prof_alloc = 0, g_prof_on = 0;
+
+template <int WM, int WN, int TM, int TN>
+int launch_cfg(const KParams &kp, int loader, hipStream_t s) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  KParams p = kp;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.d.Cout + BN - 1) / BN;
+  const int grid = tiles_m * p.tiles_n;
+  if (loader == 0) hipLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, 0>), dim3(grid), dim3(256), 0, s, p);
+  else if (loader == 1) hipLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, 1>), dim3(grid), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, 2>), dim3(grid), dim3(256), 0, s, p);
+  return ymi_launch_status();
+}
+
+int tile_dims(int tile, int &bm, int &bn) {
+  switch (tile) {
+    case YMI_TILE_128x128: bm = 128; bn = 128; return 0;
+    case YMI_TILE_128x64: bm = 128; bn = 64; return 0;
+    case YMI_TILE_64x64: bm = 64; bn = 64; return 0;
+    case YMI_TILE_128x32: bm = 128; bn = 32; return 0;
+    case YMI_TILE_64x128: bm = 64; bn = 128; return 0;
+  }
+  return -1;
+}
+
+int pick_tile(const ymi_conv_desc *d) {
+  const long M = (long)d->B * d->Ho * d->Wo;
+  const int N = d->Cout;
+  // Largest tile that still yields >= ~2 blocks per CU over 256 CUs; otherwise the finest tile.
+  const int order[4] = {YMI_TILE_128x128, YMI_TILE_128x64, YMI_TILE_64x128, YMI_TILE_64x64};
+  if (N <= 32) return YMI_TILE_128x32;
+  int best = YMI_TILE_64x64;
+  for (int i = 0; i < 4; ++i) {
+    int bm, bn; tile_dims(order[i], bm, bn);
+    if (bn > 64 && N <= 64) continue;                 // don't waste half the N tile
+    if (order[i] == YMI_TILE_64x128 && N < 128) continue;
+    const long tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+    if (tiles >= 512) { best = order[i]; break; }
+  }
+  return best;
+}
+
+int validate(const ymi_conv_desc *d, int loader) {
+  if (!d || !d->x || !d->w) return YMI_ENULL;
+  if (d->nseg < 1 || d->nseg > 3) return YMI_EARG;
+  for (int s = 0; s < d->nseg; ++s) if (!d->seg[s].ptr) return YMI_ENULL;
+  if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0 || d->Ho <= 0 || d->Wo <= 0) return YMI_EARG;
+  if (d->ldx % 4 != 0 || d->Kpad % 32 != 0 || d->Kpad < d->kh * d->kw * d->Cin) return YMI_ESHAPE;
+  if (loader == 1) { if (d->Cin != 4) return YMI_ESHAPE; }
+  else if (d->Cin % 32 != 0) return YMI_ESHAPE;
+  if (loader == 2 && (d->kh != 3 || d->kw != 3 || d->pad != 1)) return YMI_ESHAPE;
+  if (d->Ho != (d->H + 2 * d->pad - d->kh) / d->stride + 1) return YMI_ESHAPE;
+  if (d->Wo != (d->W + 2 * d->pad - d->kw) / d->stride + 1) return YMI_ESHAPE;
+  if ((long)d->B * d->H * d->W * d->ldx >= (1L << 31)) return YMI_ESHAPE;
+  if (d->res_mode != YMI_RES_NONE && !d->res) return YMI_ENULL;
+  return YMI_OK;
+}
+
+int run_conv(const ymi_conv_desc *d, int loader, const float *offmask, int ldo, hipStream_t s) {
+  int rc = validate(d, loader);
+  if (rc) return rc;
+  KParams kp;
+  kp.d = *d;
+  kp.HoWo = d->Ho * d->Wo;
+  kp.M = d->B * kp.HoWo;
+  kp.nk = d->Kpad / BK;
+  kp.cpt = (loader == 1) ? 1 : d->Cin / 32;
+  kp.tiles_n = 0;
+  kp.offmask = offmask;
+  kp.ldo = ldo;
+  int tile = d->tile ? d->tile : pick_tile(d);
+  ProfRec *pr = nullptr;
+  if (g_prof_on && g_prof_n < PROF_MAX) {
+    pr = &g_prof[g_prof_n];
+    if (g_prof_n >= g_prof_alloc) { hipEventCreate(&pr->e0); hipEventCreate(&pr->e1); g_prof_alloc = g_prof_n + 1; }
+    pr->flops = ymi_conv_flops(d); pr->tile = tile; pr->kind = loader;
+    hipEventRecord(pr->e0, s);
+  }
+  switch (tile) {
+    case YMI_TILE_128x128: rc = launch_cfg<2, 2, 2, 2>(kp, loader, s); break;
+    case YMI_TILE_128x64: rc = launch_cfg<2, 2, 2, 1>(kp, loader, s); break;
+    case YMI_TILE_64x128: rc = launch_cfg<2, 2, 1, 2>(kp, loader, s); break;
+    case YMI_TILE_64x64: rc = launch_cfg<2, 2, 1, 1>(kp, loader, s); break;
+    case YMI_TILE_128x32: rc = launch_cfg<4, 1, 1, 1>(kp, loader, s); break;
+    default: return YMI_EARG;
+  }
+  if (pr) { hipEventRecord(pr->e1, s); ++g_prof_n; }
+  return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+double ymi_conv_flops(const ymi_conv_desc *d) {
+  return 2.0 * d->B * d->Ho * d->Wo * (double)d->Cout * d->kh * d->kw * (double)d->Cin;
+}
+
+int ymi_conv_pick_tile(const ymi_conv_desc *d) { return d ? pick_tile(d) : YMI_ENULL; }
+
+int ymi_conv2d_nhwc_f32(const ymi_conv_desc *d, void *stream) {
+  if (!d) return YMI_ENULL;
+  return run_conv(d, d->Cin == 4 ? 1 : 0, nullptr, 0, (hipStream_t)stream);
+}
+
+int ymi_dcn_v2_forward_f32(const ymi_dcn_desc *d, void *stream) {
+  if (!d || !d->offmask) return YMI_ENULL;
+  if (d->ldo < 27) return YMI_ESHAPE;
+  return run_conv(&d->conv, 2, d->offmask, d->ldo, (hipStream_t)stream);
+}
+
+int ymi_prof_enable(int on) { g_prof_on = on; return YMI_OK; }
+int ymi_prof_count(void) { return g_prof_n; }
+int ymi_prof_reset(void) { g_prof_n = 0; return YMI_OK; }
+int ymi_prof_read(int i, float *ms, double *flops, int32_t *tile, int32_t *kind) {
+  if (i < 0 || i >= g_prof_n) return YMI_EARG;
+  hipError_t e = hipEventSynchronize(g_prof[i].e1);
+  if (e != hipSuccess) return (int)e;
+  float t = 0.f;
+  e = hipEventElapsedTime(&t, g_prof[i].e0, g_prof[i].e1);
+  if (e != hipSuccess) return (int)e;
+  if (ms) *ms = t;
+  if (flops) *flops = g_prof[i].flops;
+  if (tile) *tile = g_prof[i].tile;
+  if (kind) *kind = g_prof[i].kind;
+  return YMI_OK;
+}
+
+}  // extern "C"

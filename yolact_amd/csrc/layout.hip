@@ -1,0 +1,155 @@
+// Bandwidth kernels around the conv engine: layout change, max-pool, bilinear resize (NHWC, float4 lanes).
+#include "common.h"
+#include "../../include/yolact_amd.h"
+
+namespace {
+
+// x [B,C,H,W] (C <= 4) -> y [B,H,W,4]; one thread per pixel, plane reads coalesced, 16-byte stores.
+__global__ __launch_bounds__(256) void nchw_to_nhwc4_k(const float *__restrict__ x, float *__restrict__ y,
+                                                        int C, int HW, long total) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    const long b = i / HW, pix = i - b * HW;
+    const float *src = x + b * C * HW + pix;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (C > 0) v[0] = src[0];
+    if (C > 1) v[1] = src[HW];
+    if (C > 2) v[2] = src[2L * HW];
+    if (C > 3) v[3] = src[3L * HW];
+    *reinterpret_cast<f32x4 *>(y + i * 4) = v;
+  }
+}
+
+// x [B,H,W,C] -> y [B,C,H,W] through a 32x33 LDS tile (pixels x channels) so both sides coalesce.
+__global__ __launch_bounds__(256) void nhwc_to_nchw_k(const float *__restrict__ x, float *__restrict__ y,
+                                                       int C, int HW) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int p = p0 + r, c = c0 + tx;
+    tile[r][tx] = (p < HW && c < C) ? x[((long)b * HW + p) * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r, p = p0 + tx;
+    if (p < HW && c < C) y[((long)b * C + c) * HW + p] = tile[tx][r];
+  }
+}
+
+// MaxPool 3x3 / stride 2 / pad 1, -inf padding (nn.MaxPool2d semantics). One thread per (pixel, 4 channels).
+__global__ __launch_bounds__(256) void maxpool3x3s2_k(const float *__restrict__ x, float *__restrict__ y,
+                                                       int H, int W, int C4, int Ho, int Wo, long total) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    const int c4 = (int)(i % C4);
+    long r = i / C4;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const long b = r / Ho;
+    const float ninf = -__builtin_inff();
+    f32x4 m = {ninf, ninf, ninf, ninf};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * 2 - 1 + ky;
+      if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * 2 - 1 + kx;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(x + (((b * H + iy) * W + ix) * C4 + c4) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+      }
+    }
+    *reinterpret_cast<f32x4 *>(y + i * 4) = m;
+  }
+}
+
+__device__ __forceinline__ void bl_coord(int dst, float scale, int in_size, int &i0, int &i1, float &l1) {
+  float src = scale * ((float)dst + 0.5f) - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  i0 = (int)src;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+  l1 = src - (float)i0;
+}
+
+// F.interpolate(bilinear, align_corners=False) on NHWC; thread per (out pixel, 4 channels).
+__global__ __launch_bounds__(256) void bilinear_nhwc_k(const float *__restrict__ x, float *__restrict__ y,
+                                                        int Hi, int Wi, int C4, int Ho, int Wo, float sh, float sw,
+                                                        int relu, long total) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    const int c4 = (int)(i % C4);
+    long r = i / C4;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const long b = r / Ho;
+    int y0, y1, x0, x1; float ly, lx;
+    bl_coord(oy, sh, Hi, y0, y1, ly);
+    bl_coord(ox, sw, Wi, x0, x1, lx);
+    const float *img = x + (b * Hi * Wi * C4 + c4) * 4;
+    const f32x4 v00 = *reinterpret_cast<const f32x4 *>(img + (long)(y0 * Wi + x0) * C4 * 4);
+    const f32x4 v01 = *reinterpret_cast<const f32x4 *>(img + (long)(y0 * Wi + x1) * C4 * 4);
+    const f32x4 v10 = *reinterpret_cast<const f32x4 *>(img + (long)(y1 * Wi + x0) * C4 * 4);
+    const f32x4 v11 = *reinterpret_cast<const f32x4 *>(img + (long)(y1 * Wi + x1) * C4 * 4);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = hy * (hx * v00[e] + lx * v01[e]) + ly * (hx * v10[e] + lx * v11[e]);
+      o[e] = (relu && v < 0.f) ? 0.f : v;
+    }
+    *reinterpret_cast<f32x4 *>(y + i * 4) = o;
+  }
+}
+
+inline int grid_for(long total) {
+  long g = (total + 255) / 256;
+  const long cap = 256L * 8;  // 8 blocks per CU, grid-stride the rest
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+extern "C" {
+
+int ymi_nchw_to_nhwc4_f32(const float *x, float *y, int B, int C, int H, int W, void *stream) {
+  if (!x || !y) return YMI_ENULL;
+  if (B <= 0 || C <= 0 || C > 4 || H <= 0 || W <= 0) return YMI_EARG;
+  const long total = (long)B * H * W;
+  hipLaunchKernelGGL(nchw_to_nhwc4_k, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, C, H * W, total);
+  return ymi_launch_status();
+}
+
+int ymi_nhwc_to_nchw_f32(const float *x, float *y, int B, int C, int H, int W, void *stream) {
+  if (!x || !y) return YMI_ENULL;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || B > 65535) return YMI_EARG;
+  const int HW = H * W;
+  dim3 grid((HW + 31) / 32, (C + 31) / 32, B);
+  if (grid.y > 65535) return YMI_EARG;
+  hipLaunchKernelGGL(nhwc_to_nchw_k, grid, dim3(256), 0, (hipStream_t)stream, x, y, C, HW);
+  return ymi_launch_status();
+}
+
+int ymi_maxpool3x3s2_nhwc_f32(const float *x, float *y, int B, int H, int W, int C, int Ho, int Wo, void *stream) {
+  if (!x || !y) return YMI_ENULL;
+  if (C % 4 != 0 || B <= 0) return YMI_ESHAPE;
+  if (Ho != (H + 2 - 3) / 2 + 1 || Wo != (W + 2 - 3) / 2 + 1) return YMI_ESHAPE;
+  const long total = (long)B * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(maxpool3x3s2_k, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C / 4, Ho,
+                     Wo, total);
+  return ymi_launch_status();
+}
+
+int ymi_bilinear_nhwc_f32(const float *x, float *y, int B, int Hi, int Wi, int C, int Ho, int Wo, float scale_h,
+                          float scale_w, int relu, void *stream) {
+  if (!x || !y) return YMI_ENULL;
+  if (C % 4 != 0 || B <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return YMI_ESHAPE;
+  const float sh = scale_h > 0.f ? scale_h : (float)Hi / (float)Ho;
+  const float sw = scale_w > 0.f ? scale_w : (float)Wi / (float)Wo;
+  const long total = (long)B * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(bilinear_nhwc_k, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, Hi, Wi, C / 4,
+                     Ho, Wo, sh, sw, relu, total);
+  return ymi_launch_status();
+}
+
+}  // extern "C"

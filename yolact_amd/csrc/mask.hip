@@ -1,0 +1,185 @@
+// postprocess() on device: prototype linear combination on the fp32 matrix cores + sigmoid + crop,
+// then bilinear upsample to the image size + binarise, and box sanitising.
+// Reference: layers/output_utils.py:69-99, layers/box_utils.py:327-373 (sanitize_coordinates, crop).
+#include "common.h"
+#include "../../include/yolact_amd.h"
+
+namespace {
+
+// masks_lo[n, pix] = crop(sigmoid(sum_k coef[n,k] * proto[pix,k])).
+// MFMA roles: A = coef (rows n), B = proto^T (cols = pixels) so that for a fixed accumulator register the
+// 32 lanes of a half-wave hold 32 consecutive pixels of ONE detection -> 128-byte coalesced stores into
+// the [N, ph*pw] output.  K = D (32): lane-half h holds k = 16h..16h+15 (64 contiguous bytes of the
+// pixel's / detection's row) and step s pairs (s, 16+s) — same free-K-order trick as the conv engine.
+template <int D>
+__global__ __launch_bounds__(256) void lincomb_crop_k(const float *__restrict__ proto, const float *__restrict__ coef,
+                                                      const float *__restrict__ box, float *__restrict__ out, int ph,
+                                                      int pw, int N, int crop) {
+  static_assert(D == 32, "mask_dim 32");
+  extern __shared__ float cb[];  // [Npad][4] crop bounds x1,x2,y1,y2
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int npix = ph * pw;
+  const int ntiles = (N + 31) / 32;
+  for (int n = t; n < ntiles * 32; n += 256) {
+    float x1 = 0.f, x2 = (float)pw, y1 = 0.f, y2 = (float)ph;
+    if (n < N && crop) {
+      // sanitize_coordinates(_x1, _x2, img_size, padding=1, cast=False)
+      const float a = box[n * 4 + 0] * (float)pw, b = box[n * 4 + 2] * (float)pw;
+      x1 = fminf(a, b) - 1.f; x1 = x1 < 0.f ? 0.f : x1;
+      x2 = fmaxf(a, b) + 1.f; x2 = x2 > (float)pw ? (float)pw : x2;
+      const float c = box[n * 4 + 1] * (float)ph, e = box[n * 4 + 3] * (float)ph;
+      y1 = fminf(c, e) - 1.f; y1 = y1 < 0.f ? 0.f : y1;
+      y2 = fmaxf(c, e) + 1.f; y2 = y2 > (float)ph ? (float)ph : y2;
+    }
+    cb[n * 4 + 0] = x1; cb[n * 4 + 1] = x2; cb[n * 4 + 2] = y1; cb[n * 4 + 3] = y2;
+  }
+  __syncthreads();
+
+  const int pix0 = (blockIdx.x * 4 + wave) * 32;
+  if (pix0 >= npix) return;
+  const int half = lane >> 5, l31 = lane & 31;
+  // B operand: proto row of pixel (pix0 + l31), k = 16*half .. +15
+  float bfrag[16];
+  {
+    const int pix = pix0 + l31;
+    const bool ok = pix < npix;
+    const float *src = proto + (size_t)(ok ? pix : 0) * D + 16 * half;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(src + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bfrag[4 * q + e] = ok ? v[e] : 0.f;
+    }
+  }
+  const int pix = pix0 + l31;
+  const int py = pix / pw, px = pix - py * pw;
+  const float fx = (float)px, fy = (float)py;
+  for (int nt = 0; nt < ntiles; ++nt) {
+    const int n_a = nt * 32 + l31;
+    const bool ok = n_a < N;
+    const float *src = coef + (size_t)(ok ? n_a : 0) * D + 16 * half;
+    float afrag[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(src + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) afrag[4 * q + e] = ok ? v[e] : 0.f;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[s], bfrag[s], acc, 0, 0, 0);
+    if (pix < npix) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (n < N) {
+          float v = 1.f / (1.f + expf(-acc[r]));
+          const float *c4 = cb + n * 4;
+          const bool in = fx >= c4[0] && fx < c4[1] && fy >= c4[2] && fy < c4[3];
+          out[(size_t)n * npix + pix] = in ? v : 0.f;
+        }
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void up_coord(int dst, float scale, int in_size, int &i0, int &i1, float &l1) {
+  float src = scale * ((float)dst + 0.5f) - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  i0 = (int)src;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+  l1 = src - (float)i0;
+}
+
+// out[n,y,x] = (bilinear(masks_lo[n])[y,x] > thresh) ? 1 : 0.  Flat float4 stores: pure HBM-write stream
+// (N*h*w*4 bytes, 121 MB at N=100, 550x550) while the [N,ph,pw] source stays L2-resident.
+__global__ __launch_bounds__(256) void mask_upsample_k(const float *__restrict__ lo, float *__restrict__ out, int ph,
+                                                       int pw, int h, int w, float sh, float sw, float thresh,
+                                                       long total4, long total) {
+  const long hw = (long)h * w;
+  for (long i4 = blockIdx.x * 256L + threadIdx.x; i4 < total4; i4 += (long)gridDim.x * 256L) {
+    const long base = i4 * 4;
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long i = base + e;
+      float r = 0.f;
+      if (i < total) {
+        const long n = i / hw;
+        const int rem = (int)(i - n * hw);
+        const int y = rem / w, x = rem - y * w;
+        int y0, y1, x0, x1; float ly, lx;
+        up_coord(y, sh, ph, y0, y1, ly);
+        up_coord(x, sw, pw, x0, x1, lx);
+        const float *img = lo + n * (long)ph * pw;
+        const float v00 = img[y0 * pw + x0], v01 = img[y0 * pw + x1];
+        const float v10 = img[y1 * pw + x0], v11 = img[y1 * pw + x1];
+        const float v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+        r = thresh < 0.f ? v : (v > thresh ? 1.f : 0.f);
+      }
+      o[e] = r;
+    }
+    if (base + 3 < total) {
+      *reinterpret_cast<f32x4 *>(out + base) = o;
+    } else {
+      for (int e = 0; e < 4; ++e) if (base + e < total) out[base + e] = o[e];
+    }
+  }
+}
+
+// boxes -> absolute int64 pixels: sanitize_coordinates(x1, x2, w, padding=0, cast=False) then .long()
+__global__ void boxes_to_pixels_k(const float *__restrict__ box, long long *__restrict__ out, int N, int w, int h) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const float a = box[n * 4 + 0] * (float)w, b = box[n * 4 + 2] * (float)w;
+  float x1 = fminf(a, b); x1 = x1 < 0.f ? 0.f : x1;
+  float x2 = fmaxf(a, b); x2 = x2 > (float)w ? (float)w : x2;
+  const float c = box[n * 4 + 1] * (float)h, e = box[n * 4 + 3] * (float)h;
+  float y1 = fminf(c, e); y1 = y1 < 0.f ? 0.f : y1;
+  float y2 = fmaxf(c, e); y2 = y2 > (float)h ? (float)h : y2;
+  out[n * 4 + 0] = (long long)x1; out[n * 4 + 1] = (long long)y1;
+  out[n * 4 + 2] = (long long)x2; out[n * 4 + 3] = (long long)y2;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ymi_lincomb_crop_f32(const float *proto, const float *coef, const float *box, float *masks_lo, int ph, int pw,
+                         int D, int N, int crop, void *stream) {
+  if (!proto || !coef || !box || !masks_lo) return YMI_ENULL;
+  if (D != 32) return YMI_ESHAPE;  // cfg.mask_dim of every shipped config (data/config.py:691)
+  if (ph <= 0 || pw <= 0 || N <= 0 || N > 1024) return YMI_EARG;
+  const int npix = ph * pw;
+  const int grid = (npix + 127) / 128;
+  const size_t lds = (size_t)((N + 31) / 32) * 32 * 4 * sizeof(float);
+  hipLaunchKernelGGL(lincomb_crop_k<32>, dim3(grid), dim3(256), lds, (hipStream_t)stream, proto, coef, box, masks_lo,
+                     ph, pw, N, crop);
+  return ymi_launch_status();
+}
+
+int ymi_mask_upsample_f32(const float *masks_lo, float *out, int N, int ph, int pw, int h, int w, float thresh,
+                          void *stream) {
+  if (!masks_lo || !out) return YMI_ENULL;
+  if (N <= 0 || ph <= 0 || pw <= 0 || h <= 0 || w <= 0) return YMI_EARG;
+  const long total = (long)N * h * w, total4 = (total + 3) / 4;
+  long g = (total4 + 255) / 256;
+  const long cap = 256L * 16;
+  const int grid = (int)(g > cap ? cap : g);
+  hipLaunchKernelGGL(mask_upsample_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, masks_lo, out, ph, pw, h, w,
+                     (float)ph / (float)h, (float)pw / (float)w, thresh, total4, total);
+  return ymi_launch_status();
+}
+
+int ymi_boxes_to_pixels(const float *box, int64_t *out, int N, int w, int h, void *stream) {
+  if (!box || !out) return YMI_ENULL;
+  if (N <= 0) return YMI_EARG;
+  hipLaunchKernelGGL(boxes_to_pixels_k, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, box, (long long *)out, N,
+                     w, h);
+  return ymi_launch_status();
+}
+
+}  // extern "C"
