@@ -1,0 +1,52 @@
+"""Pins the CPU oracle (oracle/yolact_oracle.py) against outputs of the reference itself (tests/golden/, written
+by oracle/make_golden.py from /root/reference).  CPU only."""
+import pytest
+import torch
+
+from helpers import ALL_CASES, check_digest, load_golden, match_detections, oracle_run, unpack_masks
+
+
+@pytest.mark.parametrize('name', ALL_CASES)
+def test_forward_stages_match_reference(name):
+    meta, arrays, cfg, sd, raw, dets = oracle_run(name)
+    for k, t in raw['stages'].items():
+        check_digest(t.permute(0, 2, 3, 1), meta, arrays, k, rtol=2e-5, atol=2e-5)
+    for k in ('loc', 'conf', 'mask', 'priors', 'proto'):
+        check_digest(raw[k], meta, arrays, k, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize('name', ALL_CASES)
+def test_detect_matches_reference(name):
+    meta, arrays, cfg, sd, raw, dets = oracle_run(name)
+    for b in range(meta['B']):
+        n = meta['n'][b]
+        if n == 0:
+            assert dets[b] is None
+            continue
+        ref = {k: torch.from_numpy(arrays['det%d_%s' % (b, k)]) for k in ('box', 'mask', 'class', 'score')}
+        problems = match_detections(dets[b], ref, score_tol=1e-6, box_tol=1e-6, coef_tol=1e-6)
+        assert not problems, problems[:5]
+
+
+@pytest.mark.parametrize('name', ALL_CASES)
+def test_postprocess_matches_reference(name):
+    from oracle import yolact_oracle as O
+    meta, arrays, cfg, sd, raw, dets = oracle_run(name)
+    w, h = meta['post']
+    for b in range(meta['B']):
+        if meta['n'][b] == 0:
+            assert O.postprocess(dets[b], w, h, cfg, sd) is None
+            continue
+        classes, scores, boxes, masks, soft = O.postprocess(dets[b], w, h, cfg, sd, return_soft=True)
+        assert torch.equal(classes, torch.from_numpy(arrays['post%d_class' % b]))
+        assert torch.equal(boxes, torch.from_numpy(arrays['post%d_box' % b]))
+        if isinstance(scores, list):
+            assert torch.allclose(scores[0], torch.from_numpy(arrays['post%d_score' % b]), atol=1e-6)
+            assert torch.allclose(scores[1], torch.from_numpy(arrays['post%d_score2' % b]), atol=1e-5)
+        else:
+            assert torch.allclose(scores, torch.from_numpy(arrays['post%d_score' % b]), atol=1e-6)
+        ref = unpack_masks(arrays, b, meta['n'][b], h, w)
+        bad = (masks != ref)
+        # a binarised pixel may only flip where the soft value sits on the 0.5 threshold
+        assert (soft[bad] - 0.5).abs().max().item() < 1e-5 if bad.any() else True
+        assert bad.float().mean().item() < 1e-5

@@ -1,0 +1,113 @@
+"""ctypes binding of libyolact_amd.so (the C ABI declared in include/yolact_amd.h).
+
+The product path has NO fallback: if the HIP library is missing or a call fails, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libyolact_amd.so')
+
+ABI_VERSION = 1
+
+ACT_NONE, ACT_RELU, ACT_LEAKY01, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
+RES_NONE, RES_ADD, RES_BILINEAR = 0, 1, 2
+TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32, TILE_64x128 = 0, 1, 2, 3, 4, 5
+TILE_NAMES = {1: '128x128', 2: '128x64', 3: '64x64', 4: '128x32', 5: '64x128'}
+
+
+class ConvSeg(C.Structure):
+    _fields_ = [('n0', C.c_int32), ('n1', C.c_int32), ('act', C.c_int32), ('row_stride', C.c_int32),
+                ('batch_stride', C.c_int64), ('ptr', C.c_void_p)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('w', C.c_void_p), ('scale', C.c_void_p), ('bias', C.c_void_p),
+                ('res', C.c_void_p),
+                ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('Cin', C.c_int32), ('ldx', C.c_int32),
+                ('Ho', C.c_int32), ('Wo', C.c_int32), ('Cout', C.c_int32),
+                ('kh', C.c_int32), ('kw', C.c_int32), ('stride', C.c_int32), ('pad', C.c_int32),
+                ('Kpad', C.c_int32), ('res_mode', C.c_int32), ('res_ld', C.c_int32),
+                ('res_H', C.c_int32), ('res_W', C.c_int32), ('res_after_act', C.c_int32),
+                ('nseg', C.c_int32), ('tile', C.c_int32), ('seg', ConvSeg * 3)]
+
+
+class DcnDesc(C.Structure):
+    _fields_ = [('conv', ConvDesc), ('offmask', C.c_void_p), ('ldo', C.c_int32)]
+
+
+class DetectDesc(C.Structure):
+    _fields_ = [('conf', C.c_void_p), ('loc', C.c_void_p), ('coef', C.c_void_p), ('priors', C.c_void_p),
+                ('B', C.c_int32), ('P', C.c_int32), ('C', C.c_int32), ('D', C.c_int32),
+                ('conf_is_logits', C.c_int32), ('top_k', C.c_int32), ('max_det', C.c_int32),
+                ('conf_thresh', C.c_float), ('nms_thresh', C.c_float), ('cross_class', C.c_int32),
+                ('scores_t', C.c_void_p), ('keep', C.c_void_p), ('num_keep', C.c_void_p),
+                ('maxsc', C.c_void_p), ('argmax', C.c_void_p),
+                ('cand_score', C.c_void_p), ('cand_prior', C.c_void_p),
+                ('out_count', C.c_void_p), ('out_box', C.c_void_p), ('out_score', C.c_void_p),
+                ('out_class', C.c_void_p), ('out_coef', C.c_void_p), ('out_prior', C.c_void_p)]
+
+
+# every symbol include/yolact_amd.h declares: (name, restype, argtypes)
+_P, _I, _F = C.c_void_p, C.c_int, C.c_float
+SYMBOLS = [
+    ('ymi_abi_version', C.c_int, []),
+    ('ymi_strerror', C.c_char_p, [C.c_int]),
+    ('ymi_conv2d_nhwc_f32', C.c_int, [C.POINTER(ConvDesc), _P]),
+    ('ymi_conv_flops', C.c_double, [C.POINTER(ConvDesc)]),
+    ('ymi_conv_pick_tile', C.c_int, [C.POINTER(ConvDesc)]),
+    ('ymi_nchw_to_nhwc4_f32', C.c_int, [_P, _P, _I, _I, _I, _I, _P]),
+    ('ymi_nhwc_to_nchw_f32', C.c_int, [_P, _P, _I, _I, _I, _I, _P]),
+    ('ymi_maxpool3x3s2_nhwc_f32', C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    ('ymi_bilinear_nhwc_f32', C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _I, _P]),
+    ('ymi_detect_f32', C.c_int, [C.POINTER(DetectDesc), _P]),
+    ('ymi_lincomb_crop_f32', C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    ('ymi_mask_upsample_f32', C.c_int, [_P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    ('ymi_boxes_to_pixels', C.c_int, [_P, _P, _I, _I, _I, _P]),
+    ('ymi_dcn_v2_forward_f32', C.c_int, [C.POINTER(DcnDesc), _P]),
+    ('ymi_prof_enable', C.c_int, [_I]),
+    ('ymi_prof_count', C.c_int, []),
+    ('ymi_prof_read', C.c_int, [_I, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int32),
+                                C.POINTER(C.c_int32)]),
+    ('ymi_prof_reset', C.c_int, []),
+]
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the HIP library; loud failure if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                'yolact_amd: HIP library %s not found. Build it with `python -c "import __graft_entry__ as g; '
+                'g.build()"` or `make -C yolact_amd/csrc`. There is no CPU fallback.' % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(l, name)   # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        if l.ymi_abi_version() != ABI_VERSION:
+            raise RuntimeError('yolact_amd: ABI mismatch: library %d, binding %d' % (l.ymi_abi_version(), ABI_VERSION))
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = ''):
+    if rc != 0:
+        msg = lib().ymi_strerror(rc).decode()
+        raise RuntimeError('yolact_amd: %s failed: %s (code %d)' % (what or 'call', msg, rc))
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(t, name='tensor'):
+    if not t.is_cuda:
+        raise RuntimeError('yolact_amd: %s must live on the GPU (MI355X/HIP); there is no CPU path in the product '
+                           '(the CPU oracle lives under oracle/ and is test-only)' % name)

@@ -1,0 +1,397 @@
+"""Execution plan for the HIP forward pass: weight packing, activation arena, op list.
+
+A plan is built once per (batch, height, width): every convolution becomes one `ymi_conv_desc` with all
+pointers/strides resolved, activations live in a small arena of reusable device buffers (NHWC), and the
+forward pass is a flat loop of C-ABI calls on the current HIP stream — no Python tensor math, no host
+synchronisation.  PyTorch is used for device memory only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from .config import act_name, make_priors_host
+from . import modules as M
+
+
+def _ceil(a, b):
+    return (a + b - 1) // b * b
+
+
+class Packed:
+    """A convolution's filters in the engine layout [CoutPad][Kpad] (k = (ky*kw+kx)*Cin + c) + folded epilogue."""
+
+    def __init__(self, weight, bias=None, bn: Optional[nn.BatchNorm2d] = None, stride=1, pad=0, cin_pad=None,
+                 device=None):
+        weight = weight.detach().to(torch.float32)
+        Cout, Cin, kh, kw = weight.shape
+        cin_p = cin_pad or Cin
+        w = weight.permute(0, 2, 3, 1)
+        if cin_p != Cin:
+            w = torch.nn.functional.pad(w, (0, cin_p - Cin))
+        K = kh * kw * cin_p
+        self.Kpad, self.CoutPad = _ceil(K, 32), _ceil(Cout, 128)
+        wp = torch.zeros(self.CoutPad, self.Kpad, dtype=torch.float32, device=weight.device)
+        wp[:Cout, :K] = w.reshape(Cout, K)
+        self.w = wp.to(device).contiguous()
+        self.Cin, self.Cout, self.kh, self.kw, self.stride, self.pad = cin_p, Cout, kh, kw, stride, pad
+        scale = shift = None
+        if bn is not None:
+            # torch's eval BatchNorm: alpha = gamma * rsqrt(var + eps); y = x*alpha + (beta - mean*alpha), fp32
+            invstd = 1.0 / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+            scale = bn.weight.detach().float() * invstd
+            shift = bn.bias.detach().float() - bn.running_mean.detach().float() * scale
+            if bias is not None:
+                shift = shift + bias.detach().float() * scale
+        elif bias is not None:
+            shift = bias.detach().float()
+        self.scale = scale.to(device).contiguous() if scale is not None else None
+        self.bias = shift.to(device).contiguous() if shift is not None else None
+
+
+def pack_module(conv: nn.Conv2d, bn=None, device=None, cin_pad=None) -> Packed:
+    assert conv.dilation == (1, 1) and conv.groups == 1
+    assert conv.stride[0] == conv.stride[1] and conv.padding[0] == conv.padding[1]
+    return Packed(conv.weight, conv.bias, bn, conv.stride[0], conv.padding[0], cin_pad, device)
+
+
+class T:
+    """An NHWC activation living in an arena buffer."""
+    __slots__ = ('buf', 'B', 'H', 'W', 'C')
+
+    def __init__(self, buf, B, H, W, C):
+        self.buf, self.B, self.H, self.W, self.C = buf, B, H, W, C
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr()
+
+    def view(self):
+        return self.buf[: self.B * self.H * self.W * self.C].view(self.B, self.H, self.W, self.C)
+
+
+class Arena:
+    """Best-fit reuse of device buffers; ops run in program order on one stream so reuse is race-free.
+    Keeps the working set small enough to sit in the 256 MB Infinity Cache between layers."""
+
+    def __init__(self, device):
+        self.device = device
+        self.free_list: List[torch.Tensor] = []
+        self.all: List[torch.Tensor] = []
+
+    def alloc(self, numel) -> torch.Tensor:
+        best = None
+        for i, b in enumerate(self.free_list):
+            if b.numel() >= numel and (best is None or b.numel() < self.free_list[best].numel()):
+                best = i
+        if best is not None:
+            return self.free_list.pop(best)
+        b = torch.empty(numel, dtype=torch.float32, device=self.device)
+        self.all.append(b)
+        return b
+
+    def free(self, t):
+        if isinstance(t, _Borrowed):
+            return  # owned by someone else (a stage output the FPN still needs)
+        buf = t.buf if isinstance(t, T) else t
+        assert all(buf is not f for f in self.free_list)
+        self.free_list.append(buf)
+
+    def total_bytes(self):
+        return sum(b.numel() * 4 for b in self.all)
+
+
+def out_size(n, k, s, p):
+    return (n + 2 * p - k) // s + 1
+
+
+class Plan:
+    def __init__(self, net, B, H, W, device):
+        self.net, self.B, self.H, self.W, self.device = net, B, H, W, device
+        self.ops = []          # (callable, args...) executed in order
+        self.conv_meta = []    # (name, desc) for profiling / roofline accounting
+        self.arena = Arena(device)
+        self.keepalive = []
+        self.lib = L.lib()
+        self._build()
+
+    # ---- op emitters ---------------------------------------------------------------------------
+    def _new(self, B, H, W, C) -> T:
+        return T(self.arena.alloc(B * H * W * C), B, H, W, C)
+
+    def conv(self, name, x: T, pk: Packed, act=L.ACT_NONE, res: Optional[T] = None, res_mode=L.RES_NONE,
+             res_after_act=0, out: Optional[T] = None, segs=None, dcn_offmask: Optional[T] = None) -> Optional[T]:
+        """Emit one fused convolution. `segs`: list of (n0, n1, act, row_stride, batch_stride, ptr) overrides the
+        single dense NHWC output."""
+        assert x.C == pk.Cin, (name, x.C, pk.Cin)
+        Ho, Wo = out_size(x.H, pk.kh, pk.stride, pk.pad), out_size(x.W, pk.kw, pk.stride, pk.pad)
+        d = L.ConvDesc()
+        d.x, d.w = x.ptr, pk.w.data_ptr()
+        d.scale = pk.scale.data_ptr() if pk.scale is not None else None
+        d.bias = pk.bias.data_ptr() if pk.bias is not None else None
+        d.B, d.H, d.W, d.Cin, d.ldx = x.B, x.H, x.W, pk.Cin, x.C
+        d.Ho, d.Wo, d.Cout = Ho, Wo, pk.Cout
+        d.kh, d.kw, d.stride, d.pad, d.Kpad = pk.kh, pk.kw, pk.stride, pk.pad, pk.Kpad
+        d.res_mode = res_mode
+        d.res_after_act = res_after_act
+        if res is not None:
+            d.res, d.res_ld, d.res_H, d.res_W = res.ptr, res.C, res.H, res.W
+            if res_mode == L.RES_ADD:
+                assert (res.B, res.H, res.W, res.C) == (x.B, Ho, Wo, pk.Cout), name
+        d.tile = L.TILE_AUTO
+        y = None
+        if segs is None:
+            y = out if out is not None else self._new(x.B, Ho, Wo, pk.Cout)
+            d.nseg = 1
+            d.seg[0] = L.ConvSeg(0, pk.Cout, act, pk.Cout, Ho * Wo * pk.Cout, y.ptr)
+        else:
+            d.nseg = len(segs)
+            for i, s in enumerate(segs):
+                d.seg[i] = L.ConvSeg(*s)
+        self.keepalive.append(pk)
+        if dcn_offmask is not None:
+            dd = L.DcnDesc()
+            dd.conv = d
+            dd.offmask, dd.ldo = dcn_offmask.ptr, dcn_offmask.C
+            self.ops.append((self.lib.ymi_dcn_v2_forward_f32, C.pointer(dd), name))
+            self.conv_meta.append((name, dd.conv))
+        else:
+            self.ops.append((self.lib.ymi_conv2d_nhwc_f32, C.pointer(d), name))
+            self.conv_meta.append((name, d))
+        return y
+
+    def call(self, fn, *args, name=''):
+        self.ops.append((fn, args, name))
+
+    # ---- graph construction --------------------------------------------------------------------
+    def _build(self):
+        net, B, H, W, dev = self.net, self.B, self.H, self.W, self.device
+        cfg = net.cfg
+        lib = self.lib
+        ar = self.arena
+
+        # input: NCHW fp32 -> NHWC with C padded to 4 (pointer patched per call)
+        x4 = self._new(B, H, W, 4)
+        self.in_args = [None, x4.ptr, B, 3, H, W]
+        self.ops.append(('input', None, 'nchw_to_nhwc4'))
+
+        bb = net.backbone
+        if isinstance(bb, M.ResNetBackbone):
+            outs = self._resnet(bb, x4)
+        else:
+            outs = self._darknet(bb, x4)
+        sel = [outs[i] for i in net.backbone_selected]
+        for i, t in enumerate(outs):
+            if i not in net.backbone_selected and t is not None:
+                ar.free(t)
+
+        # FPN (yolact.py:319-361)
+        fpn = net.fpn
+        n = len(sel)
+        sums = [None] * n
+        prev = None
+        for i in range(n):
+            j = n - 1 - i
+            pk = pack_module(fpn.lat_layers[i], device=dev)
+            if prev is None:
+                sums[j] = self.conv('fpn.lat%d' % i, sel[j], pk)
+            else:
+                sums[j] = self.conv('fpn.lat%d' % i, sel[j], pk, res=prev, res_mode=L.RES_BILINEAR)
+            prev = sums[j]
+        for t in sel:
+            ar.free(t)
+        feats = [None] * n
+        for i in range(n):
+            j = n - 1 - i
+            feats[j] = self.conv('fpn.pred%d' % i, sums[j], pack_module(fpn.pred_layers[i], device=dev), act=L.ACT_RELU)
+        for t in sums:
+            ar.free(t)
+        for i, m in enumerate(fpn.downsample_layers):
+            feats.append(self.conv('fpn.down%d' % i, feats[-1], pack_module(m, device=dev)))
+        self.feat_shapes = [(t.H, t.W) for t in feats]
+
+        # protonet (utils/functions.py:163-213 + yolact.py:588-599); the last conv writes the per-call proto tensor
+        t = feats[net.proto_src]
+        mods = list(net.proto_net)
+        conv_idx = [i for i, m in enumerate(mods) if isinstance(m, nn.Conv2d)]
+        self.proto_patch = None
+        first = True
+        for i, m in enumerate(mods):
+            if isinstance(m, nn.Conv2d):
+                last = i == conv_idx[-1]
+                has_relu = (i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU))
+                if last:
+                    a = {'relu': L.ACT_RELU, 'none': L.ACT_NONE, 'sigmoid': L.ACT_SIGMOID, 'tanh': L.ACT_TANH}[
+                        act_name(cfg.mask_proto_prototype_activation)]
+                    assert not has_relu
+                else:
+                    a = L.ACT_RELU if has_relu else L.ACT_NONE
+                pk = pack_module(m, device=dev)
+                if last:
+                    Ho, Wo = out_size(t.H, pk.kh, pk.stride, pk.pad), out_size(t.W, pk.kw, pk.stride, pk.pad)
+                    self.proto_shape = (B, Ho, Wo, pk.Cout)
+                    self.conv('proto.%d' % i, t, pk, segs=[(0, pk.Cout, a, pk.Cout, Ho * Wo * pk.Cout, None)])
+                    self.proto_patch = self.ops[-1][1].contents  # seg[0].ptr set per call
+                    nt = None
+                else:
+                    nt = self.conv('proto.%d' % i, t, pk, act=a)
+                if not first:
+                    ar.free(t)
+                first = False
+                t = nt
+            elif isinstance(m, M.InterpolateModule):
+                s = int(m.scale_factor)
+                has_relu = (i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU))
+                y = self._new(t.B, t.H * s, t.W * s, t.C)
+                self.call(lib.ymi_bilinear_nhwc_f32, t.ptr, y.ptr, t.B, t.H, t.W, t.C, y.H, y.W,
+                          C.c_float(1.0 / s), C.c_float(1.0 / s), 1 if has_relu else 0, name='proto.interp')
+                if not first:
+                    ar.free(t)
+                first = False
+                t = y
+        assert self.proto_patch is not None
+
+        # prediction heads (yolact.py:133-212), shared weights, one merged GEMM per level writing straight into
+        # the level-concatenated [B,P,k] tensors
+        pm = net.prediction_layers[0]
+        A = pm.num_priors
+        Ccls, D = cfg.num_classes, net.mask_dim
+        cells = [h * w for h, w in self.feat_shapes]
+        P = sum(cells) * A
+        self.P, self.A, self.D, self.Ccls = P, A, D, Ccls
+        self.loc = torch.empty(B, P, 4, device=dev)
+        self.conf = torch.empty(B, P, Ccls, device=dev)
+        self.coef = torch.empty(B, P, D, device=dev)
+        up_pk = [pack_module(m, device=dev) for m in pm.upfeature if isinstance(m, nn.Conv2d)] \
+            if hasattr(pm, 'upfeature') else []
+        wcat = torch.cat([pm.bbox_layer.weight, pm.conf_layer.weight, pm.mask_layer.weight], 0)
+        bcat = torch.cat([pm.bbox_layer.bias, pm.conf_layer.bias, pm.mask_layer.bias], 0)
+        hp = pm.bbox_layer
+        head_pk = Packed(wcat, bcat, None, hp.stride[0], hp.padding[0], None, dev)
+        coef_act = {'tanh': L.ACT_TANH, 'sigmoid': L.ACT_SIGMOID, 'relu': L.ACT_RELU, 'none': L.ACT_NONE}[
+            act_name(cfg.mask_proto_coeff_activation)]
+        n_b, n_c, n_m = A * 4, A * Ccls, A * D
+        off = 0
+        pri = []
+        bbc = cfg.backbone
+        for lvl, f in enumerate(feats):
+            u = f
+            for k, pk in enumerate(up_pk):
+                nu = self.conv('head%d.up%d' % (lvl, k), u, pk, act=L.ACT_RELU)
+                if u is not f:
+                    ar.free(u)
+                u = nu
+            segs = [
+                (0, n_b, L.ACT_NONE, n_b, P * 4, self.loc.data_ptr() + off * 4 * 4),
+                (n_b, n_b + n_c, L.ACT_NONE, n_c, P * Ccls, self.conf.data_ptr() + off * Ccls * 4),
+                (n_b + n_c, n_b + n_c + n_m, coef_act, n_m, P * D, self.coef.data_ptr() + off * D * 4),
+            ]
+            self.conv('head%d.out' % lvl, u, head_pk, segs=segs)
+            if u is not f:
+                ar.free(u)
+            off += f.H * f.W * A
+            pri += make_priors_host(f.H, f.W, bbc.pred_scales[lvl], bbc.pred_aspect_ratios[lvl], cfg.max_size, bbc)
+        for f in feats:
+            ar.free(f)
+        self.priors = torch.tensor(pri, dtype=torch.float32).view(-1, 4).to(dev)
+        assert self.priors.shape[0] == P
+
+    def _resnet(self, bb: M.ResNetBackbone, x4: T):
+        dev, ar, lib = self.device, self.arena, self.lib
+        stem = self.conv('stem', x4, pack_module(bb.conv1, bb.bn1, dev, cin_pad=4), act=L.ACT_RELU)
+        ar.free(x4)
+        Hp, Wp = out_size(stem.H, 3, 2, 1), out_size(stem.W, 3, 2, 1)
+        x = self._new(stem.B, Hp, Wp, stem.C)
+        self.call(lib.ymi_maxpool3x3s2_nhwc_f32, stem.ptr, x.ptr, stem.B, stem.H, stem.W, stem.C, Hp, Wp, name='maxpool')
+        ar.free(stem)
+        outs = []
+        for li, layer in enumerate(bb.layers):
+            for bi, blk in enumerate(layer):
+                nm = 'layer%d.%d' % (li, bi)
+                o1 = self.conv(nm + '.conv1', x, pack_module(blk.conv1, blk.bn1, dev), act=L.ACT_RELU)
+                if blk.use_dcn:
+                    dcn = blk.conv2
+                    om = self.conv(nm + '.offmask', o1, pack_module(dcn.conv_offset_mask, None, dev))
+                    pk = Packed(dcn.weight, dcn.bias, blk.bn2, dcn.stride, 1, None, dev)
+                    o2 = self.conv(nm + '.dcn', o1, pk, act=L.ACT_RELU, dcn_offmask=om)
+                    ar.free(om)
+                else:
+                    o2 = self.conv(nm + '.conv2', o1, pack_module(blk.conv2, blk.bn2, dev), act=L.ACT_RELU)
+                ar.free(o1)
+                if blk.downsample is not None:
+                    res = self.conv(nm + '.down', x, pack_module(blk.downsample[0], blk.downsample[1], dev))
+                else:
+                    res = x
+                y = self.conv(nm + '.conv3', o2, pack_module(blk.conv3, blk.bn3, dev), act=L.ACT_RELU, res=res,
+                              res_mode=L.RES_ADD)
+                ar.free(o2)
+                if res is not x:
+                    ar.free(res)
+                ar.free(x)
+                x = y
+            # stage output: still needed by the FPN, so the next stage only borrows it
+            outs.append(x)
+            x = _Borrowed(x)
+        return outs
+
+    def _darknet(self, bb: M.DarkNetBackbone, x4: T):
+        dev, ar = self.device, self.arena
+
+        def unit(name, t, seq, cin_pad=None, res=None):
+            pk = pack_module(seq[0], seq[1], dev, cin_pad=cin_pad)
+            if res is None:
+                return self.conv(name, t, pk, act=L.ACT_LEAKY01)
+            return self.conv(name, t, pk, act=L.ACT_LEAKY01, res=res, res_mode=L.RES_ADD, res_after_act=1)
+
+        x = unit('preconv', x4, bb._preconv, cin_pad=4)
+        ar.free(x4)
+        outs = []
+        for li, layer in enumerate(bb.layers):
+            mods = list(layer)
+            y = unit('dark%d.down' % li, x, mods[0])
+            ar.free(x)
+            x = y
+            for bi, blk in enumerate(mods[1:]):
+                a = unit('dark%d.%d.conv1' % (li, bi), x, blk.conv1)
+                y = unit('dark%d.%d.conv2' % (li, bi), a, blk.conv2, res=x)
+                ar.free(a)
+                ar.free(x)
+                x = y
+            outs.append(x)
+            x = _Borrowed(x)
+        return outs
+
+    # ---- execution -------------------------------------------------------------------------------
+    def run(self, x: torch.Tensor):
+        """x [B,3,H,W] fp32 contiguous on the plan's device. Returns the fresh proto tensor; loc/conf/coef are the
+        plan's persistent head buffers (consumed by Detect before the next forward)."""
+        lib = self.lib
+        s = L.stream_ptr()
+        proto = torch.empty(self.proto_shape, dtype=torch.float32, device=self.device)
+        self.proto_patch.seg[0].ptr = proto.data_ptr()
+        for fn, args, name in self.ops:
+            if fn == 'input':
+                a = self.in_args
+                rc = lib.ymi_nchw_to_nhwc4_f32(x.data_ptr(), a[1], a[2], a[3], a[4], a[5], s)
+            elif isinstance(args, tuple):
+                rc = fn(*args, s)
+            else:
+                rc = fn(args, s)
+            if rc != 0:
+                L.check(rc, name)
+        return proto
+
+    def conv_flops(self):
+        return sum(self.lib.ymi_conv_flops(C.byref(d)) for _, d in self.conv_meta)
+
+
+class _Borrowed(T):
+    """A stage output that is still needed later (FPN input): the consuming block must not free it."""
+    __slots__ = ()
+
+    def __init__(self, t: T):
+        super().__init__(t.buf, t.B, t.H, t.W, t.C)

@@ -1,0 +1,57 @@
+"""The box helpers eval.py imports from layers.box_utils (eval.py:4): jaccard, center_size, mask_iou, plus
+crop / sanitize_coordinates.  These run in eval.py's metric code, downstream of the hot path,
+on whatever device the caller's tensors live; they are thin torch expressions with the reference's op order
+(box_utils.py:20-113, :327-373) — plumbing, not the accelerated path.
+"""
+import torch
+
+
+def center_size(boxes):
+    return torch.cat(((boxes[:, 2:] + boxes[:, :2]) / 2, boxes[:, 2:] - boxes[:, :2]), 1)
+
+
+def point_form(boxes):
+    return torch.cat((boxes[:, :2] - boxes[:, 2:] / 2, boxes[:, :2] + boxes[:, 2:] / 2), 1)
+
+
+def intersect(box_a, box_b):
+    mx = torch.min(box_a[:, :, None, 2:], box_b[:, None, :, 2:])
+    mn = torch.max(box_a[:, :, None, :2], box_b[:, None, :, :2])
+    return torch.clamp(mx - mn, min=0).prod(3)
+
+
+def jaccard(box_a, box_b, iscrowd: bool = False):
+    use_batch = box_a.dim() == 3
+    if not use_batch:
+        box_a, box_b = box_a[None], box_b[None]
+    inter = intersect(box_a, box_b)
+    area_a = ((box_a[:, :, 2] - box_a[:, :, 0]) * (box_a[:, :, 3] - box_a[:, :, 1])).unsqueeze(2).expand_as(inter)
+    area_b = ((box_b[:, :, 2] - box_b[:, :, 0]) * (box_b[:, :, 3] - box_b[:, :, 1])).unsqueeze(1).expand_as(inter)
+    out = inter / area_a if iscrowd else inter / (area_a + area_b - inter)
+    return out if use_batch else out.squeeze(0)
+
+
+def mask_iou(masks_a, masks_b, iscrowd=False):
+    a = masks_a.reshape(masks_a.size(0), -1)
+    b = masks_b.reshape(masks_b.size(0), -1)
+    inter = a @ b.t()
+    area_a, area_b = a.sum(1).unsqueeze(1), b.sum(1).unsqueeze(0)
+    return inter / (area_a + area_b - inter) if not iscrowd else inter / area_a
+
+
+def sanitize_coordinates(_x1, _x2, img_size: int, padding: int = 0, cast: bool = True):
+    _x1, _x2 = _x1 * img_size, _x2 * img_size
+    if cast:
+        _x1, _x2 = _x1.long(), _x2.long()
+    x1, x2 = torch.min(_x1, _x2), torch.max(_x1, _x2)
+    return torch.clamp(x1 - padding, min=0), torch.clamp(x2 + padding, max=img_size)
+
+
+def crop(masks, boxes, padding: int = 1):
+    h, w, n = masks.size()
+    x1, x2 = sanitize_coordinates(boxes[:, 0], boxes[:, 2], w, padding, cast=False)
+    y1, y2 = sanitize_coordinates(boxes[:, 1], boxes[:, 3], h, padding, cast=False)
+    cols = torch.arange(w, device=masks.device, dtype=x1.dtype).view(1, -1, 1)
+    rows = torch.arange(h, device=masks.device, dtype=x1.dtype).view(-1, 1, 1)
+    inside = (cols >= x1.view(1, 1, -1)) & (cols < x2.view(1, 1, -1)) & (rows >= y1.view(1, 1, -1)) & (rows < y2.view(1, 1, -1))
+    return masks * inside.float()

@@ -1,0 +1,109 @@
+"""`Detect` — layers/functions/detection.py:11-78 on device.
+
+Same constructor, same flags (`use_fast_nms`, `use_cross_class_nms`, set by eval.py:871-872), same return
+structure.  The per-image Python loop, boolean-mask gathers and 80 sorts of the reference become three kernel
+launches for the whole batch (csrc/detect.hip) plus ONE device->host read of the per-image counts, which the
+reference's dynamic output shapes make unavoidable.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import sys
+import contextlib
+
+import torch
+
+from .. import _lib as L
+from ..config import active_cfg
+
+
+def _timer_env(name):
+    t = sys.modules.get('utils.timer')
+    return t.env(name) if (t is not None and hasattr(t, 'env')) else contextlib.nullcontext()
+
+
+class Detect(object):
+    def __init__(self, num_classes, bkg_label, top_k, conf_thresh, nms_thresh):
+        self.num_classes = num_classes
+        self.background_label = bkg_label
+        self.top_k = top_k
+        self.nms_thresh = nms_thresh
+        if nms_thresh <= 0:
+            raise ValueError('nms_threshold must be non negative.')   # detection.py:25-26
+        self.conf_thresh = conf_thresh
+        self.use_cross_class_nms = False
+        self.use_fast_nms = True   # the reference defaults to False and eval.py:871 turns it on; see __call__
+        self._ws = {}
+
+    def _workspace(self, B, P, C, D, cap, dev):
+        key = (B, P, C, D, cap, dev)
+        ws = self._ws.get(key)
+        if ws is None:
+            nfg = C - 1
+            ws = dict(
+                scores_t=torch.empty(B, nfg, P, device=dev), keep=torch.empty(B, P, dtype=torch.int32, device=dev),
+                num_keep=torch.zeros(B, dtype=torch.int32, device=dev), maxsc=torch.empty(B, P, device=dev),
+                argmax=torch.empty(B, P, dtype=torch.int32, device=dev),
+                cand_score=torch.empty(B, nfg * self.top_k, device=dev),
+                cand_prior=torch.empty(B, nfg * self.top_k, dtype=torch.int32, device=dev))
+            self._ws = {key: ws}
+        return ws
+
+    def run_device(self, loc, conf, mask, priors, conf_is_logits):
+        """Launch the Detect kernels; returns fixed-capacity device tensors (no host sync)."""
+        for name, t in (('loc', loc), ('conf', conf), ('mask', mask), ('priors', priors)):
+            L.require_cuda(t, name)
+        cfg = active_cfg()
+        B, P, Ccls = conf.shape
+        D = mask.shape[2]
+        dev = conf.device
+        max_det = int(cfg.max_num_detections)
+        cap = self.top_k if self.use_cross_class_nms else max_det
+        ws = self._workspace(B, P, Ccls, D, cap, dev)
+        out = dict(count=torch.empty(B, dtype=torch.int32, device=dev), box=torch.empty(B, cap, 4, device=dev),
+                   score=torch.empty(B, cap, device=dev), cls=torch.empty(B, cap, dtype=torch.int64, device=dev),
+                   coef=torch.empty(B, cap, D, device=dev), prior=torch.empty(B, cap, dtype=torch.int32, device=dev))
+        d = L.DetectDesc()
+        loc, conf, mask, priors = (t.contiguous() for t in (loc.float(), conf.float(), mask.float(), priors.float()))
+        d.conf, d.loc, d.coef, d.priors = conf.data_ptr(), loc.data_ptr(), mask.data_ptr(), priors.data_ptr()
+        d.B, d.P, d.C, d.D = B, P, Ccls, D
+        d.conf_is_logits = 1 if conf_is_logits else 0
+        d.top_k, d.max_det = int(self.top_k), max_det
+        d.conf_thresh, d.nms_thresh = float(self.conf_thresh), float(self.nms_thresh)
+        d.cross_class = 1 if self.use_cross_class_nms else 0
+        d.scores_t, d.keep, d.num_keep = ws['scores_t'].data_ptr(), ws['keep'].data_ptr(), ws['num_keep'].data_ptr()
+        d.maxsc, d.argmax = ws['maxsc'].data_ptr(), ws['argmax'].data_ptr()
+        d.cand_score, d.cand_prior = ws['cand_score'].data_ptr(), ws['cand_prior'].data_ptr()
+        d.out_count, d.out_box, d.out_score = out['count'].data_ptr(), out['box'].data_ptr(), out['score'].data_ptr()
+        d.out_class, d.out_coef, d.out_prior = out['cls'].data_ptr(), out['coef'].data_ptr(), out['prior'].data_ptr()
+        with torch.cuda.device(dev):
+            L.check(L.lib().ymi_detect_f32(C.byref(d), L.stream_ptr()), 'ymi_detect_f32')
+        out['_keepalive'] = (loc, conf, mask, priors)
+        return out
+
+    def __call__(self, predictions, net):
+        """predictions: 'loc' [B,P,4], 'conf' [B,P,C] post-softmax (reference contract) or 'conf_logits' (fused
+        softmax), 'mask' [B,P,D], 'priors' [P,4], optional 'proto' [B,ph,pw,D]."""
+        if not self.use_fast_nms:
+            raise NotImplementedError('traditional (Cython, CPU) NMS is outside the hot path; eval.py runs with '
+                                      '--fast_nms=True by default (SURVEY §2)')
+        if 'conf_logits' in predictions and 'conf' not in predictions:
+            conf, is_logits = predictions['conf_logits'], True
+        else:
+            conf, is_logits = predictions['conf'], False
+        proto = predictions.get('proto')
+        with _timer_env('Detect'):
+            o = self.run_device(predictions['loc'], conf, predictions['mask'], predictions['priors'], is_logits)
+            counts = o['count'].tolist()          # the one host sync per batch
+            out = []
+            for b, n in enumerate(counts):
+                if n == 0:
+                    out.append({'detection': None, 'net': net})
+                    continue
+                det = {'box': o['box'][b, :n], 'mask': o['coef'][b, :n], 'class': o['cls'][b, :n],
+                       'score': o['score'][b, :n]}
+                if proto is not None:
+                    det['proto'] = proto[b]
+                det['_prior'] = o['prior'][b, :n]
+                out.append({'detection': det, 'net': net})
+        return out

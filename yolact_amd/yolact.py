@@ -1,0 +1,177 @@
+"""`Yolact` — the reference's model class (yolact.py:379-676) re-hosted on the MI355X HIP engine.
+
+API kept: `Yolact()` reads the active config, `.load_weights/.save_weights`, `.forward(x[B,3,H,W])` in eval mode
+returns `[{'detection': {...}|None, 'net': self}] * B` exactly like the reference's `self.detect(pred_outs, self)`
+(yolact.py:676), `.detect.use_fast_nms / .use_cross_class_nms`, `.maskiou_net`, `.prediction_layers`, `.backbone`.
+State-dict keys/shapes equal the reference's, so its checkpoints load unchanged.
+
+Compute: none here.  forward() builds (once per input shape) an execution plan of C-ABI calls into
+libyolact_amd.so and replays it on the current HIP stream.  CPU tensors are rejected: there is no fallback.
+"""
+from __future__ import annotations
+
+import contextlib
+import sys
+import threading
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import modules as M
+from .config import active_cfg, backbone_kind, is_lincomb
+from .engine import Plan
+from .layers.detection import Detect
+
+
+def _timer_env(name):
+    """Use the reference's utils.timer sections (yolact.py:570-607) when eval.py has it loaded."""
+    t = sys.modules.get('utils.timer')
+    if t is not None and hasattr(t, 'env'):
+        return t.env(name)
+    return contextlib.nullcontext()
+
+
+class Yolact(nn.Module):
+    def __init__(self):
+        super().__init__()
+        cfg = active_cfg()
+        self.cfg = cfg
+        if not (is_lincomb(cfg) and cfg.eval_mask_branch):
+            raise NotImplementedError('only mask_type.lincomb configs are on the hot path (SURVEY §8)')
+        for flag in ('use_prediction_module', 'use_yolo_regressors', 'use_mask_scoring', 'use_instance_coeff',
+                     'use_focal_loss', 'use_objectness_score', 'mask_proto_use_grid', 'mask_proto_bias',
+                     'mask_proto_prototypes_as_features', 'mask_proto_split_prototypes_by_head',
+                     'mask_proto_coeff_gate'):
+            if cfg.get(flag, False) if isinstance(cfg, dict) else getattr(cfg, flag, False):
+                raise NotImplementedError('cfg.%s is not used by any shipped YOLACT config and is out of scope' % flag)
+        bb = cfg.backbone
+        kind = backbone_kind(bb)
+        args = list(bb.args)
+        if kind == 'resnet':
+            self.backbone = M.ResNetBackbone(*args)
+        else:
+            self.backbone = M.DarkNetBackbone(*args)
+        if cfg.freeze_bn:
+            pass  # eval-only engine: BatchNorm always uses running statistics
+
+        # protonet (yolact.py:408-425); writes cfg.mask_dim back like the reference
+        self.proto_src = cfg.mask_proto_src
+        if cfg.fpn is None or self.proto_src is None:
+            raise NotImplementedError('configs without an FPN / with image-sourced prototypes are out of scope')
+        self.proto_net, mask_dim = M.make_net(cfg.fpn.num_features, cfg.mask_proto_net, include_last_relu=False)
+        cfg.mask_dim = mask_dim
+        self.mask_dim = mask_dim
+
+        self.backbone_selected = list(bb.selected_layers)
+        src_channels = self.backbone.channels
+        if cfg.use_maskiou:
+            self.maskiou_net = M.FastMaskIoUNet(cfg.maskiou_net, cfg.num_classes)
+        self.fpn = M.FPN([src_channels[i] for i in self.backbone_selected], cfg.fpn.num_features,
+                         cfg.fpn.num_downsample, cfg.fpn.pad)
+        if not (cfg.fpn.use_conv_downsample and cfg.fpn.relu_pred_layers and not cfg.fpn.relu_downsample_layers
+                and cfg.fpn.interpolation_mode == 'bilinear'):
+            raise NotImplementedError('FPN variant outside the shipped configs')
+        self.selected_layers = list(range(len(self.backbone_selected) + cfg.fpn.num_downsample))
+        nf = cfg.fpn.num_features
+
+        self.prediction_layers = nn.ModuleList()
+        cfg.num_heads = len(self.selected_layers)
+        if not cfg.share_prediction_module:
+            raise NotImplementedError('unshared prediction modules are not used by any shipped config')
+        for idx in self.selected_layers:
+            ars, scales = bb.pred_aspect_ratios[idx], bb.pred_scales[idx]
+            num_priors = sum(len(a) * len(scales) for a in ars)
+            parent = self.prediction_layers[0] if idx > 0 else None
+            self.prediction_layers.append(M.PredictionModule(
+                nf, num_priors, cfg.num_classes, mask_dim, cfg.extra_head_net, dict(cfg.head_layer_params),
+                ars, scales, parent=parent, index=idx))
+        if cfg.use_semantic_segmentation_loss:
+            self.semantic_seg_conv = nn.Conv2d(nf, cfg.num_classes - 1, kernel_size=1)  # train-only, in checkpoints
+
+        self.detect = Detect(cfg.num_classes, bkg_label=0, top_k=cfg.nms_top_k, conf_thresh=cfg.nms_conf_thresh,
+                             nms_thresh=cfg.nms_thresh)
+        self._plans = {}
+        self._plan_lock = threading.Lock()
+        self.eval()
+
+    # ---- weights ---------------------------------------------------------------------------------------
+    def save_weights(self, path):
+        torch.save(self.state_dict(), path)
+
+    def load_weights(self, path):
+        """yolact.py:477-490: drop legacy `backbone.layer*` keys and surplus fpn.downsample_layers."""
+        sd = torch.load(path, map_location='cpu')
+        self.load_state_dict_compat(sd)
+
+    def load_state_dict_compat(self, sd):
+        sd = dict(sd)
+        for key in list(sd.keys()):
+            if key.startswith('backbone.layer') and not key.startswith('backbone.layers'):
+                del sd[key]
+            elif key.startswith('fpn.downsample_layers.'):
+                if int(key.split('.')[2]) >= self.cfg.fpn.num_downsample:
+                    del sd[key]
+        self.load_state_dict(sd)
+        self.invalidate_plans()
+
+    def invalidate_plans(self):
+        with self._plan_lock:
+            self._plans.clear()
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)   # .cuda()/.to(): packed filters must be rebuilt on the new device
+        if hasattr(self, '_plans'):
+            self._plans.clear()
+        return r
+
+    def init_weights(self, backbone_path):
+        raise NotImplementedError('training initialisation is out of scope (inference hot path only)')
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError('yolact_amd.Yolact is inference-only; training returns raw preds in the reference '
+                                      '(yolact.py:639-647) and is out of scope for this tier')
+        return super().train(False)
+
+    # ---- forward ---------------------------------------------------------------------------------------
+    def plan_for(self, x) -> Plan:
+        key = (tuple(x.shape), x.device)
+        p = self._plans.get(key)
+        if p is None:
+            with self._plan_lock:   # one-time setup is not thread-safe in the reference either (eval.py:793-796)
+                p = self._plans.get(key)
+                if p is None:
+                    B, _, H, W = x.shape
+                    with torch.no_grad():
+                        p = Plan(self, B, H, W, x.device)
+                    self._plans[key] = p
+        return p
+
+    def forward(self, x):
+        """x: float32 [B,3,H,W], normalised RGB (resnet_transform, data/config.py:181-186)."""
+        L.require_cuda(x, 'input batch')
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError('expected [B,3,H,W], got %s' % (tuple(x.shape),))
+        if next(self.parameters()).device != x.device:
+            raise RuntimeError('model and input live on different devices')
+        cfg = self.cfg
+        cfg._tmp_img_h, cfg._tmp_img_w = int(x.shape[2]), int(x.shape[3])
+        x = x.detach().to(torch.float32).contiguous()
+        with torch.cuda.device(x.device):
+            plan = self.plan_for(x)
+            with _timer_env('backbone'):
+                proto = plan.run(x)
+            preds = {'loc': plan.loc, 'conf_logits': plan.conf, 'mask': plan.coef, 'priors': plan.priors,
+                     'proto': proto}
+            return self.detect(preds, self)
+
+    def forward_raw(self, x):
+        """Head outputs before Detect (for parity tests): loc, conf (logits), mask, priors, proto — clones."""
+        L.require_cuda(x, 'input batch')
+        x = x.detach().to(torch.float32).contiguous()
+        with torch.cuda.device(x.device):
+            plan = self.plan_for(x)
+            proto = plan.run(x)
+            return {'loc': plan.loc.clone(), 'conf_logits': plan.conf.clone(), 'mask': plan.coef.clone(),
+                    'priors': plan.priors, 'proto': proto}
