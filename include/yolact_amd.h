@@ -58,6 +58,8 @@ typedef struct {
   int32_t res_after_act;/* 1: y = act(conv) + res (darknet block, backbone.py:214-215); 0: y = act(conv + res) */
   int32_t nseg;         /* 1..3 */
   int32_t tile;         /* 0 = auto; else YMI_TILE_* override (tests / tuning) */
+  int32_t cin_alg;      /* real (un-padded) input channels for FLOP accounting; 0 = Cin */
+  int32_t _pad0;
   ymi_conv_seg seg[3];
 } ymi_conv_desc;
 

@@ -1,0 +1,71 @@
+"""Helpers for the GPU parity tests: drive single kernels through the C ABI from torch tensors."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from yolact_amd import _lib as L
+from yolact_amd.engine import Packed, out_size
+
+DEV = 'cuda:0'
+
+
+def nhwc(x_nchw):
+    return x_nchw.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x_nhwc):
+    return x_nhwc.permute(0, 3, 1, 2).contiguous()
+
+
+def run_conv(x, weight, bias=None, bn=None, stride=1, pad=0, act=L.ACT_NONE, res=None, res_mode=L.RES_NONE,
+             res_after_act=0, tile=L.TILE_AUTO, cin_pad=None, dcn_offmask=None):
+    """x: CPU NCHW tensor. Returns CPU NCHW output of the HIP conv."""
+    pk = Packed(weight, bias, bn, stride, pad, cin_pad, DEV)
+    xn = nhwc(x)
+    if cin_pad and cin_pad != xn.shape[-1]:
+        xn = torch.nn.functional.pad(xn, (0, cin_pad - xn.shape[-1]))
+    xd = xn.to(DEV)
+    B, H, W, Cx = xd.shape
+    Ho, Wo = out_size(H, pk.kh, stride, pad), out_size(W, pk.kw, stride, pad)
+    y = torch.full((B, Ho, Wo, pk.Cout), float('nan'), device=DEV)
+    d = L.ConvDesc()
+    d.x, d.w = xd.data_ptr(), pk.w.data_ptr()
+    d.scale = pk.scale.data_ptr() if pk.scale is not None else None
+    d.bias = pk.bias.data_ptr() if pk.bias is not None else None
+    d.B, d.H, d.W, d.Cin, d.ldx = B, H, W, pk.Cin, Cx
+    d.Ho, d.Wo, d.Cout = Ho, Wo, pk.Cout
+    d.kh, d.kw, d.stride, d.pad, d.Kpad = pk.kh, pk.kw, stride, pad, pk.Kpad
+    d.res_mode, d.res_after_act = res_mode, res_after_act
+    rd = None
+    if res is not None:
+        rd = nhwc(res).to(DEV)
+        d.res, d.res_ld, d.res_H, d.res_W = rd.data_ptr(), rd.shape[3], rd.shape[1], rd.shape[2]
+    d.nseg, d.tile = 1, tile
+    d.seg[0] = L.ConvSeg(0, pk.Cout, act, pk.Cout, Ho * Wo * pk.Cout, y.data_ptr())
+    s = L.stream_ptr()
+    if dcn_offmask is not None:
+        om = nhwc(dcn_offmask).to(DEV)
+        dd = L.DcnDesc()
+        dd.conv = d
+        dd.offmask, dd.ldo = om.data_ptr(), om.shape[3]
+        L.check(L.lib().ymi_dcn_v2_forward_f32(C.byref(dd), s), 'dcn')
+    else:
+        L.check(L.lib().ymi_conv2d_nhwc_f32(C.byref(d), s), 'conv')
+    torch.cuda.synchronize()
+    return nchw(y.cpu())
+
+
+def rel_err(a, b):
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def build_net(meta, device=DEV):
+    import yolact_amd
+    from helpers import case_state_dict
+    yolact_amd.set_cfg(meta['config'])
+    from yolact_amd.yolact import Yolact
+    net = Yolact()
+    net.load_state_dict_compat(case_state_dict(meta))
+    return net.to(device)

@@ -1,0 +1,221 @@
+"""GPU parity of the individual HIP kernels (through the C ABI) against plain torch fp32 CPU references."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from yolact_amd import _lib as L  # noqa: E402
+
+
+def _g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+TILES = [L.TILE_128x128, L.TILE_128x64, L.TILE_64x128, L.TILE_64x64, L.TILE_128x32]
+
+
+@pytest.mark.parametrize('tile', TILES)
+@pytest.mark.parametrize('shape', [
+    # B, Cin, H, W, Cout, k, stride, pad
+    (2, 64, 19, 23, 96, 1, 1, 0),
+    (1, 32, 17, 13, 40, 3, 1, 1),
+    (2, 64, 21, 18, 130, 3, 2, 1),
+    (1, 128, 9, 9, 64, 1, 2, 0),
+    (3, 96, 5, 7, 351, 3, 1, 1),
+])
+def test_conv_plain(shape, tile):
+    from gpu_utils import run_conv, rel_err
+    B, Cin, H, W, Cout, k, s, p = shape
+    g = _g(B * 1000 + Cin + Cout + k)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    y = run_conv(x, w, b, None, s, p, tile=tile)
+    ref = F.conv2d(x, w, b, s, p)
+    assert y.shape == ref.shape
+    assert rel_err(y, ref) < 2e-5
+
+
+def test_conv_asymmetric_filter_detects_transposes():
+    """A = identity-like checks miss swapped roles; use a one-hot filter tap so every (ky,kx,c)->n route is unique."""
+    from gpu_utils import run_conv
+    Cin, Cout = 32, 64
+    x = torch.randn(1, Cin, 6, 5, generator=_g(5))
+    w = torch.zeros(Cout, Cin, 3, 3)
+    for n in range(Cout):
+        w[n, (n * 7) % Cin, (n // 3) % 3, n % 3] = 1.0 + n
+    y = run_conv(x, w, None, None, 1, 1)
+    assert torch.equal(y, F.conv2d(x, w, None, 1, 1))   # one product per output: exact
+
+
+def test_conv_bn_relu_residual():
+    from gpu_utils import run_conv, rel_err
+    import torch.nn as nn
+    g = _g(7)
+    x = torch.randn(2, 64, 14, 14, generator=g)
+    w = torch.randn(256, 64, 1, 1, generator=g) / 8
+    bn = nn.BatchNorm2d(256).eval()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(256, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(256, generator=g) * 0.1)
+        bn.running_mean.copy_(torch.randn(256, generator=g) * 0.1)
+        bn.running_var.copy_(torch.rand(256, generator=g) + 0.5)
+    res = torch.randn(2, 256, 14, 14, generator=g)
+    y = run_conv(x, w, None, bn, 1, 0, act=L.ACT_RELU, res=res, res_mode=L.RES_ADD)
+    with torch.no_grad():
+        ref = F.relu(bn(F.conv2d(x, w)) + res)
+    assert rel_err(y, ref) < 2e-5
+    # darknet form: act(conv) + res
+    y2 = run_conv(x, w, None, bn, 1, 0, act=L.ACT_LEAKY01, res=res, res_mode=L.RES_ADD, res_after_act=1)
+    with torch.no_grad():
+        ref2 = F.leaky_relu(bn(F.conv2d(x, w)), 0.1) + res
+    assert rel_err(y2, ref2) < 2e-5
+
+
+@pytest.mark.parametrize('sizes', [((18, 18), (35, 35)), ((35, 35), (69, 69)), ((5, 7), (9, 13))])
+def test_conv_fpn_bilinear_residual(sizes):
+    """lat conv + F.interpolate(prev, size) fused in the epilogue (yolact.py:331-335)."""
+    from gpu_utils import run_conv, rel_err
+    (hs, ws), (h, w_) = sizes
+    g = _g(hs * 100 + h)
+    x = torch.randn(2, 64, h, w_, generator=g)
+    w = torch.randn(256, 64, 1, 1, generator=g) / 8
+    b = torch.randn(256, generator=g)
+    prev = torch.randn(2, 256, hs, ws, generator=g)
+    y = run_conv(x, w, b, None, 1, 0, res=prev, res_mode=L.RES_BILINEAR)
+    ref = F.interpolate(prev, size=(h, w_), mode='bilinear', align_corners=False) + F.conv2d(x, w, b)
+    assert rel_err(y, ref) < 2e-5
+
+
+def test_conv_stem_7x7_c4_loader():
+    from gpu_utils import run_conv, rel_err
+    g = _g(11)
+    x = torch.randn(2, 3, 61, 47, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) / 12
+    y = run_conv(x, w, None, None, 2, 3, act=L.ACT_RELU, cin_pad=4)
+    ref = F.relu(F.conv2d(x, w, None, 2, 3))
+    assert rel_err(y, ref) < 2e-5
+    # darknet pre-conv: 3x3 / s1 / p1 on 3 channels
+    w3 = torch.randn(32, 3, 3, 3, generator=g) / 5
+    y3 = run_conv(x, w3, None, None, 1, 1, cin_pad=4)
+    assert rel_err(y3, F.conv2d(x, w3, None, 1, 1)) < 2e-5
+
+
+def test_conv_head_segments_and_tanh():
+    """One GEMM scattering to loc / conf / coef tensors with per-level offsets (yolact.py:169-173,633-634)."""
+    from gpu_utils import nhwc, DEV
+    from yolact_amd.engine import Packed
+    g = _g(13)
+    B, Cin, H, W, A, Ccls, D = 2, 64, 6, 5, 3, 81, 32
+    x = torch.randn(B, Cin, H, W, generator=g)
+    wb, wc, wm = (torch.randn(A * k, Cin, 3, 3, generator=g) / 24 for k in (4, Ccls, D))
+    bb, bc, bm = (torch.randn(A * k, generator=g) for k in (4, Ccls, D))
+    pk = Packed(torch.cat([wb, wc, wm]), torch.cat([bb, bc, bm]), None, 1, 1, None, DEV)
+    P, off = H * W * A + 17, 17
+    loc = torch.zeros(B, P, 4, device=DEV)
+    conf = torch.zeros(B, P, Ccls, device=DEV)
+    coef = torch.zeros(B, P, D, device=DEV)
+    xd = nhwc(x).to(DEV)
+    d = L.ConvDesc()
+    d.x, d.w, d.bias = xd.data_ptr(), pk.w.data_ptr(), pk.bias.data_ptr()
+    d.B, d.H, d.W, d.Cin, d.ldx, d.Ho, d.Wo, d.Cout = B, H, W, Cin, Cin, H, W, pk.Cout
+    d.kh, d.kw, d.stride, d.pad, d.Kpad = 3, 3, 1, 1, pk.Kpad
+    d.nseg = 3
+    n_b, n_c, n_m = A * 4, A * Ccls, A * D
+    d.seg[0] = L.ConvSeg(0, n_b, L.ACT_NONE, n_b, P * 4, loc.data_ptr() + off * 4 * 4)
+    d.seg[1] = L.ConvSeg(n_b, n_b + n_c, L.ACT_NONE, n_c, P * Ccls, conf.data_ptr() + off * Ccls * 4)
+    d.seg[2] = L.ConvSeg(n_b + n_c, n_b + n_c + n_m, L.ACT_TANH, n_m, P * D, coef.data_ptr() + off * D * 4)
+    L.check(L.lib().ymi_conv2d_nhwc_f32(C.byref(d), L.stream_ptr()), 'conv')
+    torch.cuda.synchronize()
+    rl = F.conv2d(x, wb, bb, 1, 1).permute(0, 2, 3, 1).reshape(B, -1, 4)
+    rc = F.conv2d(x, wc, bc, 1, 1).permute(0, 2, 3, 1).reshape(B, -1, Ccls)
+    rm = torch.tanh(F.conv2d(x, wm, bm, 1, 1).permute(0, 2, 3, 1).reshape(B, -1, D))
+    assert torch.allclose(loc.cpu()[:, off:], rl, atol=2e-5)
+    assert torch.allclose(conf.cpu()[:, off:], rc, atol=2e-5)
+    assert torch.allclose(coef.cpu()[:, off:], rm, atol=2e-5)
+    assert loc.cpu()[:, :off].abs().max() == 0      # nothing written before the level offset
+
+
+def test_conv_rejects_bad_arguments():
+    d = L.ConvDesc()
+    assert L.lib().ymi_conv2d_nhwc_f32(C.byref(d), None) == -3        # null pointers
+    assert L.lib().ymi_conv2d_nhwc_f32(None, None) == -3
+    with pytest.raises(RuntimeError, match='null'):
+        L.check(-3, 'x')
+
+
+def test_layout_pool_resize():
+    from gpu_utils import DEV, nhwc, nchw
+    lib, s = L.lib(), L.stream_ptr()
+    g = _g(17)
+    x = torch.randn(2, 3, 37, 29, generator=g)
+    xd = x.to(DEV)
+    y = torch.empty(2, 37, 29, 4, device=DEV)
+    L.check(lib.ymi_nchw_to_nhwc4_f32(xd.data_ptr(), y.data_ptr(), 2, 3, 37, 29, s))
+    assert torch.equal(y.cpu()[..., :3], nhwc(x)) and y.cpu()[..., 3].abs().max() == 0
+    a = torch.randn(2, 40, 21, 19, generator=g)
+    ad = nhwc(a).to(DEV)
+    back = torch.empty(2, 40, 21, 19, device=DEV)
+    L.check(lib.ymi_nhwc_to_nchw_f32(ad.data_ptr(), back.data_ptr(), 2, 40, 21, 19, s))
+    assert torch.equal(back.cpu(), a)
+    # maxpool 3x3/2/1 with -inf padding (all-negative input exercises the padding value)
+    m = -torch.rand(2, 64, 23, 31, generator=g) - 1
+    md = nhwc(m).to(DEV)
+    Ho, Wo = (23 + 2 - 3) // 2 + 1, (31 + 2 - 3) // 2 + 1
+    mo = torch.empty(2, Ho, Wo, 64, device=DEV)
+    L.check(lib.ymi_maxpool3x3s2_nhwc_f32(md.data_ptr(), mo.data_ptr(), 2, 23, 31, 64, Ho, Wo, s))
+    assert torch.equal(nchw(mo.cpu()), F.max_pool2d(m, 3, 2, 1))
+    # bilinear x2 (scale_factor form) + relu, and to-size form
+    u = torch.randn(2, 32, 13, 11, generator=g)
+    ud = nhwc(u).to(DEV)
+    uo = torch.empty(2, 26, 22, 32, device=DEV)
+    L.check(lib.ymi_bilinear_nhwc_f32(ud.data_ptr(), uo.data_ptr(), 2, 13, 11, 32, 26, 22, C.c_float(0.5), C.c_float(0.5), 1, s))
+    ref = F.relu(F.interpolate(u, scale_factor=2, mode='bilinear', align_corners=False))
+    assert torch.allclose(nchw(uo.cpu()), ref, atol=1e-6)
+    uo2 = torch.empty(2, 30, 17, 32, device=DEV)
+    L.check(lib.ymi_bilinear_nhwc_f32(ud.data_ptr(), uo2.data_ptr(), 2, 13, 11, 32, 30, 17, C.c_float(0), C.c_float(0), 0, s))
+    ref2 = F.interpolate(u, size=(30, 17), mode='bilinear', align_corners=False)
+    assert torch.allclose(nchw(uo2.cpu()), ref2, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------
+def _dcn_inputs(seed, B=2, Cc=32, H=9, W=8, Co=48, stride=1):
+    g = _g(seed)
+    x = torch.randn(B, Cc, H, W, generator=g)
+    w = torch.randn(Co, Cc, 3, 3, generator=g) / 17
+    b = torch.randn(Co, generator=g)
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    om = torch.randn(B, 27, Ho, Wo, generator=g) * 1.5
+    return x, w, b, om
+
+
+@pytest.mark.parametrize('stride', [1, 2])
+def test_dcn_matches_oracle(stride):
+    from gpu_utils import run_conv, rel_err
+    from oracle.yolact_oracle import dcn_v2_forward
+    x, w, b, om = _dcn_inputs(23 + stride, stride=stride)
+    y = run_conv(x, w, b, None, stride, 1, dcn_offmask=om)
+    ref = dcn_v2_forward(x, om[:, :18], torch.sigmoid(om[:, 18:]), w, b, stride, 1, 1)
+    assert rel_err(y, ref) < 2e-5
+
+
+def test_dcn_known_answers():
+    """external/DCNv2/test.py:32-67: zero offsets, mask logit 0 (sigmoid = 0.5), identity 3x3 centre weights
+    => 2*DCN(x) == x; and offset 0 with mask -> 1 reduces DCN to F.conv2d."""
+    from gpu_utils import run_conv
+    Cc = 32
+    x = torch.randn(2, Cc, 10, 7, generator=_g(31))
+    w = torch.zeros(Cc, Cc, 3, 3)
+    for i in range(Cc):
+        w[i, i, 1, 1] = 1.0
+    om = torch.zeros(2, 27, 10, 7)
+    y = run_conv(x, w, torch.zeros(Cc), None, 1, 1, dcn_offmask=om)
+    assert (2 * y - x).abs().max().item() < 1e-6
+    w2 = torch.randn(40, Cc, 3, 3, generator=_g(32)) / 17
+    om2 = torch.zeros(2, 27, 10, 7)
+    om2[:, 18:] = 40.0      # sigmoid(40) == 1 in fp32
+    y2 = run_conv(x, w2, None, None, 1, 1, dcn_offmask=om2)
+    assert torch.allclose(y2, F.conv2d(x, w2, None, 1, 1), atol=2e-5)

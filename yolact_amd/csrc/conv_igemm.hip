@@ -375,7 +375,7 @@ int run_conv(const ymi_conv_desc *d, int loader, const float *offmask, int ldo, 
 extern "C" {
 
 double ymi_conv_flops(const ymi_conv_desc *d) {
-  return 2.0 * d->B * d->Ho * d->Wo * (double)d->Cout * d->kh * d->kw * (double)d->Cin;
+  return 2.0 * d->B * d->Ho * d->Wo * (double)d->Cout * d->kh * d->kw * (double)(d->cin_alg > 0 ? d->cin_alg : d->Cin);
 }
 
 int ymi_conv_pick_tile(const ymi_conv_desc *d) { return d ? pick_tile(d) : YMI_ENULL; }

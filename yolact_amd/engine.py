@@ -39,6 +39,7 @@ class Packed:
         wp[:Cout, :K] = w.reshape(Cout, K)
         self.w = wp.to(device).contiguous()
         self.Cin, self.Cout, self.kh, self.kw, self.stride, self.pad = cin_p, Cout, kh, kw, stride, pad
+        self.cin_alg = Cin
         scale = shift = None
         if bn is not None:
             # torch's eval BatchNorm: alpha = gamma * rsqrt(var + eps); y = x*alpha + (beta - mean*alpha), fp32
@@ -143,6 +144,7 @@ class Plan:
             if res_mode == L.RES_ADD:
                 assert (res.B, res.H, res.W, res.C) == (x.B, Ho, Wo, pk.Cout), name
         d.tile = L.TILE_AUTO
+        d.cin_alg = pk.cin_alg
         y = None
         if segs is None:
             y = out if out is not None else self._new(x.B, Ho, Wo, pk.Cout)

@@ -166,6 +166,19 @@ class Yolact(nn.Module):
                      'proto': proto}
             return self.detect(preds, self)
 
+    def forward_device(self, x):
+        """Forward + Detect with NO host synchronisation: fixed-capacity device tensors
+        (count [B], box [B,cap,4], score, cls, coef, prior) + 'proto'. Used by the data-parallel path
+        (yolact_amd.parallel) and by throughput runs that keep results on the GPU."""
+        L.require_cuda(x, 'input batch')
+        x = x.detach().to(torch.float32).contiguous()
+        with torch.cuda.device(x.device):
+            plan = self.plan_for(x)
+            proto = plan.run(x)
+            out = self.detect.run_device(plan.loc, plan.conf, plan.coef, plan.priors, True)
+            out['proto'] = proto
+            return out
+
     def forward_raw(self, x):
         """Head outputs before Detect (for parity tests): loc, conf (logits), mask, priors, proto — clones."""
         L.require_cuda(x, 'input batch')
