@@ -187,6 +187,8 @@ def main():
                 'roofline': rf,
             }
             if args.layers:
+                for name, best, times in getattr(net.plan_for(x), 'tune_table', []):
+                    print('tune %-20s -> %-8s %s' % (name, best, times), file=sys.stderr)
                 for k, (ms, fl, kern) in layers.items():
                     print('%-22s %8.3f ms %8.2f GFLOP %7.1f TF/s  %s' % (k, ms, fl / 1e9, fl / ms / 1e9, kern),
                           file=sys.stderr)

@@ -174,11 +174,11 @@ def test_layout_pool_resize():
     uo = torch.empty(2, 26, 22, 32, device=DEV)
     L.check(lib.ymi_bilinear_nhwc_f32(ud.data_ptr(), uo.data_ptr(), 2, 13, 11, 32, 26, 22, C.c_float(0.5), C.c_float(0.5), 1, s))
     ref = F.relu(F.interpolate(u, scale_factor=2, mode='bilinear', align_corners=False))
-    assert torch.allclose(nchw(uo.cpu()), ref, atol=1e-6)
+    assert torch.allclose(nchw(uo.cpu()), ref, atol=1e-5)
     uo2 = torch.empty(2, 30, 17, 32, device=DEV)
     L.check(lib.ymi_bilinear_nhwc_f32(ud.data_ptr(), uo2.data_ptr(), 2, 13, 11, 32, 30, 17, C.c_float(0), C.c_float(0), 0, s))
     ref2 = F.interpolate(u, size=(30, 17), mode='bilinear', align_corners=False)
-    assert torch.allclose(nchw(uo2.cpu()), ref2, atol=1e-6)
+    assert torch.allclose(nchw(uo2.cpu()), ref2, atol=1e-5)   # fp32 coordinate math, no FMA contraction
 
 
 # ---------------------------------------------------------------------------------------------------

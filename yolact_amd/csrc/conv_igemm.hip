@@ -219,57 +219,110 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const KParams p) {
   }
 
   // ---- epilogue ----------------------------------------------------------------------------
-  // C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)
-  const int ncol = lane & 31;
+  // Accumulators -> LDS tile [BM][BN+4] -> each thread owns 4 consecutive output channels of a row, so
+  // residual loads and output stores are 16 bytes per lane and 512 contiguous bytes per 32 lanes
+  // (the first version stored one dword per lane per accumulator register and was store-issue bound on
+  // the K <= 128 1x1 layers: 18-35 TF/s; see profiles/).
+  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5).
+  constexpr int ELD = BN + 4;
+  static_assert(BM * ELD <= 2 * (BM + BN) * LDS_LD, "epilogue tile must fit in the staging LDS");
+  float *es = lds;  // the main loop ended with a barrier: LDS is free
+  {
+    const int ncol = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          es[((wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * ELD + (wn * TN + j) * 32 + ncol] = acc[i][j][r];
+  }
+  __syncthreads();
+
+  constexpr int C4 = BN / 4;        // float4 columns per tile row
+  constexpr int RSTEP = 256 / C4;   // rows covered by one pass of the block
+  constexpr int RPT = BM / RSTEP;   // rows per thread
+  const int c4 = t % C4, rbase = t / C4;
+  const int n = n0 + 4 * c4;
+  if (n >= d.Cout) return;
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (n + e < d.Cout) {
+      if (d.scale) sc[e] = d.scale[n + e];
+      if (d.bias) bi[e] = d.bias[n + e];
+    }
+  }
+  // segment of each of the 4 channels; vector store only if all 4 live in one aligned segment
+  int e_seg[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    e_seg[e] = -1;
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+      if (s < d.nseg && n + e >= d.seg[s].n0 && n + e < d.seg[s].n1 && n + e < d.Cout) e_seg[e] = s;
+  }
+  bool vec_out = e_seg[0] >= 0 && e_seg[0] == e_seg[1] && e_seg[0] == e_seg[2] && e_seg[0] == e_seg[3];
+  if (vec_out) {
+    const ymi_conv_seg &sg = d.seg[e_seg[0]];
+    vec_out = ((n - sg.n0) & 3) == 0 && (sg.row_stride & 3) == 0 && (sg.batch_stride & 3) == 0 &&
+              (((uintptr_t)sg.ptr) & 15) == 0;
+  }
+  const bool vec_res = (d.res_ld & 3) == 0 && ((((uintptr_t)d.res) & 15) == 0) && (n + 3 < d.Cout);
   float rscale_h = 0.f, rscale_w = 0.f;
   if (d.res_mode == YMI_RES_BILINEAR) {
     rscale_h = (float)d.res_H / (float)d.Ho;
     rscale_w = (float)d.res_W / (float)d.Wo;
   }
+#pragma unroll 4
+  for (int i = 0; i < RPT; ++i) {
+    const int row = rbase + RSTEP * i;
+    const int m = m0 + row;
+    if (m >= p.M) continue;
+    const int b = m / p.HoWo, pix = m - b * p.HoWo;
+    f32x4 v = *reinterpret_cast<const f32x4 *>(es + row * ELD + 4 * c4);
+    v = v * sc + bi;
+    f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+    if (d.res_mode == YMI_RES_ADD) {
+      const float *rp = d.res + (size_t)m * d.res_ld + n;
+      if (vec_res) rv = *reinterpret_cast<const f32x4 *>(rp);
+      else {
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + (wn * TN + j) * 32 + ncol;
-    const bool n_ok = n < d.Cout;
-    float sc = 1.f, bi = 0.f;
-    int sact = 0, srow = 0, sn0 = 0;
-    int64_t sbatch = 0;
-    float *sptr = nullptr;
-    if (n_ok) {
-      if (d.scale) sc = d.scale[n];
-      if (d.bias) bi = d.bias[n];
-#pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        if (s < d.nseg && n >= d.seg[s].n0 && n < d.seg[s].n1) {
-          sact = d.seg[s].act; srow = d.seg[s].row_stride; sn0 = d.seg[s].n0;
-          sbatch = d.seg[s].batch_stride; sptr = d.seg[s].ptr;
-        }
+        for (int e = 0; e < 4; ++e) if (n + e < d.Cout) rv[e] = rp[e];
       }
+    } else if (d.res_mode == YMI_RES_BILINEAR) {
+      const int oy = pix / d.Wo, ox = pix - oy * d.Wo;
+      int y0, y1, x0, x1; float ly, lx;
+      bilin_coord(oy, rscale_h, d.res_H, y0, y1, ly);
+      bilin_coord(ox, rscale_w, d.res_W, x0, x1, lx);
+      const float *rb_ = d.res + (size_t)b * d.res_H * d.res_W * d.res_ld + n;
+      const float *p00 = rb_ + (size_t)(y0 * d.res_W + x0) * d.res_ld, *p01 = rb_ + (size_t)(y0 * d.res_W + x1) * d.res_ld;
+      const float *p10 = rb_ + (size_t)(y1 * d.res_W + x0) * d.res_ld, *p11 = rb_ + (size_t)(y1 * d.res_W + x1) * d.res_ld;
+      f32x4 v00 = rv, v01 = rv, v10 = rv, v11 = rv;
+      if (vec_res) {
+        v00 = *reinterpret_cast<const f32x4 *>(p00); v01 = *reinterpret_cast<const f32x4 *>(p01);
+        v10 = *reinterpret_cast<const f32x4 *>(p10); v11 = *reinterpret_cast<const f32x4 *>(p11);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < d.Cout) { v00[e] = p00[e]; v01[e] = p01[e]; v10[e] = p10[e]; v11[e] = p11[e]; }
+      }
+      rv = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
     }
+    if (vec_out) {
+      const ymi_conv_seg &sg = d.seg[e_seg[0]];
+      f32x4 o;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+      for (int e = 0; e < 4; ++e)
+        o[e] = d.res_after_act ? act_apply(v[e], sg.act) + rv[e] : act_apply(v[e] + rv[e], sg.act);
+      *reinterpret_cast<f32x4 *>(sg.ptr + (size_t)b * sg.batch_stride + (size_t)pix * sg.row_stride + (n - sg.n0)) = o;
+    } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (n_ok && sptr && m < p.M) {
-          const int b = m / p.HoWo, pix = m - b * p.HoWo;
-          float v = acc[i][j][r] * sc + bi;
-          float rv = 0.f;
-          if (d.res_mode == YMI_RES_ADD) {
-            rv = d.res[(size_t)m * d.res_ld + n];
-          } else if (d.res_mode == YMI_RES_BILINEAR) {
-            const int oy = pix / d.Wo, ox = pix - oy * d.Wo;
-            int y0, y1, x0, x1; float ly, lx;
-            bilin_coord(oy, rscale_h, d.res_H, y0, y1, ly);
-            bilin_coord(ox, rscale_w, d.res_W, x0, x1, lx);
-            const float *rb_ = d.res + (size_t)b * d.res_H * d.res_W * d.res_ld + n;
-            const float v00 = rb_[(y0 * d.res_W + x0) * d.res_ld], v01 = rb_[(y0 * d.res_W + x1) * d.res_ld];
-            const float v10 = rb_[(y1 * d.res_W + x0) * d.res_ld], v11 = rb_[(y1 * d.res_W + x1) * d.res_ld];
-            rv = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
-          }
-          if (d.res_after_act) v = act_apply(v, sact) + rv;
-          else v = act_apply(v + rv, sact);
-          sptr[(size_t)b * sbatch + (size_t)pix * srow + (n - sn0)] = v;
-        }
+      for (int e = 0; e < 4; ++e) {
+        if (e_seg[e] < 0) continue;
+        const ymi_conv_seg &sg = d.seg[e_seg[e]];
+        const float o = d.res_after_act ? act_apply(v[e], sg.act) + rv[e] : act_apply(v[e] + rv[e], sg.act);
+        sg.ptr[(size_t)b * sg.batch_stride + (size_t)pix * sg.row_stride + (n + e - sg.n0)] = o;
       }
     }
   }
@@ -306,18 +359,29 @@ int tile_dims(int tile, int &bm, int &bn) {
 }
 
 int pick_tile(const ymi_conv_desc *d) {
+  // Fallback heuristic (the Python plan autotunes on the device and overrides this).  Cost model: the GEMMs are
+  // MFMA-bound, a CU runs its ceil(tiles/256) blocks `occ` at a time, and the matrix-pipe utilisation u(c) with c
+  // co-resident blocks was measured in round 1 (profiles/r01_layers_v1.txt): one block per CU leaves the pipe
+  // idle during its LDS-store/barrier/ds_read bubbles (u ~0.45), two or more overlap (u ~0.7-0.76).
   const long M = (long)d->B * d->Ho * d->Wo;
   const int N = d->Cout;
-  // Largest tile that still yields >= ~2 blocks per CU over 256 CUs; otherwise the finest tile.
-  const int order[4] = {YMI_TILE_128x128, YMI_TILE_128x64, YMI_TILE_64x128, YMI_TILE_64x64};
   if (N <= 32) return YMI_TILE_128x32;
+  const int cand[4] = {YMI_TILE_128x128, YMI_TILE_128x64, YMI_TILE_64x128, YMI_TILE_64x64};
+  const int occ[4] = {2, 2, 2, 4};
+  const double u[4][4] = {{0.50, 0.76, 0.76, 0.76}, {0.46, 0.72, 0.72, 0.72}, {0.46, 0.72, 0.72, 0.72},
+                          {0.41, 0.69, 0.66, 0.64}};
   int best = YMI_TILE_64x64;
+  double best_cost = 1e300;
   for (int i = 0; i < 4; ++i) {
-    int bm, bn; tile_dims(order[i], bm, bn);
-    if (bn > 64 && N <= 64) continue;                 // don't waste half the N tile
-    if (order[i] == YMI_TILE_64x128 && N < 128) continue;
+    int bm, bn; tile_dims(cand[i], bm, bn);
+    if (bn > 64 && N <= 64) continue;  // don't waste half the N tile
     const long tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
-    if (tiles >= 512) { best = order[i]; break; }
+    const long n = (tiles + 255) / 256;           // blocks on the busiest CU
+    const long full = n / occ[i], rem = n % occ[i];
+    double cost = full * occ[i] / u[i][occ[i] - 1];
+    if (rem) cost += rem / u[i][rem - 1];
+    cost *= (double)bm * bn;
+    if (cost < best_cost) { best_cost = cost; best = cand[i]; }
   }
   return best;
 }

@@ -8,6 +8,8 @@ synchronisation.  PyTorch is used for device memory only.
 from __future__ import annotations
 
 import ctypes as C
+import json
+import os
 from typing import List, Optional
 
 import torch
@@ -270,8 +272,9 @@ class Plan:
         self.coef = torch.empty(B, P, D, device=dev)
         up_pk = [pack_module(m, device=dev) for m in pm.upfeature if isinstance(m, nn.Conv2d)] \
             if hasattr(pm, 'upfeature') else []
-        wcat = torch.cat([pm.bbox_layer.weight, pm.conf_layer.weight, pm.mask_layer.weight], 0)
-        bcat = torch.cat([pm.bbox_layer.bias, pm.conf_layer.bias, pm.mask_layer.bias], 0)
+        # row order bbox | coef | conf keeps the bbox and coef segments 16-byte aligned (vector stores)
+        wcat = torch.cat([pm.bbox_layer.weight, pm.mask_layer.weight, pm.conf_layer.weight], 0)
+        bcat = torch.cat([pm.bbox_layer.bias, pm.mask_layer.bias, pm.conf_layer.bias], 0)
         hp = pm.bbox_layer
         head_pk = Packed(wcat, bcat, None, hp.stride[0], hp.padding[0], None, dev)
         coef_act = {'tanh': L.ACT_TANH, 'sigmoid': L.ACT_SIGMOID, 'relu': L.ACT_RELU, 'none': L.ACT_NONE}[
@@ -289,8 +292,8 @@ class Plan:
                 u = nu
             segs = [
                 (0, n_b, L.ACT_NONE, n_b, P * 4, self.loc.data_ptr() + off * 4 * 4),
-                (n_b, n_b + n_c, L.ACT_NONE, n_c, P * Ccls, self.conf.data_ptr() + off * Ccls * 4),
-                (n_b + n_c, n_b + n_c + n_m, coef_act, n_m, P * D, self.coef.data_ptr() + off * D * 4),
+                (n_b, n_b + n_m, coef_act, n_m, P * D, self.coef.data_ptr() + off * D * 4),
+                (n_b + n_m, n_b + n_m + n_c, L.ACT_NONE, n_c, P * Ccls, self.conf.data_ptr() + off * Ccls * 4),
             ]
             self.conv('head%d.out' % lvl, u, head_pk, segs=segs)
             if u is not f:
@@ -386,6 +389,56 @@ class Plan:
             if rc != 0:
                 L.check(rc, name)
         return proto
+
+    def autotune(self, x: torch.Tensor, reps: int = 3):
+        """Measure, don't guess: time every tile configuration of every distinct conv shape on the device (HIP
+        events on the launch stream) and keep the fastest.  All tile shapes accumulate K in the same order, so
+        the choice never changes results (tests/test_gpu_path.py::test_full_size_batch8_properties)."""
+        cache_path = os.environ.get('YOLACT_AMD_TUNE_CACHE')
+        disk = {}
+        if cache_path and os.path.exists(cache_path):
+            with open(cache_path) as f:
+                disk = json.load(f)
+        self.run(x)                      # realistic values in every buffer
+        s = L.stream_ptr()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        cache, table = {}, []
+        for fn, dptr, name in self.ops:
+            if fn is not self.lib.ymi_conv2d_nhwc_f32:
+                continue
+            d = dptr.contents
+            key = (d.B, d.H, d.W, d.Cin, d.Cout, d.kh, d.kw, d.stride, d.pad, d.res_mode, d.nseg, d.Kpad)
+            if key not in cache and str(key) in disk:
+                cache[key] = int(disk[str(key)])     # tuned in an earlier process (e.g. before a rocprofv3 run)
+            if key not in cache:
+                if d.Cout <= 32:
+                    cands = [L.TILE_128x32, L.TILE_64x64]
+                elif d.Cout <= 64:
+                    cands = [L.TILE_128x64, L.TILE_64x64]
+                else:
+                    cands = [L.TILE_128x128, L.TILE_128x64, L.TILE_64x128, L.TILE_64x64]
+                best, best_ms, times = None, 1e30, {}
+                for t in cands:
+                    d.tile = t
+                    L.check(fn(dptr, s), name)
+                    e0.record()
+                    for _ in range(reps):
+                        fn(dptr, s)
+                    e1.record()
+                    e1.synchronize()
+                    ms = e0.elapsed_time(e1) / reps
+                    times[L.TILE_NAMES[t]] = round(ms, 4)
+                    if ms < best_ms:
+                        best, best_ms = t, ms
+                cache[key] = best
+                table.append((name, L.TILE_NAMES[best], times))
+            d.tile = cache[key]
+        self.tune_table = table
+        if cache_path and table:
+            disk.update({str(k): v for k, v in cache.items()})
+            with open(cache_path, 'w') as f:
+                json.dump(disk, f)
+        return table
 
     def conv_flops(self):
         return sum(self.lib.ymi_conv_flops(C.byref(d)) for _, d in self.conv_meta)

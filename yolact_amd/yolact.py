@@ -11,6 +11,7 @@ libyolact_amd.so and replays it on the current HIP stream.  CPU tensors are reje
 from __future__ import annotations
 
 import contextlib
+import os
 import sys
 import threading
 
@@ -145,6 +146,8 @@ class Yolact(nn.Module):
                     B, _, H, W = x.shape
                     with torch.no_grad():
                         p = Plan(self, B, H, W, x.device)
+                        if x.is_cuda and os.environ.get('YOLACT_AMD_AUTOTUNE', '1') != '0':
+                            p.autotune(x)
                     self._plans[key] = p
         return p
 
