@@ -89,6 +89,15 @@ int ymi_maxpool3x3s2_nhwc_f32(const float *x, float *y, int B, int H, int W, int
 int ymi_bilinear_nhwc_f32(const float *x, float *y, int B, int Hi, int Wi, int C, int Ho, int Wo,
                           float scale_h, float scale_w, int relu, void *stream);
 
+/* Small direct convolution for FastMaskIoUNet (yolact.py:363-375; config maskiou_net, data/config.py:785-791):
+ * x [B,H,W,Cin] NHWC, w [kh*kw*Cin][CoutPad4] (k = (ky*kw+kx)*Cin + c, CoutPad4 = ceil(Cout/4)*4, zero padded),
+ * y [B,Ho,Wo,Cout]; optional bias and ReLU. */
+int ymi_conv2d_direct_nhwc_f32(const float *x, const float *w, const float *bias, float *y, int B, int H, int W,
+                               int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int relu,
+                               void *stream);
+/* y[b,c] = max_p x[b,p,c]  (F.max_pool2d over the whole map, yolact.py:372) */
+int ymi_global_maxpool_nhwc_f32(const float *x, float *y, int B, int HW, int C, void *stream);
+
 /* -- Detect: softmax + decode + Fast NMS (layers/functions/detection.py:32-180) ---------- */
 typedef struct {
   const float *conf;    /* [B,P,C] raw class logits if conf_is_logits else post-softmax scores */

@@ -267,3 +267,35 @@ def test_full_size_batch8_properties():
     for i, p in enumerate(perm.tolist()):
         assert torch.equal(outp[i]['detection']['score'], out[p]['detection']['score'])
         assert torch.equal(outp[i]['detection']['_prior'], out[p]['detection']['_prior'])
+
+
+def test_yolact_plus_postprocess_maskiou_rescoring():
+    """YOLACT++ (config 4): postprocess returns scores = [box_scores, box_scores * maskiou] (output_utils.py:79-88);
+    FastMaskIoUNet runs on the cropped prototype-resolution masks (yolact.py:363-375)."""
+    import yolact_amd
+    from gpu_utils import build_net
+    from oracle import yolact_oracle as O
+    from yolact_amd.layers.output_utils import postprocess
+    meta, arrays, cfg, sd, raw, dets = oracle_run('plus_r50')
+    net = build_net(meta)
+    w, h = meta['post']
+    ref = dets[0]
+    d = {k: ref[k].to(DEV).clone() for k in ('box', 'mask', 'class', 'score', 'proto')}
+    classes, scores, boxes, masks = postprocess([{'detection': d, 'net': net}], w, h)
+    rc, rs, rb, rm = O.postprocess(ref, w, h, cfg, sd)
+    assert isinstance(scores, list) and len(scores) == 2 and isinstance(rs, list)
+    assert torch.equal(scores[0].cpu(), rs[0])
+    assert (scores[1].cpu() - rs[1]).abs().max().item() < 1e-4 * max(1.0, rs[1].abs().max().item())
+    assert torch.equal(classes.cpu(), rc) and torch.equal(boxes.cpu(), rb)
+    assert (masks.cpu() != rm).float().mean().item() < 1e-4
+    # the reference's own numbers
+    assert (scores[1].cpu() - torch.from_numpy(arrays['post0_score2'])).abs().max().item() < 1e-4 * max(
+        1.0, float(abs(arrays['post0_score2']).max()))
+    # rescore_bbox=True (what eval.py's prep_display forces, eval.py:147-152) -> a single product tensor
+    yolact_amd.active_cfg().rescore_bbox = True
+    try:
+        d = {k: ref[k].to(DEV).clone() for k in ('box', 'mask', 'class', 'score', 'proto')}
+        _, s2, _, _ = postprocess([{'detection': d, 'net': net}], w, h)
+        assert torch.is_tensor(s2) and (s2.cpu() - rs[1]).abs().max().item() < 1e-4 * max(1.0, rs[1].abs().max().item())
+    finally:
+        yolact_amd.active_cfg().rescore_bbox = False

@@ -153,3 +153,82 @@ int ymi_bilinear_nhwc_f32(const float *x, float *y, int B, int Hi, int Wi, int C
 }
 
 }  // extern "C"
+
+// ---- small direct convolution (FastMaskIoUNet, yolact.py:363-375: Cin = 1..64, tiny spatial sizes) ----------
+namespace {
+
+// One thread per (pixel, 4 output channels); weights [K][CoutPad4] with k = (ky*kw+kx)*Cin + c so the four
+// output channels of a k are one float4.  ~9 MFLOP per detection: bandwidth/latency, not matrix-core, work.
+__global__ __launch_bounds__(256) void conv_direct_k(const float *__restrict__ x, const float *__restrict__ w,
+                                                      const float *__restrict__ bias, float *__restrict__ y, int H,
+                                                      int W, int Cin, int Ho, int Wo, int Cout, int Co4, int kh, int kw,
+                                                      int stride, int pad, int relu, long total) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    const int c4 = (int)(i % Co4);
+    long r = i / Co4;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const long b = r / Ho;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int ky = 0; ky < kh; ++ky) {
+      const int iy = oy * stride - pad + ky;
+      if ((unsigned)iy >= (unsigned)H) continue;
+      for (int kx = 0; kx < kw; ++kx) {
+        const int ix = ox * stride - pad + kx;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        const float *xp = x + ((b * H + iy) * W + ix) * Cin;
+        const float *wp = w + ((long)(ky * kw + kx) * Cin) * (Co4 * 4) + c4 * 4;
+        for (int c = 0; c < Cin; ++c) {
+          const f32x4 wv = *reinterpret_cast<const f32x4 *>(wp + (long)c * (Co4 * 4));
+          acc += xp[c] * wv;
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int co = c4 * 4 + e;
+      if (co < Cout) {
+        float v = acc[e] + (bias ? bias[co] : 0.f);
+        if (relu && v < 0.f) v = 0.f;
+        y[((b * Ho + oy) * Wo + ox) * Cout + co] = v;
+      }
+    }
+  }
+}
+
+// y[b,c] = max over the HW positions of x[b,:,c]   (F.max_pool2d with kernel = full map)
+__global__ void global_max_k(const float *__restrict__ x, float *__restrict__ y, int HW, int C, long total) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long b = i / C; const int c = (int)(i - b * C);
+  float m = -__builtin_inff();
+  for (int p = 0; p < HW; ++p) { const float v = x[(b * HW + p) * C + c]; m = v > m ? v : m; }
+  y[i] = m;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ymi_conv2d_direct_nhwc_f32(const float *x, const float *w, const float *bias, float *y, int B, int H, int W, int Cin,
+                               int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int relu, void *stream) {
+  if (!x || !w || !y) return YMI_ENULL;
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0) return YMI_EARG;
+  if (Ho != (H + 2 * pad - kh) / stride + 1 || Wo != (W + 2 * pad - kw) / stride + 1) return YMI_ESHAPE;
+  const int Co4 = (Cout + 3) / 4;
+  const long total = (long)B * Ho * Wo * Co4;
+  hipLaunchKernelGGL(conv_direct_k, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, H, W, Cin,
+                     Ho, Wo, Cout, Co4, kh, kw, stride, pad, relu, total);
+  return ymi_launch_status();
+}
+
+int ymi_global_maxpool_nhwc_f32(const float *x, float *y, int B, int HW, int C, void *stream) {
+  if (!x || !y) return YMI_ENULL;
+  if (B <= 0 || HW <= 0 || C <= 0) return YMI_EARG;
+  const long total = (long)B * C;
+  hipLaunchKernelGGL(global_max_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, HW, C,
+                     total);
+  return ymi_launch_status();
+}
+
+}  // extern "C"

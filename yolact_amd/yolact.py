@@ -169,6 +169,40 @@ class Yolact(nn.Module):
                      'proto': proto}
             return self.detect(preds, self)
 
+    def maskiou_forward(self, masks_lo):
+        """FastMaskIoUNet.forward (yolact.py:363-375) on cropped prototype-resolution masks [N,ph,pw] -> [N,80]:
+        5 x (3x3 stride-2 unpadded conv + ReLU), 1x1 -> 80 + ReLU, global max-pool. Called by postprocess()
+        for YOLACT++ configs (output_utils.py:79-88)."""
+        L.require_cuda(masks_lo, 'masks')
+        dev = masks_lo.device
+        lib = L.lib()
+        key = ('maskiou', dev)
+        packed = self._plans.get(key)
+        if packed is None:
+            packed = []
+            for m in self.maskiou_net.maskiou_net:
+                if isinstance(m, nn.Conv2d):
+                    Cout, Cin, kh, kw = m.weight.shape
+                    co4 = (Cout + 3) // 4 * 4
+                    w = torch.zeros(kh * kw * Cin, co4, device=dev)
+                    w[:, :Cout] = m.weight.detach().float().permute(2, 3, 1, 0).reshape(kh * kw * Cin, Cout)
+                    packed.append((w.contiguous(), m.bias.detach().float().contiguous(), Cin, Cout, kh, kw,
+                                   m.stride[0], m.padding[0]))
+            self._plans[key] = packed
+        N, H, W = masks_lo.shape
+        x = masks_lo.contiguous()          # [N,H,W,1] NHWC with one channel
+        with torch.cuda.device(dev):
+            s = L.stream_ptr()
+            for (w, b, Cin, Cout, kh, kw, stride, pad) in packed:
+                Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+                y = torch.empty(N, Ho, Wo, Cout, device=dev)
+                L.check(lib.ymi_conv2d_direct_nhwc_f32(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), N, H, W,
+                                                       Cin, Ho, Wo, Cout, kh, kw, stride, pad, 1, s), 'maskiou conv')
+                x, H, W = y, Ho, Wo
+            out = torch.empty(N, x.shape[3], device=dev)
+            L.check(lib.ymi_global_maxpool_nhwc_f32(x.data_ptr(), out.data_ptr(), N, H * W, x.shape[3], s), 'maskiou max')
+        return out
+
     def forward_device(self, x):
         """Forward + Detect with NO host synchronisation: fixed-capacity device tensors
         (count [B], box [B,cap,4], score, cls, coef, prior) + 'proto'. Used by the data-parallel path
