@@ -20,6 +20,7 @@
 // Epilogue (fused): folded-BN scale/bias, residual add (plain or bilinear-upsampled source = FPN
 // top-down path), activation, scatter to up to 3 output segments with independent strides.
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/yolact_amd.h"
 
 namespace {
@@ -32,6 +33,8 @@ struct KParams {
   int M, HoWo, tiles_n, nk, cpt;  // cpt = chunks per tap (Cin/32) for the C32 loader
   const float *offmask;           // DCN only
   int ldo;
+  int abl;                        // diagnostics only (env YMI_ABLATE): bit0 skip global loads, bit1 skip LDS stores,
+                                  // bit2 skip barriers in the K loop — wrong results, used to attribute stall time
 };
 
 __device__ __forceinline__ float act_apply(float v, int act) {
@@ -212,10 +215,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const KParams p) {
   for (int kc = 0; kc < p.nk; ++kc) {
     const int cur = kc & 1;
     const bool more = (kc + 1) < p.nk;
-    if (more) load_tiles(kc + 1);
+    if (more && !(p.abl & 1)) load_tiles(kc + 1);
     compute(cur);
-    if (more) store_lds(cur ^ 1);
-    __syncthreads();
+    if (more && !(p.abl & 2)) store_lds(cur ^ 1);
+    if (!(p.abl & 4)) __syncthreads();
   }
 
   // ---- epilogue ----------------------------------------------------------------------------
@@ -414,6 +417,7 @@ int run_conv(const ymi_conv_desc *d, int loader, const float *offmask, int ldo, 
   kp.tiles_n = 0;
   kp.offmask = offmask;
   kp.ldo = ldo;
+  { const char *e = getenv("YMI_ABLATE"); kp.abl = e ? atoi(e) : 0; }
   int tile = d->tile ? d->tile : pick_tile(d);
   ProfRec *pr = nullptr;
   if (g_prof_on && g_prof_n < PROF_MAX) {
