@@ -43,7 +43,7 @@ typedef struct {
  * y[b,oy,ox,n] = act( scale[n] * sum_{ky,kx,c} x[b, oy*s-p+ky, ox*s-p+kx, c] * w[n,ky,kx,c] + bias[n]  (+ res) )
  * computed with v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate). */
 typedef struct {
-  const float *x;       /* [B,H,W,ldx] NHWC; channels [0,Cin) of each pixel are used */
+  const float *x;       /* [B,H,W,ldx] NHWC; channels [0,Cin) of each pixel are used; 16-byte aligned, < 2 GiB */
   const float *w;       /* packed [CoutPad][Kpad], k = (ky*kw+kx)*Cin + c; CoutPad % 128 == 0, Kpad % 32 == 0, zero padded */
   const float *scale;   /* [Cout] or NULL (=1)  — folded BatchNorm gamma/sqrt(var+eps) */
   const float *bias;    /* [Cout] or NULL (=0)  — conv bias or folded BatchNorm shift */
@@ -63,8 +63,10 @@ typedef struct {
   ymi_conv_seg seg[3];
 } ymi_conv_desc;
 
+/* block tile BMxBN; _Kn = the block's 4 waves also split K n ways (partial sums reduced in LDS in a fixed order:
+ * deterministic, but a different fp32 summation order than the unsplit tiles) */
 enum { YMI_TILE_AUTO = 0, YMI_TILE_128x128 = 1, YMI_TILE_128x64 = 2, YMI_TILE_64x64 = 3, YMI_TILE_128x32 = 4,
-       YMI_TILE_64x128 = 5 };
+       YMI_TILE_64x128 = 5, YMI_TILE_32x32_K4 = 6, YMI_TILE_64x32_K2 = 7, YMI_TILE_32x64_K2 = 8 };
 
 int ymi_abi_version(void);
 const char *ymi_strerror(int code);

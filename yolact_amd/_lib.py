@@ -15,7 +15,9 @@ ABI_VERSION = 1
 ACT_NONE, ACT_RELU, ACT_LEAKY01, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 RES_NONE, RES_ADD, RES_BILINEAR = 0, 1, 2
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32, TILE_64x128 = 0, 1, 2, 3, 4, 5
-TILE_NAMES = {1: '128x128', 2: '128x64', 3: '64x64', 4: '128x32', 5: '64x128'}
+TILE_32x32_K4, TILE_64x32_K2, TILE_32x64_K2 = 6, 7, 8
+TILE_NAMES = {1: '128x128', 2: '128x64', 3: '64x64', 4: '128x32', 5: '64x128', 6: '32x32k4', 7: '64x32k2', 8: '32x64k2'}
+KSPLIT_TILES = (6, 7, 8)   # different (still deterministic) fp32 summation order than the unsplit tiles
 
 
 class ConvSeg(C.Structure):

@@ -3,22 +3,29 @@
 // GEMM view:  M = B*Ho*Wo output pixels, N = Cout, K = kh*kw*Cin with k = (ky*kw+kx)*Cin + c.
 //   A[m,k]  gathered on the fly from the NHWC input (zero for padding / m >= M / k >= K)
 //   B[k,n]  packed weights, stored [n][k] (k contiguous) so A and B tiles have the same LDS image
-// Block = 256 threads = 4 wave64; block tile BM x BN, K step 32.  Each wave owns TM x TN MFMA tiles of
-// 32x32.  LDS image of both operands: [row][36] floats (32 k-values + 4 pad): the 144-byte row stride
-// makes both the ds_write_b128 staging stores and the ds_read_b128 fragment loads bank-conflict free
-// (9 sixteen-byte slots per row; 9 is odd so the 16 rows of any ds_read_b128 lane group cover all 16
-// slots of the 256-byte bank row).
+// Block = 256 threads = 4 wave64; block tile BM x BN, K step 32.  Each wave owns TM x TN MFMA tiles of 32x32.
 //
-// Fragment trick: the MFMA consumes k in pairs {lanes 0-31: k0, lanes 32-63: k1}.  The K order of a
-// dot product is free as long as A and B agree, so lane-half h loads k = 8g+4h .. 8g+4h+3 with ONE
-// 16-byte LDS read and MFMA step j pairs (8g+j, 8g+4+j).  4 MFMAs (256 cycles/SIMD) per ds_read_b128 pair.
+// Staging: LDS-DMA.  Both operand tiles go global -> LDS directly with `buffer_load_dwordx4 ... lds`
+// (no VGPR round trip, no ds_write, no select): one wave instruction fills 8 rows x 128 bytes.  Rows that fall in the
+// convolution's zero padding (or past M) are fetched with an out-of-range buffer offset, for which the hardware's
+// buffer bounds check returns zeros — the padding costs no branch and no extra instruction.  The round-1 register
+// staged version lost 14 % (global loads) + 11 % (ds_write) of the K loop to staging (profiles/r01_probe_v3.txt).
 //
-// Pipeline: LDS double buffer; the global loads of chunk kc+1 are issued into registers before the
-// MFMAs of chunk kc and written to the other LDS buffer afterwards: one barrier per K step, HBM/L2
-// latency hidden under 64*TM*TN*... MFMA cycles; 2 blocks/CU co-reside for the rest.
+// LDS image: [row][32 floats] = 128-byte rows, no padding (an LDS-DMA destination is lane-linear), 16-byte slots
+// XOR-swizzled: physical slot = logical slot ^ ((row >> 1) & 7).  The swizzle is applied on the SOURCE side (each lane
+// fetches the k-slot that belongs at its physical position — still the same 128-byte global segment per row) and on
+// the ds_read_b128 fragment addresses; every 16-lane group of a fragment read then covers all 64 banks (rows are
+// distinct mod 16 within a group), i.e. conflict-free like the padded layout it replaces.
 //
-// Epilogue (fused): folded-BN scale/bias, residual add (plain or bilinear-upsampled source = FPN
-// top-down path), activation, scatter to up to 3 output segments with independent strides.
+// Fragment trick: the MFMA consumes k in pairs {lanes 0-31: k0, lanes 32-63: k1}.  The K order of a dot product is
+// free as long as A and B agree, so lane-half h loads k = 8g+4h .. 8g+4h+3 with ONE 16-byte LDS read and MFMA step j
+// pairs (8g+j, 8g+4+j).  4 MFMAs (256 cycles/SIMD) per ds_read_b128 pair.
+//
+// Pipeline: LDS double buffer; the DMA of chunk kc+1 is issued before the MFMAs of chunk kc, one barrier per K step.
+// Tap/channel bookkeeping is incremental (no integer division in the loop).
+//
+// Epilogue (fused): folded-BN scale/bias, residual add (plain or bilinear-upsampled source = FPN top-down path),
+// activation, scatter to up to 3 output segments with independent strides.
 #include "common.h"
 #include <stdlib.h>
 #include "../../include/yolact_amd.h"
@@ -26,14 +33,17 @@
 namespace {
 
 constexpr int BK = 32;
-constexpr int LDS_LD = 36;  // floats per LDS row
+constexpr unsigned OOB = 0x80000000u;  // buffer offset >= num_records (< 2^31, validated) -> the load returns zeros
+
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
 
 struct KParams {
   ymi_conv_desc d;
-  int M, HoWo, tiles_n, nk, cpt;  // cpt = chunks per tap (Cin/32) for the C32 loader
+  int M, HoWo, tiles_n, nk;
+  unsigned x_bytes, w_bytes;      // buffer-resource sizes
   const float *offmask;           // DCN only
   int ldo;
-  int abl;                        // diagnostics only (env YMI_ABLATE): bit0 skip global loads, bit1 skip LDS stores,
+  int abl;                        // diagnostics only (env YMI_ABLATE): bit0 skip the staging of chunks > 0,
                                   // bit2 skip barriers in the K loop — wrong results, used to attribute stall time
 };
 
@@ -59,27 +69,65 @@ __device__ __forceinline__ void bilin_coord(int dst, float scale, int in_size, i
 }
 
 // LOADER: 0 = Cin % 32 == 0 (a K chunk lies inside one filter tap; tap is block-uniform)
-//         1 = Cin == 4 (stem; a K chunk = 8 taps x 4 channels; tap is per-thread)
-//         2 = DCNv2 modulated deformable gather (Cin % 32 == 0, 3x3, pad 1)
-template <int WM, int WN, int TM, int TN, int LOADER>
+//         1 = Cin == 4 (stem; a K chunk = 8 taps x 4 channels; tap is per-lane)
+//         2 = DCNv2 modulated deformable gather (Cin % 32 == 0, 3x3, pad 1): A through registers, B by DMA (WK == 1)
+// WK:     waves along K.  WM*WN*WK == 4.  With WK > 1 a pipeline stage holds WK consecutive 32-deep chunks and wave
+//         (wm, wn, wk) multiplies chunk wk of every stage; the WK partial tiles are summed (fixed order) in the
+//         epilogue's LDS tile.  This quarters the block tile (32x32 with WK = 4) without an inter-block reduction:
+//         4x the blocks and 1/4 of the serial K chain for the small-M layers (18x18 ... 5x5 maps) that otherwise
+//         leave most CUs idle behind one long K loop.
+template <int WM, int WN, int WK, int TM, int TN, int LOADER>
 __global__ __launch_bounds__(256) void conv_igemm_f32(const KParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // host pass: empty body.  hipcc (ROCm 7.2) silently drops the host launch stub of a
+                                      // templated kernel whose body uses the buffer-resource LDS-DMA builtins.
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr int RA = BM / 32, RB = BN / 32;  // float4 rows per thread for the A / B tile
-  static_assert(WM * WN == 4, "4 waves per block");
-  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDS_LD];
+  constexpr int RA = BM / 32, RB = BN / 32;  // 8-row DMA pieces per wave per chunk for the A / B tile
+  constexpr int SUB = (BM + BN) * BK;        // floats per chunk image [BM + BN rows][32]
+  constexpr int STAGE = SUB * WK;            // floats per pipeline stage
+  constexpr int ELD = BN + 4;                // epilogue tile row stride
+  constexpr int LDS_FLOATS = (2 * STAGE > WK * BM * ELD) ? 2 * STAGE : WK * BM * ELD;
+  static_assert(WM * WN * WK == 4, "4 waves per block");
+  static_assert(LOADER != 2 || WK == 1, "DCN gather runs without the K split");
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
   const ymi_conv_desc &d = p.d;
   const int t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  const int kq = t & 7, r0 = t >> 3;
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);   // wave-uniform -> SGPR (LDS-DMA bases)
+  const int wk = wave % WK, wmn = wave / WK;
+  const int wm = wmn / WN, wn = wmn % WN;
+  const int kq = t & 7, r0 = t >> 3;          // DMA: physical 16-byte slot and row (within a 32-row group) of this lane
+  const int sl = kq ^ ((r0 >> 1) & 7);        // logical k-slot that lives at this lane's physical position
 
   const int logical = ymi_xcd_remap(blockIdx.x, gridDim.x);
   const int tile_n = logical % p.tiles_n, tile_m = logical / p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)d.x, 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)d.w, 0, (int)p.w_bytes, 0x00020000);
+
+  // ---- epilogue thread mapping + residual prefetch -----------------------------------------------
+  // Each thread owns 4 consecutive output channels of RPT rows.  A plain residual (bottleneck shortcut) is fetched
+  // NOW, so its HBM latency overlaps the whole K loop instead of serialising behind it in the epilogue (the
+  // K <= 128 1x1 layers at 138x138 are HBM-bound: 2.3 TB/s before this, profiles/r01_*).
+  constexpr int C4 = BN / 4;        // float4 columns per tile row
+  constexpr int RSTEP = 256 / C4;   // rows covered by one pass of the block
+  constexpr int RPT = BM / RSTEP;   // rows per thread
+  constexpr bool RES_PREFETCH = RPT <= 8;
+  const int c4 = t % C4, rbase = t / C4;
+  const int n = n0 + 4 * c4;
+  const bool vec_res = (d.res_ld & 3) == 0 && ((((uintptr_t)d.res) & 15) == 0) && (n + 3 < d.Cout);
+  f32x4 rpre[RES_PREFETCH ? RPT : 1];
+  if (RES_PREFETCH && d.res_mode == YMI_RES_ADD && vec_res) {
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int m = m0 + rbase + RSTEP * i;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      rpre[i] = (m < p.M) ? *reinterpret_cast<const f32x4 *>(d.res + (size_t)m * d.res_ld + n) : z;
+    }
+  }
+
   // ---- per-thread A-row bookkeeping (fixed over the K loop) ---------------------------------
-  int a_iy0[RA], a_ix0[RA], a_base[RA];
+  int a_iy0[RA], a_ix0[RA], a_base[RA];        // a_base: byte offset of (pixel, channel 4*sl) for tap (0,0)
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
     const int m = m0 + r0 + 32 * i;
@@ -88,7 +136,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const KParams p) {
       const int oy = pix / d.Wo, ox = pix - oy * d.Wo;
       a_iy0[i] = oy * d.stride - d.pad;
       a_ix0[i] = ox * d.stride - d.pad;
-      a_base[i] = ((b * d.H + a_iy0[i]) * d.W + a_ix0[i]) * d.ldx;
+      a_base[i] = (((b * d.H + a_iy0[i]) * d.W + a_ix0[i]) * d.ldx + 4 * sl) * 4;
       if (LOADER == 2) a_base[i] = m;  // DCN: remember the output pixel, geometry recomputed per tap
     } else {
       a_iy0[i] = -(1 << 28);  // never valid
@@ -96,86 +144,99 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const KParams p) {
       a_base[i] = 0;
     }
   }
-  const float *wrow[RB];
+  unsigned b_off[RB];                           // byte offset of (filter row, k-slot sl) for chunk 0
 #pragma unroll
-  for (int i = 0; i < RB; ++i) wrow[i] = d.w + (size_t)(n0 + r0 + 32 * i) * d.Kpad + 4 * kq;
+  for (int i = 0; i < RB; ++i) b_off[i] = (unsigned)(((n0 + r0 + 32 * i) * d.Kpad + 4 * sl) * 4);
 
-  f32x4 ra[RA], rb[RB];
-  unsigned amask = 0;  // bit i: ra[i] holds real data (else it must be stored as zeros)
-
-  auto load_tiles = [&](int kc) {
-    amask = 0;
-    if (LOADER == 0) {
-      const int tap = kc / p.cpt, c = (kc - tap * p.cpt) * 32 + 4 * kq;
-      const int ky = tap / d.kw, kx = tap - ky * d.kw;
-      const int koff = (ky * d.W + kx) * d.ldx + c;
-#pragma unroll
-      for (int i = 0; i < RA; ++i) {
-        const bool ok = (unsigned)(a_iy0[i] + ky) < (unsigned)d.H && (unsigned)(a_ix0[i] + kx) < (unsigned)d.W;
-        // unconditional load from a clamped address + select: no branch, loads stay in flight together
-        ra[i] = *reinterpret_cast<const f32x4 *>(d.x + (ok ? (a_base[i] + koff) : 0));
-        amask |= (ok ? 1u : 0u) << i;  // zeroing is applied at store_lds time so the wait sits after the MFMAs
-      }
-    } else if (LOADER == 1) {
-      const int tap = kc * 8 + kq;
-      const int ky = tap / d.kw, kx = tap - ky * d.kw;
-      const bool tap_ok = tap < d.kh * d.kw;
-      const int koff = (ky * d.W + kx) * d.ldx;
-#pragma unroll
-      for (int i = 0; i < RA; ++i) {
-        const bool ok = tap_ok && (unsigned)(a_iy0[i] + ky) < (unsigned)d.H &&
-                        (unsigned)(a_ix0[i] + kx) < (unsigned)d.W;
-        // unconditional load from a clamped address + select: no branch, loads stay in flight together
-        ra[i] = *reinterpret_cast<const f32x4 *>(d.x + (ok ? (a_base[i] + koff) : 0));
-        amask |= (ok ? 1u : 0u) << i;  // zeroing is applied at store_lds time so the wait sits after the MFMAs
-      }
-    } else {
-      // DCNv2 (dcn_v2_im2col_cuda.cu:143-193): sample point = (oy*s - p + ky + dh, ox*s - p + kx + dw),
-      // zero unless -1 < h < H and -1 < w < W; zero-padded bilinear; times sigmoid(mask logit).
-      const int tap = kc / p.cpt, c = (kc - tap * p.cpt) * 32 + 4 * kq;
-      const int ky = tap / 3, kx = tap - ky * 3;
-#pragma unroll
-      for (int i = 0; i < RA; ++i) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (a_iy0[i] > -(1 << 27)) {
-          const int m = a_base[i];
-          const float *om = p.offmask + (size_t)m * p.ldo;
-          const float dh = om[2 * tap], dw = om[2 * tap + 1];
-          const float mk = 1.f / (1.f + expf(-om[18 + tap]));
-          const float h = (float)(a_iy0[i] + ky) + dh, w = (float)(a_ix0[i] + kx) + dw;
-          if (h > -1.f && w > -1.f && h < (float)d.H && w < (float)d.W) {
-            const int hl = (int)floorf(h), wl = (int)floorf(w);
-            const int hh = hl + 1, wh = wl + 1;
-            const float lh = h - (float)hl, lw = w - (float)wl, uh = 1.f - lh, uw = 1.f - lw;
-            const int b = m / p.HoWo;
-            const float *img = d.x + (size_t)b * d.H * d.W * d.ldx + c;
-            f32x4 v1 = {0.f, 0.f, 0.f, 0.f}, v2 = v1, v3 = v1, v4 = v1;
-            if (hl >= 0 && wl >= 0) v1 = *reinterpret_cast<const f32x4 *>(img + (hl * d.W + wl) * d.ldx);
-            if (hl >= 0 && wh <= d.W - 1) v2 = *reinterpret_cast<const f32x4 *>(img + (hl * d.W + wh) * d.ldx);
-            if (hh <= d.H - 1 && wl >= 0) v3 = *reinterpret_cast<const f32x4 *>(img + (hh * d.W + wl) * d.ldx);
-            if (hh <= d.H - 1 && wh <= d.W - 1) v4 = *reinterpret_cast<const f32x4 *>(img + (hh * d.W + wh) * d.ldx);
-            const float w1 = uh * uw, w2 = uh * lw, w3 = lh * uw, w4 = lh * lw;
-            v = (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4) * mk;
-          }
-        }
-        ra[i] = v;
-      }
-      amask = 0xffffffffu;
-    }
-#pragma unroll
-    for (int i = 0; i < RB; ++i) rb[i] = *reinterpret_cast<const f32x4 *>(wrow[i] + kc * BK);
+  // incremental (tap, channel-chunk) state of the next chunk to stage for each of the WK chunk slots (LOADER 0 / 2)
+  int nx_c[WK], nx_ky[WK], nx_kx[WK];
+  auto advance = [&](int j) {
+    nx_c[j] += BK;
+    if (nx_c[j] == d.Cin) { nx_c[j] = 0; if (++nx_kx[j] == d.kw) { nx_kx[j] = 0; ++nx_ky[j]; } }
   };
+#pragma unroll
+  for (int j = 0; j < WK; ++j) {
+    nx_c[j] = 0; nx_ky[j] = 0; nx_kx[j] = 0;
+    if (LOADER != 1) for (int a = 0; a < j; ++a) advance(j);
+  }
 
-  auto store_lds = [&](int buf) {
-    float *As = lds + buf * (BM + BN) * LDS_LD;
-    float *Bs = As + BM * LDS_LD;
+  f32x4 ra[LOADER == 2 ? RA : 1];
+
+  // stage step `st` (chunks st*WK .. st*WK + WK - 1) into LDS stage `buf`
+  auto issue_tile = [&](int st, int buf) {
 #pragma unroll
-    for (int i = 0; i < RA; ++i) {
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      *reinterpret_cast<f32x4 *>(As + (r0 + 32 * i) * LDS_LD + 4 * kq) = ((amask >> i) & 1u) ? ra[i] : z;
+    for (int j = 0; j < WK; ++j) {
+      const int kc = st * WK + j;
+      if (WK > 1 && kc >= p.nk) break;      // ragged last step: that chunk slot is simply not multiplied
+      float *As = lds + buf * STAGE + j * SUB;
+      float *Bs = As + BM * BK;
+      if (LOADER == 0) {
+        const int koff = ((nx_ky[j] * d.W + nx_kx[j]) * d.ldx + nx_c[j]) * 4;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+          const bool ok = (unsigned)(a_iy0[i] + nx_ky[j]) < (unsigned)d.H && (unsigned)(a_ix0[i] + nx_kx[j]) < (unsigned)d.W;
+          const unsigned voff = ok ? (unsigned)(a_base[i] + koff) : OOB;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(As + (wave * 8 + 32 * i) * BK), 16, voff, 0, 0, 0);
+        }
+      } else if (LOADER == 1) {
+        const int tap = kc * 8 + sl;
+        const int ky = tap / d.kw, kx = tap - ky * d.kw;
+        const bool tap_ok = tap < d.kh * d.kw;
+        const int koff = ((ky * d.W + kx) * d.ldx - 4 * sl) * 4;   // a_base carries +4*sl channels; Cin == 4 -> channel 0
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+          const bool ok = tap_ok && (unsigned)(a_iy0[i] + ky) < (unsigned)d.H && (unsigned)(a_ix0[i] + kx) < (unsigned)d.W;
+          const unsigned voff = ok ? (unsigned)(a_base[i] + koff) : OOB;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(As + (wave * 8 + 32 * i) * BK), 16, voff, 0, 0, 0);
+        }
+      } else {
+        // DCNv2 (dcn_v2_im2col_cuda.cu:143-193): sample point = (oy*s - p + ky + dh, ox*s - p + kx + dw),
+        // zero unless -1 < h < H and -1 < w < W; zero-padded bilinear; times sigmoid(mask logit).
+        // Thread (kq, r0) produces LOGICAL slot kq of its rows and stores it at the swizzled position.
+        const int tap = nx_ky[j] * 3 + nx_kx[j], c = nx_c[j] + 4 * kq;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (a_iy0[i] > -(1 << 27)) {
+            const int m = a_base[i];
+            const float *om = p.offmask + (size_t)m * p.ldo;
+            const float dh = om[2 * tap], dw = om[2 * tap + 1];
+            const float mk = 1.f / (1.f + expf(-om[18 + tap]));
+            const float h = (float)(a_iy0[i] + nx_ky[j]) + dh, w = (float)(a_ix0[i] + nx_kx[j]) + dw;
+            if (h > -1.f && w > -1.f && h < (float)d.H && w < (float)d.W) {
+              const int hl = (int)floorf(h), wl = (int)floorf(w);
+              const int hh = hl + 1, wh = wl + 1;
+              const float lh = h - (float)hl, lw = w - (float)wl, uh = 1.f - lh, uw = 1.f - lw;
+              const int b = m / p.HoWo;
+              const float *img = d.x + (size_t)b * d.H * d.W * d.ldx + c;
+              f32x4 v1 = {0.f, 0.f, 0.f, 0.f}, v2 = v1, v3 = v1, v4 = v1;
+              if (hl >= 0 && wl >= 0) v1 = *reinterpret_cast<const f32x4 *>(img + (hl * d.W + wl) * d.ldx);
+              if (hl >= 0 && wh <= d.W - 1) v2 = *reinterpret_cast<const f32x4 *>(img + (hl * d.W + wh) * d.ldx);
+              if (hh <= d.H - 1 && wl >= 0) v3 = *reinterpret_cast<const f32x4 *>(img + (hh * d.W + wl) * d.ldx);
+              if (hh <= d.H - 1 && wh <= d.W - 1) v4 = *reinterpret_cast<const f32x4 *>(img + (hh * d.W + wh) * d.ldx);
+              const float w1 = uh * uw, w2 = uh * lw, w3 = lh * uw, w4 = lh * lw;
+              v = (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4) * mk;
+            }
+          }
+          ra[i] = v;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < RB; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(Bs + (wave * 8 + 32 * i) * BK), 16, b_off[i], kc * (BK * 4), 0, 0);
+      if (LOADER != 1) {  // this slot's next chunk is WK chunks further
+#pragma unroll
+        for (int a = 0; a < WK; ++a) advance(j);
+      }
     }
+  };
+  // DCN only: registers -> swizzled LDS image
+  auto store_a_regs = [&](int buf) {
+    if (LOADER == 2) {
+      float *As = lds + buf * STAGE;
 #pragma unroll
-    for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4 *>(Bs + (r0 + 32 * i) * LDS_LD + 4 * kq) = rb[i];
+      for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4 *>(As + (r0 + 32 * i) * BK + 4 * sl) = ra[i];
+    }
   };
 
   f32x16 acc[TM][TN];
@@ -186,49 +247,72 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const KParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int frag_off = (lane & 31) * LDS_LD + 4 * (lane >> 5);
+  // fragment addressing: row = lane & 31 (+ tile offsets), logical slot 2g + h at physical (2g + h) ^ f
+  const int fsw = (lane >> 1) & 7, hh_ = lane >> 5;
+  const int frag_row = (lane & 31) * BK;
+  int fo[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) fo[g] = frag_row + 4 * ((2 * g + hh_) ^ fsw);
 
+  // Fragments are double-buffered in registers: the ds_read_b128s of k-group g+1 are issued before the 4*TM*TN
+  // MFMAs of group g, so LDS latency hides behind the matrix pipe even with a single wave on the SIMD.  The first
+  // two groups of a stage are requested BEFORE the next chunk's DMA is issued, so their latency overlaps the
+  // staging address math instead of stalling the first MFMA.
+  f32x4 fa[2][TM], fb[2][TN];
+  auto load_frag = [&](int buf, int g, int slot) {
+    const float *As = lds + buf * STAGE + wk * SUB + (wm * TM * 32) * BK;
+    const float *Bs = lds + buf * STAGE + wk * SUB + BM * BK + (wn * TN * 32) * BK;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[slot][i] = *reinterpret_cast<const f32x4 *>(As + i * 32 * BK + fo[g]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[slot][j] = *reinterpret_cast<const f32x4 *>(Bs + j * 32 * BK + fo[g]);
+  };
   auto compute = [&](int buf) {
-    const float *As = lds + buf * (BM + BN) * LDS_LD + (wm * TM * 32) * LDS_LD + frag_off;
-    const float *Bs = lds + buf * (BM + BN) * LDS_LD + BM * LDS_LD + (wn * TN * 32) * LDS_LD + frag_off;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      f32x4 a[TM], b[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4 *>(As + i * 32 * LDS_LD + g * 8);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4 *>(Bs + j * 32 * LDS_LD + g * 8);
+      const int slot = g & 1;
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][i][s], fb[slot][j][s], acc[i][j], 0, 0, 0);
+      if (g + 2 < 4) {
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch right behind the MFMAs that free its registers
+        load_frag(buf, g + 2, slot);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   };
 
   // ---- main loop ---------------------------------------------------------------------------
-  load_tiles(0);
-  store_lds(0);
-  __syncthreads();
-  for (int kc = 0; kc < p.nk; ++kc) {
-    const int cur = kc & 1;
-    const bool more = (kc + 1) < p.nk;
-    if (more && !(p.abl & 1)) load_tiles(kc + 1);
-    compute(cur);
-    if (more && !(p.abl & 2)) store_lds(cur ^ 1);
+  const int nsteps = (p.nk + WK - 1) / WK;
+  issue_tile(0, 0);
+  store_a_regs(0);
+  __syncthreads();   // drains the DMA (vmcnt(0)) then barrier
+  for (int st = 0; st < nsteps; ++st) {
+    const int cur = st & 1;
+    const bool more = (st + 1) < nsteps;
+    const bool mine = (WK == 1) || (st * WK + wk < p.nk);   // wave-uniform: does this wave's chunk exist?
+    if (mine) {
+      load_frag(cur, 0, 0);
+      load_frag(cur, 1, 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more && !(p.abl & 1)) issue_tile(st + 1, cur ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (mine) compute(cur);
+    if (more) store_a_regs(cur ^ 1);
     if (!(p.abl & 4)) __syncthreads();
   }
 
   // ---- epilogue ----------------------------------------------------------------------------
-  // Accumulators -> LDS tile [BM][BN+4] -> each thread owns 4 consecutive output channels of a row, so
-  // residual loads and output stores are 16 bytes per lane and 512 contiguous bytes per 32 lanes
+  // Accumulators -> LDS tile [WK][BM][BN+4] -> each thread owns 4 consecutive output channels of a row, so
+  // residual loads and output stores are 16 bytes per lane and 16*C4 contiguous bytes per row
   // (the first version stored one dword per lane per accumulator register and was store-issue bound on
   // the K <= 128 1x1 layers: 18-35 TF/s; see profiles/).
   // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5).
-  constexpr int ELD = BN + 4;
-  static_assert(BM * ELD <= 2 * (BM + BN) * LDS_LD, "epilogue tile must fit in the staging LDS");
   float *es = lds;  // the main loop ended with a barrier: LDS is free
   {
     const int ncol = lane & 31, half = lane >> 5;
@@ -238,15 +322,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const KParams p) {
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          es[((wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * ELD + (wn * TN + j) * 32 + ncol] = acc[i][j][r];
+          es[wk * (BM * ELD) + ((wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * ELD + (wn * TN + j) * 32 + ncol] =
+              acc[i][j][r];
   }
   __syncthreads();
 
-  constexpr int C4 = BN / 4;        // float4 columns per tile row
-  constexpr int RSTEP = 256 / C4;   // rows covered by one pass of the block
-  constexpr int RPT = BM / RSTEP;   // rows per thread
-  const int c4 = t % C4, rbase = t / C4;
-  const int n = n0 + 4 * c4;
   if (n >= d.Cout) return;
   f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -271,24 +351,25 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const KParams p) {
     vec_out = ((n - sg.n0) & 3) == 0 && (sg.row_stride & 3) == 0 && (sg.batch_stride & 3) == 0 &&
               (((uintptr_t)sg.ptr) & 15) == 0;
   }
-  const bool vec_res = (d.res_ld & 3) == 0 && ((((uintptr_t)d.res) & 15) == 0) && (n + 3 < d.Cout);
   float rscale_h = 0.f, rscale_w = 0.f;
   if (d.res_mode == YMI_RES_BILINEAR) {
     rscale_h = (float)d.res_H / (float)d.Ho;
     rscale_w = (float)d.res_W / (float)d.Wo;
   }
-#pragma unroll 4
+#pragma unroll
   for (int i = 0; i < RPT; ++i) {
     const int row = rbase + RSTEP * i;
     const int m = m0 + row;
     if (m >= p.M) continue;
     const int b = m / p.HoWo, pix = m - b * p.HoWo;
     f32x4 v = *reinterpret_cast<const f32x4 *>(es + row * ELD + 4 * c4);
+#pragma unroll
+    for (int q = 1; q < WK; ++q) v += *reinterpret_cast<const f32x4 *>(es + q * (BM * ELD) + row * ELD + 4 * c4);
     v = v * sc + bi;
     f32x4 rv = {0.f, 0.f, 0.f, 0.f};
     if (d.res_mode == YMI_RES_ADD) {
       const float *rp = d.res + (size_t)m * d.res_ld + n;
-      if (vec_res) rv = *reinterpret_cast<const f32x4 *>(rp);
+      if (vec_res) rv = RES_PREFETCH ? rpre[i] : *reinterpret_cast<const f32x4 *>(rp);
       else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) if (n + e < d.Cout) rv[e] = rp[e];
@@ -329,6 +410,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const KParams p) {
       }
     }
   }
+#endif  // __HIP_DEVICE_COMPILE__
 }
 
 // ---- host side --------------------------------------------------------------------------------
@@ -337,16 +419,17 @@ constexpr int PROF_MAX = 4096;
 ProfRec g_prof[PROF_MAX];
 int g_prof_n = 0, g_prof_alloc = 0, g_prof_on = 0;
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int WK, int TM, int TN>
 int launch_cfg(const KParams &kp, int loader, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   KParams p = kp;
   const int tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.d.Cout + BN - 1) / BN;
   const int grid = tiles_m * p.tiles_n;
-  if (loader == 0) hipLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, 0>), dim3(grid), dim3(256), 0, s, p);
-  else if (loader == 1) hipLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, 1>), dim3(grid), dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, 2>), dim3(grid), dim3(256), 0, s, p);
+  if (loader == 0) hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, 0>), dim3(grid), dim3(256), 0, s, p);
+  else if (loader == 1) hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, 1>), dim3(grid), dim3(256), 0, s, p);
+  else if constexpr (WK == 1) hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, 2>), dim3(grid), dim3(256), 0, s, p);
+  else return YMI_EARG;   // the DCN gather has no K-split variant
   return ymi_launch_status();
 }
 
@@ -357,6 +440,9 @@ int tile_dims(int tile, int &bm, int &bn) {
     case YMI_TILE_64x64: bm = 64; bn = 64; return 0;
     case YMI_TILE_128x32: bm = 128; bn = 32; return 0;
     case YMI_TILE_64x128: bm = 64; bn = 128; return 0;
+    case YMI_TILE_32x32_K4: bm = 32; bn = 32; return 0;
+    case YMI_TILE_64x32_K2: bm = 64; bn = 32; return 0;
+    case YMI_TILE_32x64_K2: bm = 32; bn = 64; return 0;
   }
   return -1;
 }
@@ -368,6 +454,9 @@ int pick_tile(const ymi_conv_desc *d) {
   // idle during its LDS-store/barrier/ds_read bubbles (u ~0.45), two or more overlap (u ~0.7-0.76).
   const long M = (long)d->B * d->Ho * d->Wo;
   const int N = d->Cout;
+  // few output tiles: quarter the tile and split K across the block's waves so every CU gets work and the serial
+  // K chain is 4x shorter (18x18 ... 5x5 maps)
+  if (((M + 63) / 64) * ((N + 63) / 64) < 512) return YMI_TILE_32x32_K4;
   if (N <= 32) return YMI_TILE_128x32;
   const int cand[4] = {YMI_TILE_128x128, YMI_TILE_128x64, YMI_TILE_64x128, YMI_TILE_64x64};
   const int occ[4] = {2, 2, 2, 4};
@@ -400,7 +489,10 @@ int validate(const ymi_conv_desc *d, int loader) {
   if (loader == 2 && (d->kh != 3 || d->kw != 3 || d->pad != 1)) return YMI_ESHAPE;
   if (d->Ho != (d->H + 2 * d->pad - d->kh) / d->stride + 1) return YMI_ESHAPE;
   if (d->Wo != (d->W + 2 * d->pad - d->kw) / d->stride + 1) return YMI_ESHAPE;
-  if ((long)d->B * d->H * d->W * d->ldx >= (1L << 31)) return YMI_ESHAPE;
+  // buffer-resource addressing: activation and filter tensors must each stay below 2 GiB
+  if ((long)d->B * d->H * d->W * d->ldx >= (1L << 29)) return YMI_ESHAPE;
+  if ((((long)d->Cout + 127) / 128 * 128) * d->Kpad >= (1L << 29)) return YMI_ESHAPE;
+  if ((((uintptr_t)d->x) & 15) || (((uintptr_t)d->w) & 15)) return YMI_ESHAPE;
   if (d->res_mode != YMI_RES_NONE && !d->res) return YMI_ENULL;
   return YMI_OK;
 }
@@ -413,12 +505,20 @@ int run_conv(const ymi_conv_desc *d, int loader, const float *offmask, int ldo, 
   kp.HoWo = d->Ho * d->Wo;
   kp.M = d->B * kp.HoWo;
   kp.nk = d->Kpad / BK;
-  kp.cpt = (loader == 1) ? 1 : d->Cin / 32;
   kp.tiles_n = 0;
+  kp.x_bytes = (unsigned)((size_t)d->B * d->H * d->W * d->ldx * sizeof(float));
+  {
+    const long cout_pad = ((long)d->Cout + 127) / 128 * 128;   // packing contract: CoutPad % 128 == 0
+    kp.w_bytes = (unsigned)(cout_pad * d->Kpad * (long)sizeof(float));
+  }
   kp.offmask = offmask;
   kp.ldo = ldo;
   { const char *e = getenv("YMI_ABLATE"); kp.abl = e ? atoi(e) : 0; }
   int tile = d->tile ? d->tile : pick_tile(d);
+  if (loader == 2 && (tile == YMI_TILE_32x32_K4 || tile == YMI_TILE_64x32_K2 || tile == YMI_TILE_32x64_K2)) {
+    if (d->tile) return YMI_EARG;   // explicit request the DCN gather cannot honour
+    tile = YMI_TILE_64x64;
+  }
   ProfRec *pr = nullptr;
   if (g_prof_on && g_prof_n < PROF_MAX) {
     pr = &g_prof[g_prof_n];
@@ -427,11 +527,14 @@ int run_conv(const ymi_conv_desc *d, int loader, const float *offmask, int ldo, 
     hipEventRecord(pr->e0, s);
   }
   switch (tile) {
-    case YMI_TILE_128x128: rc = launch_cfg<2, 2, 2, 2>(kp, loader, s); break;
-    case YMI_TILE_128x64: rc = launch_cfg<2, 2, 2, 1>(kp, loader, s); break;
-    case YMI_TILE_64x128: rc = launch_cfg<2, 2, 1, 2>(kp, loader, s); break;
-    case YMI_TILE_64x64: rc = launch_cfg<2, 2, 1, 1>(kp, loader, s); break;
-    case YMI_TILE_128x32: rc = launch_cfg<4, 1, 1, 1>(kp, loader, s); break;
+    case YMI_TILE_128x128: rc = launch_cfg<2, 2, 1, 2, 2>(kp, loader, s); break;
+    case YMI_TILE_128x64: rc = launch_cfg<2, 2, 1, 2, 1>(kp, loader, s); break;
+    case YMI_TILE_64x128: rc = launch_cfg<2, 2, 1, 1, 2>(kp, loader, s); break;
+    case YMI_TILE_64x64: rc = launch_cfg<2, 2, 1, 1, 1>(kp, loader, s); break;
+    case YMI_TILE_128x32: rc = launch_cfg<4, 1, 1, 1, 1>(kp, loader, s); break;
+    case YMI_TILE_32x32_K4: rc = launch_cfg<1, 1, 4, 1, 1>(kp, loader, s); break;
+    case YMI_TILE_64x32_K2: rc = launch_cfg<2, 1, 2, 1, 1>(kp, loader, s); break;
+    case YMI_TILE_32x64_K2: rc = launch_cfg<1, 2, 2, 1, 1>(kp, loader, s); break;
     default: return YMI_EARG;
   }
   if (pr) { hipEventRecord(pr->e1, s); ++g_prof_n; }

@@ -392,8 +392,10 @@ class Plan:
 
     def autotune(self, x: torch.Tensor, reps: int = 3):
         """Measure, don't guess: time every tile configuration of every distinct conv shape on the device (HIP
-        events on the launch stream) and keep the fastest.  All tile shapes accumulate K in the same order, so
-        the choice never changes results (tests/test_gpu_path.py::test_full_size_batch8_properties)."""
+        events on the launch stream) and keep the fastest.  The unsplit tile shapes accumulate K in the same
+        order (bit-identical results); the K-split tiles (_lib.KSPLIT_TILES) sum 2 or 4 partial chains in a fixed
+        order — deterministic for a given plan, ~1e-7 relative away from the unsplit order.  Set
+        YOLACT_AMD_TUNE_CACHE to a file to pin the choices across processes (bit-reproducible runs)."""
         cache_path = os.environ.get('YOLACT_AMD_TUNE_CACHE')
         disk = {}
         if cache_path and os.path.exists(cache_path):
@@ -411,12 +413,13 @@ class Plan:
             if key not in cache and str(key) in disk:
                 cache[key] = int(disk[str(key)])     # tuned in an earlier process (e.g. before a rocprofv3 run)
             if key not in cache:
+                ksplit = [L.TILE_32x32_K4, L.TILE_64x32_K2, L.TILE_32x64_K2]
                 if d.Cout <= 32:
-                    cands = [L.TILE_128x32, L.TILE_64x64]
+                    cands = [L.TILE_128x32, L.TILE_64x64, L.TILE_32x32_K4, L.TILE_64x32_K2]
                 elif d.Cout <= 64:
-                    cands = [L.TILE_128x64, L.TILE_64x64]
+                    cands = [L.TILE_128x64, L.TILE_64x64] + ksplit
                 else:
-                    cands = [L.TILE_128x128, L.TILE_128x64, L.TILE_64x128, L.TILE_64x64]
+                    cands = [L.TILE_128x128, L.TILE_128x64, L.TILE_64x128, L.TILE_64x64] + ksplit
                 best, best_ms, times = None, 1e30, {}
                 for t in cands:
                     d.tile = t
