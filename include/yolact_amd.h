@@ -66,7 +66,10 @@ typedef struct {
 /* block tile BMxBN; _Kn = the block's 4 waves also split K n ways (partial sums reduced in LDS in a fixed order:
  * deterministic, but a different fp32 summation order than the unsplit tiles) */
 enum { YMI_TILE_AUTO = 0, YMI_TILE_128x128 = 1, YMI_TILE_128x64 = 2, YMI_TILE_64x64 = 3, YMI_TILE_128x32 = 4,
-       YMI_TILE_64x128 = 5, YMI_TILE_32x32_K4 = 6, YMI_TILE_64x32_K2 = 7, YMI_TILE_32x64_K2 = 8 };
+       YMI_TILE_64x128 = 5, YMI_TILE_32x32_K4 = 6, YMI_TILE_64x32_K2 = 7, YMI_TILE_32x64_K2 = 8,
+       /* _Sn = n-stage LDS pipeline (n-1 K steps of LDS-DMA in flight); Cin % 32 == 0 layers only */
+       YMI_TILE_64x64_S3 = 9, YMI_TILE_64x64_S4 = 10, YMI_TILE_64x128_S3 = 11, YMI_TILE_128x64_S3 = 12,
+       YMI_TILE_32x32_K4_S4 = 13, YMI_TILE_64x32_K2_S3 = 14, YMI_TILE_32x64_K2_S3 = 15 };
 
 int ymi_abi_version(void);
 const char *ymi_strerror(int code);
@@ -152,6 +155,9 @@ int ymi_dcn_v2_forward_f32(const ymi_dcn_desc *d, void *stream);
 /* -- profiling hooks -------------------------------------------------------------------- */
 /* When enabled, every conv launch is bracketed by hipEvents on its stream; ymi_prof_read returns
  * (after synchronising) per-launch milliseconds, flops and tile ids. Used by bench.py roofline. */
+/* Diagnostics: when buf != NULL every conv block writes 8 x uint64 {xcc<<32 | HW_ID, t_start, t_loop, t_epilogue, t_end,
+ * t_transposed, t_computed, 0} (shader clock) at buf[blockIdx*8]; cap_blocks = capacity in blocks (larger grids are not traced). NULL disables. */
+int ymi_debug_set_trace(void *buf, long cap_blocks);
 int ymi_prof_enable(int on);
 int ymi_prof_count(void);
 int ymi_prof_read(int i, float *ms, double *flops, int32_t *tile, int32_t *kind);

@@ -14,8 +14,7 @@ def _g(seed):
     return torch.Generator().manual_seed(seed)
 
 
-TILES = [L.TILE_128x128, L.TILE_128x64, L.TILE_64x128, L.TILE_64x64, L.TILE_128x32, L.TILE_32x32_K4, L.TILE_64x32_K2,
-         L.TILE_32x64_K2]
+TILES = sorted(L.TILE_NAMES)
 
 
 @pytest.mark.parametrize('tile', TILES)

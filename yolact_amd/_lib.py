@@ -16,8 +16,11 @@ ACT_NONE, ACT_RELU, ACT_LEAKY01, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 RES_NONE, RES_ADD, RES_BILINEAR = 0, 1, 2
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32, TILE_64x128 = 0, 1, 2, 3, 4, 5
 TILE_32x32_K4, TILE_64x32_K2, TILE_32x64_K2 = 6, 7, 8
-TILE_NAMES = {1: '128x128', 2: '128x64', 3: '64x64', 4: '128x32', 5: '64x128', 6: '32x32k4', 7: '64x32k2', 8: '32x64k2'}
-KSPLIT_TILES = (6, 7, 8)   # different (still deterministic) fp32 summation order than the unsplit tiles
+TILE_64x64_S3, TILE_64x64_S4, TILE_64x128_S3, TILE_128x64_S3, TILE_32x32_K4_S4, TILE_64x32_K2_S3, TILE_32x64_K2_S3 = range(9, 16)
+TILE_NAMES = {1: '128x128', 2: '128x64', 3: '64x64', 4: '128x32', 5: '64x128', 6: '32x32k4', 7: '64x32k2', 8: '32x64k2',
+              9: '64x64s3', 10: '64x64s4', 11: '64x128s3', 12: '128x64s3', 13: '32x32k4s4', 14: '64x32k2s3', 15: '32x64k2s3'}
+BASIC_TILES = (1, 2, 3, 4, 5)      # available for every loader (stem, DCN)
+KSPLIT_TILES = (6, 7, 8, 13, 14, 15)   # different (still deterministic) fp32 summation order than the unsplit tiles
 
 
 class ConvSeg(C.Structure):
@@ -72,6 +75,7 @@ SYMBOLS = [
     ('ymi_mask_upsample_f32', C.c_int, [_P, _P, _I, _I, _I, _I, _I, _F, _P]),
     ('ymi_boxes_to_pixels', C.c_int, [_P, _P, _I, _I, _I, _P]),
     ('ymi_dcn_v2_forward_f32', C.c_int, [C.POINTER(DcnDesc), _P]),
+    ('ymi_debug_set_trace', C.c_int, [_P, C.c_long]),
     ('ymi_prof_enable', C.c_int, [_I]),
     ('ymi_prof_count', C.c_int, []),
     ('ymi_prof_read', C.c_int, [_I, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int32),

@@ -43,8 +43,10 @@ struct KParams {
   unsigned x_bytes, w_bytes;      // buffer-resource sizes
   const float *offmask;           // DCN only
   int ldo;
+  unsigned long long *trace;      // diagnostics only (ymi_debug_set_trace): per block {hw id, t0, t_loop, t_epi, t1, t_transposed}
   int abl;                        // diagnostics only (env YMI_ABLATE): bit0 skip the staging of chunks > 0,
-                                  // bit2 skip barriers in the K loop — wrong results, used to attribute stall time
+                                  // bit2 skip barriers in the K loop — wrong results, used to attribute stall time;
+                                  // bit3 disable the residency cap (results unaffected)
 };
 
 __device__ __forceinline__ float act_apply(float v, int act) {
@@ -68,6 +70,88 @@ __device__ __forceinline__ void bilin_coord(int dst, float scale, int in_size, i
   l1 = src - (float)i0;
 }
 
+// General epilogue (multi-segment scatter, unaligned rows, bilinear FPN residual, tanh / sigmoid): one row per loop
+// iteration, NOT unrolled — compact code matters more than ILP here (see the fast path's comment).  Inlined: a real
+// call would impose the callee's register budget and a scratch stack on the whole kernel (occupancy 5 -> 2).
+template <int BM, int BN, int WK, int RPT, int RSTEP, bool RES_PREFETCH>
+__device__ __forceinline__ void epilogue_general(const KParams &p, const float *es, f32x4 sc, f32x4 bi, const f32x4 *rpre,
+                                              int m0, int n, int c4, int rbase, bool vec_res) {
+  constexpr int ELD = BN + 4;
+  const ymi_conv_desc &d = p.d;
+  if (n >= d.Cout) return;
+  // The segment table lives in the kernel arguments; resolve it with compile-time indices + selects (indexing
+  // d.seg[] with a per-lane value turns into dependent per-lane global loads).
+  struct SegR { float *ptr; int64_t bs; int rs, act, n0; };
+  auto seg_of = [&](int nn) -> SegR {   // segment holding output channel nn (ptr == nullptr: none)
+    SegR r = {nullptr, 0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+      if (s < d.nseg && nn >= d.seg[s].n0 && nn < d.seg[s].n1 && nn < d.Cout)
+        r = SegR{d.seg[s].ptr, d.seg[s].batch_stride, d.seg[s].row_stride, d.seg[s].act, d.seg[s].n0};
+    return r;
+  };
+  SegR se[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) se[e] = seg_of(n + e);
+  // vector store only if all 4 channels live in one aligned segment
+  const bool vec_out = se[0].ptr != nullptr && se[0].ptr == se[3].ptr && ((n - se[0].n0) & 3) == 0 && (se[0].rs & 3) == 0 &&
+                       (se[0].bs & 3) == 0 && (((uintptr_t)se[0].ptr) & 15) == 0;
+  float rscale_h = 0.f, rscale_w = 0.f;
+  if (d.res_mode == YMI_RES_BILINEAR) {
+    rscale_h = (float)d.res_H / (float)d.Ho;
+    rscale_w = (float)d.res_W / (float)d.Wo;
+  }
+#pragma unroll 1
+  for (int i = 0; i < RPT; ++i) {
+    const int row = rbase + RSTEP * i;
+    const int m = m0 + row;
+    if (m >= p.M) break;
+    const int b = m / p.HoWo, pix = m - b * p.HoWo;
+    f32x4 v = *reinterpret_cast<const f32x4 *>(es + row * ELD + 4 * c4);
+#pragma unroll
+    for (int q = 1; q < WK; ++q) v += *reinterpret_cast<const f32x4 *>(es + q * (BM * ELD) + row * ELD + 4 * c4);
+    v = v * sc + bi;
+    f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+    if (d.res_mode == YMI_RES_ADD) {
+      const float *rp = d.res + (size_t)m * d.res_ld + n;
+      if (vec_res) rv = RES_PREFETCH ? rpre[i] : *reinterpret_cast<const f32x4 *>(rp);
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (n + e < d.Cout) rv[e] = rp[e];
+      }
+    } else if (d.res_mode == YMI_RES_BILINEAR) {
+      const int oy = pix / d.Wo, ox = pix - oy * d.Wo;
+      int y0, y1, x0, x1; float ly, lx;
+      bilin_coord(oy, rscale_h, d.res_H, y0, y1, ly);
+      bilin_coord(ox, rscale_w, d.res_W, x0, x1, lx);
+      const float *rb_ = d.res + (size_t)b * d.res_H * d.res_W * d.res_ld + n;
+      const float *p00 = rb_ + (size_t)(y0 * d.res_W + x0) * d.res_ld, *p01 = rb_ + (size_t)(y0 * d.res_W + x1) * d.res_ld;
+      const float *p10 = rb_ + (size_t)(y1 * d.res_W + x0) * d.res_ld, *p11 = rb_ + (size_t)(y1 * d.res_W + x1) * d.res_ld;
+      f32x4 v00 = rv, v01 = rv, v10 = rv, v11 = rv;
+      if (vec_res) {
+        v00 = *reinterpret_cast<const f32x4 *>(p00); v01 = *reinterpret_cast<const f32x4 *>(p01);
+        v10 = *reinterpret_cast<const f32x4 *>(p10); v11 = *reinterpret_cast<const f32x4 *>(p11);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < d.Cout) { v00[e] = p00[e]; v01[e] = p01[e]; v10[e] = p10[e]; v11[e] = p11[e]; }
+      }
+      rv = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+    }
+    f32x4 o = d.res_after_act ? v : v + rv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = act_apply(o[e], se[e].act);
+    if (d.res_after_act) o += rv;
+    if (vec_out) {
+      *reinterpret_cast<f32x4 *>(se[0].ptr + (size_t)b * se[0].bs + (size_t)pix * se[0].rs + (n - se[0].n0)) = o;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (se[e].ptr != nullptr) se[e].ptr[(size_t)b * se[e].bs + (size_t)pix * se[e].rs + (n + e - se[e].n0)] = o[e];
+    }
+  }
+}
+
 // LOADER: 0 = Cin % 32 == 0 (a K chunk lies inside one filter tap; tap is block-uniform)
 //         1 = Cin == 4 (stem; a K chunk = 8 taps x 4 channels; tap is per-lane)
 //         2 = DCNv2 modulated deformable gather (Cin % 32 == 0, 3x3, pad 1): A through registers, B by DMA (WK == 1)
@@ -76,16 +160,36 @@ __device__ __forceinline__ void bilin_coord(int dst, float scale, int in_size, i
 //         epilogue's LDS tile.  This quarters the block tile (32x32 with WK = 4) without an inter-block reduction:
 //         4x the blocks and 1/4 of the serial K chain for the small-M layers (18x18 ... 5x5 maps) that otherwise
 //         leave most CUs idle behind one long K loop.
-template <int WM, int WN, int WK, int TM, int TN, int LOADER>
-__global__ __launch_bounds__(256) void conv_igemm_f32(const KParams p) {
+// NSTAGE: LDS pipeline depth.  An LDS-DMA takes ~1 us from issue to landed under load (MI355X_MICROARCH.md,
+//         "ldsdma-fill"), i.e. longer than one K step of MFMA work (0.43 us at 16 MFMAs per wave), so with a prefetch
+//         distance of one step a CU needs >= 3 co-resident blocks to keep its matrix pipes fed.  NSTAGE = 3/4 keeps
+//         2/3 steps in flight per block (counted s_waitcnt vmcnt(N) + raw s_barrier, never a full drain), which is
+//         what the layers whose grid gives each CU only 1-3 blocks need.
+// blocks per CU the LDS footprint allows (= waves per SIMD for 256-thread blocks): the register budget handed to the
+// compiler, so that the epilogue's prefetch registers never cost a resident block
+template <int WM, int WN, int WK, int TM, int TN, int NSTAGE, int LOADER>
+constexpr int conv_occupancy() {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int ns = (LOADER == 2) ? 2 : NSTAGE;
+  constexpr int stage_b = ns * (BM + BN) * BK * WK * 4, epi_b = WK * BM * (BN + 4) * 4;
+  constexpr int lds_b = stage_b > epi_b ? stage_b : epi_b;
+  constexpr int occ = (160 * 1024) / lds_b;
+  return occ > 5 ? 5 : (occ < 1 ? 1 : occ);
+}
+
+template <int WM, int WN, int WK, int TM, int TN, int NSTAGE, int LOADER>
+__global__ __launch_bounds__(256, (conv_occupancy<WM, WN, WK, TM, TN, NSTAGE, LOADER>())) void conv_igemm_f32(const KParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // host pass: empty body.  hipcc (ROCm 7.2) silently drops the host launch stub of a
                                       // templated kernel whose body uses the buffer-resource LDS-DMA builtins.
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int RA = BM / 32, RB = BN / 32;  // 8-row DMA pieces per wave per chunk for the A / B tile
   constexpr int SUB = (BM + BN) * BK;        // floats per chunk image [BM + BN rows][32]
   constexpr int STAGE = SUB * WK;            // floats per pipeline stage
+  constexpr int NS = (LOADER == 2) ? 2 : NSTAGE;   // the register-staged DCN gather keeps the simple 2-stage drain
+  constexpr int DMA_PER_STEP = (RA + RB) * WK;     // LDS-DMA instructions every wave issues per step
   constexpr int ELD = BN + 4;                // epilogue tile row stride
-  constexpr int LDS_FLOATS = (2 * STAGE > WK * BM * ELD) ? 2 * STAGE : WK * BM * ELD;
+  constexpr int LDS_FLOATS = (NS * STAGE > WK * BM * ELD) ? NS * STAGE : WK * BM * ELD;
+  static_assert(DMA_PER_STEP * (NS - 2) <= 63, "vmcnt is a 6-bit counter");
   static_assert(WM * WN * WK == 4, "4 waves per block");
   static_assert(LOADER != 2 || WK == 1, "DCN gather runs without the K split");
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
@@ -98,6 +202,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const KParams p) {
   const int kq = t & 7, r0 = t >> 3;          // DMA: physical 16-byte slot and row (within a 32-row group) of this lane
   const int sl = kq ^ ((r0 >> 1) & 7);        // logical k-slot that lives at this lane's physical position
 
+  unsigned long long tr_t0 = 0, tr_loop = 0, tr_epi = 0, tr_tp = 0, tr_c = 0;
+  if (p.trace) tr_t0 = __builtin_readcyclecounter();
   const int logical = ymi_xcd_remap(blockIdx.x, gridDim.x);
   const int tile_n = logical % p.tiles_n, tile_m = logical / p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -126,6 +232,21 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const KParams p) {
     }
   }
 
+  // Folded-BN scale / bias are fetched NOW as well: epilogue loads sit behind the other blocks' DMA traffic in the
+  // CU's memory queue.
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+  if (n + 3 < d.Cout && (((uintptr_t)d.scale | (uintptr_t)d.bias) & 15) == 0) {
+    if (d.scale) sc = *reinterpret_cast<const f32x4 *>(d.scale + n);
+    if (d.bias) bi = *reinterpret_cast<const f32x4 *>(d.bias + n);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (n + e < d.Cout) {
+        if (d.scale) sc[e] = d.scale[n + e];
+        if (d.bias) bi[e] = d.bias[n + e];
+      }
+    }
+  }
   // ---- per-thread A-row bookkeeping (fixed over the K loop) ---------------------------------
   int a_iy0[RA], a_ix0[RA], a_base[RA];        // a_base: byte offset of (pixel, channel 4*sl) for tap (0,0)
 #pragma unroll
@@ -167,14 +288,16 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const KParams p) {
 #pragma unroll
     for (int j = 0; j < WK; ++j) {
       const int kc = st * WK + j;
-      if (WK > 1 && kc >= p.nk) break;      // ragged last step: that chunk slot is simply not multiplied
+      const bool live = (WK == 1) || (kc < p.nk);   // ragged last step: the slot is zero-filled (OOB) so that every
+                                                     // step issues the same number of DMAs (vmcnt accounting)
       float *As = lds + buf * STAGE + j * SUB;
       float *Bs = As + BM * BK;
       if (LOADER == 0) {
         const int koff = ((nx_ky[j] * d.W + nx_kx[j]) * d.ldx + nx_c[j]) * 4;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-          const bool ok = (unsigned)(a_iy0[i] + nx_ky[j]) < (unsigned)d.H && (unsigned)(a_ix0[i] + nx_kx[j]) < (unsigned)d.W;
+          const bool ok = live && (unsigned)(a_iy0[i] + nx_ky[j]) < (unsigned)d.H &&
+                          (unsigned)(a_ix0[i] + nx_kx[j]) < (unsigned)d.W;
           const unsigned voff = ok ? (unsigned)(a_base[i] + koff) : OOB;
           __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(As + (wave * 8 + 32 * i) * BK), 16, voff, 0, 0, 0);
         }
@@ -185,7 +308,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const KParams p) {
         const int koff = ((ky * d.W + kx) * d.ldx - 4 * sl) * 4;   // a_base carries +4*sl channels; Cin == 4 -> channel 0
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-          const bool ok = tap_ok && (unsigned)(a_iy0[i] + ky) < (unsigned)d.H && (unsigned)(a_ix0[i] + kx) < (unsigned)d.W;
+          const bool ok = live && tap_ok && (unsigned)(a_iy0[i] + ky) < (unsigned)d.H &&
+                          (unsigned)(a_ix0[i] + kx) < (unsigned)d.W;
           const unsigned voff = ok ? (unsigned)(a_base[i] + koff) : OOB;
           __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(As + (wave * 8 + 32 * i) * BK), 16, voff, 0, 0, 0);
         }
@@ -223,7 +347,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const KParams p) {
       }
 #pragma unroll
       for (int i = 0; i < RB; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(Bs + (wave * 8 + 32 * i) * BK), 16, b_off[i], kc * (BK * 4), 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(Bs + (wave * 8 + 32 * i) * BK), 16,
+                                                 live ? b_off[i] : OOB, live ? kc * (BK * 4) : 0, 0, 0);
       if (LOADER != 1) {  // this slot's next chunk is WK chunks further
 #pragma unroll
         for (int a = 0; a < WK; ++a) advance(j);
@@ -287,25 +412,71 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const KParams p) {
   };
 
   // ---- main loop ---------------------------------------------------------------------------
+  // s_waitcnt vmcnt(N) only (expcnt / lgkmcnt fields at "no wait"): gfx9 encoding vmcnt[3:0] | expcnt[6:4] |
+  // lgkmcnt[11:8] | vmcnt_hi[15:14].  The asm memory clobber keeps the compiler from moving LDS accesses across.
+#define YMI_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+#define YMI_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
   const int nsteps = (p.nk + WK - 1) / WK;
-  issue_tile(0, 0);
-  store_a_regs(0);
-  __syncthreads();   // drains the DMA (vmcnt(0)) then barrier
-  for (int st = 0; st < nsteps; ++st) {
-    const int cur = st & 1;
-    const bool more = (st + 1) < nsteps;
-    const bool mine = (WK == 1) || (st * WK + wk < p.nk);   // wave-uniform: does this wave's chunk exist?
-    if (mine) {
-      load_frag(cur, 0, 0);
-      load_frag(cur, 1, 1);
+  if (p.trace) tr_loop = __builtin_readcyclecounter();
+  if (NS == 2) {
+    issue_tile(0, 0);
+    store_a_regs(0);
+    __syncthreads();   // drains the DMA (vmcnt(0)) then barrier
+    for (int st = 0; st < nsteps; ++st) {
+      const int cur = st & 1;
+      const bool more = (st + 1) < nsteps;
+      const bool mine = (WK == 1) || (st * WK + wk < p.nk);   // wave-uniform: does this wave's chunk exist?
+      if (mine) {
+        load_frag(cur, 0, 0);
+        load_frag(cur, 1, 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (more && !(p.abl & 1)) issue_tile(st + 1, cur ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (mine) compute(cur);
+      if (more) store_a_regs(cur ^ 1);
+      if (!(p.abl & 4)) __syncthreads();
     }
-    __builtin_amdgcn_sched_barrier(0);
-    if (more && !(p.abl & 1)) issue_tile(st + 1, cur ^ 1);
-    __builtin_amdgcn_sched_barrier(0);
-    if (mine) compute(cur);
-    if (more) store_a_regs(cur ^ 1);
-    if (!(p.abl & 4)) __syncthreads();
+  } else {
+    // NS-1 steps in flight.  Stage of step s = s % NS.  At the end of iteration st the data of step st+1 must have
+    // landed: every wave waits until at most (steps issued beyond st+1) * DMA_PER_STEP of ITS DMAs are outstanding
+    // (they complete in order), then the barrier makes all waves' pieces visible.  Re-staging slot (st-1) % NS in
+    // iteration st is safe: its last readers passed the barrier that ended iteration st-1.
+#pragma unroll
+    for (int s0 = 0; s0 < NS - 1; ++s0)
+      if (s0 < nsteps) issue_tile(s0, s0);
+    {
+      const int fl = (nsteps < NS - 1 ? nsteps : NS - 1) - 1;   // steps allowed to stay in flight behind step 0
+      if (NS >= 4 && fl >= 2) YMI_WAIT_VM(2 * DMA_PER_STEP);
+      else if (fl >= 1) YMI_WAIT_VM(DMA_PER_STEP);
+      else YMI_WAIT_VM(0);
+    }
+    YMI_BARRIER();
+    int cur = 0, nxt = NS - 1;   // stage of step st, stage to refill (= stage of step st + NS - 1)
+    for (int st = 0; st < nsteps; ++st) {
+      const bool mine = (WK == 1) || (st * WK + wk < p.nk);
+      if (mine) {
+        load_frag(cur, 0, 0);
+        load_frag(cur, 1, 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (st + NS - 1 < nsteps && !(p.abl & 1)) issue_tile(st + NS - 1, nxt);
+      __builtin_amdgcn_sched_barrier(0);
+      if (mine) compute(cur);
+      if (st + 1 < nsteps) {
+        const int rem = nsteps - 2 - st;                        // steps issued beyond st+1
+        const int fl = rem < NS - 2 ? rem : NS - 2;
+        if (NS >= 4 && fl >= 2) YMI_WAIT_VM(2 * DMA_PER_STEP);
+        else if (fl >= 1) YMI_WAIT_VM(DMA_PER_STEP);
+        else YMI_WAIT_VM(0);
+      }
+      if (!(p.abl & 4)) YMI_BARRIER();
+      cur = (cur + 1 == NS) ? 0 : cur + 1;
+      nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+    }
   }
+#undef YMI_WAIT_VM
+#undef YMI_BARRIER
 
   // ---- epilogue ----------------------------------------------------------------------------
   // Accumulators -> LDS tile [WK][BM][BN+4] -> each thread owns 4 consecutive output channels of a row, so
@@ -313,6 +484,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const KParams p) {
   // (the first version stored one dword per lane per accumulator register and was store-issue bound on
   // the K <= 128 1x1 layers: 18-35 TF/s; see profiles/).
   // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5).
+  if (p.trace) tr_epi = __builtin_readcyclecounter();
   float *es = lds;  // the main loop ended with a barrier: LDS is free
   {
     const int ncol = lane & 31, half = lane >> 5;
@@ -327,88 +499,56 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const KParams p) {
   }
   __syncthreads();
 
-  if (n >= d.Cout) return;
-  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+  if (p.trace) tr_tp = __builtin_readcyclecounter();   // accumulators transposed through LDS
+  // ---- FAST PATH (block-uniform test): one dense, 16-byte aligned output segment, Cout % 4 == 0, residual none or
+  // prefetched, activation none / ReLU / LeakyReLU.  Covers every backbone / FPN-pred / protonet / upfeature layer.
+  // Kept tiny on purpose: the general path below is ~6000 instructions of divergent code and an epilogue wave
+  // streaming through it cold took 30k-70k cycles per block in steady state (instruction fetch behind the other
+  // blocks' memory traffic; block traces in profiles/), 8x longer than the same epilogue on an idle CU.
+  {
+    const ymi_conv_seg &g0 = d.seg[0];
+    const bool fast = d.nseg == 1 && g0.n0 == 0 && g0.n1 >= d.Cout && (d.Cout & 3) == 0 && (g0.row_stride & 3) == 0 &&
+                      (((uintptr_t)g0.ptr) & 15) == 0 && g0.batch_stride == (int64_t)p.HoWo * g0.row_stride &&
+                      g0.act <= YMI_ACT_LEAKY01 &&
+                      (d.res_mode == YMI_RES_NONE ||
+                       (RES_PREFETCH && d.res_mode == YMI_RES_ADD && (d.res_ld & 3) == 0 && ((((uintptr_t)d.res) & 15) == 0)));
+    if (fast) {
+      // act(x) = max(x, slope * x): slope 0 -> ReLU, 0.1 -> LeakyReLU(0.1), 1 -> identity (exact: one mul + one max)
+      const float slope = g0.act == YMI_ACT_RELU ? 0.f : (g0.act == YMI_ACT_LEAKY01 ? 0.1f : 1.f);
+      const bool has_res = d.res_mode == YMI_RES_ADD, after = d.res_after_act != 0;
+      f32x4 o[RPT];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    if (n + e < d.Cout) {
-      if (d.scale) sc[e] = d.scale[n + e];
-      if (d.bias) bi[e] = d.bias[n + e];
-    }
-  }
-  // segment of each of the 4 channels; vector store only if all 4 live in one aligned segment
-  int e_seg[4];
+      for (int i = 0; i < RPT; ++i) {
+        const int row = rbase + RSTEP * i;
+        f32x4 v = *reinterpret_cast<const f32x4 *>(es + row * ELD + 4 * c4);
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    e_seg[e] = -1;
+        for (int q = 1; q < WK; ++q) v += *reinterpret_cast<const f32x4 *>(es + q * (BM * ELD) + row * ELD + 4 * c4);
+        v = v * sc + bi;
+        f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+        if (RES_PREFETCH && has_res) rv = rpre[i];
+        if (!after) v += rv;
 #pragma unroll
-    for (int s = 0; s < 3; ++s)
-      if (s < d.nseg && n + e >= d.seg[s].n0 && n + e < d.seg[s].n1 && n + e < d.Cout) e_seg[e] = s;
-  }
-  bool vec_out = e_seg[0] >= 0 && e_seg[0] == e_seg[1] && e_seg[0] == e_seg[2] && e_seg[0] == e_seg[3];
-  if (vec_out) {
-    const ymi_conv_seg &sg = d.seg[e_seg[0]];
-    vec_out = ((n - sg.n0) & 3) == 0 && (sg.row_stride & 3) == 0 && (sg.batch_stride & 3) == 0 &&
-              (((uintptr_t)sg.ptr) & 15) == 0;
-  }
-  float rscale_h = 0.f, rscale_w = 0.f;
-  if (d.res_mode == YMI_RES_BILINEAR) {
-    rscale_h = (float)d.res_H / (float)d.Ho;
-    rscale_w = (float)d.res_W / (float)d.Wo;
-  }
-#pragma unroll
-  for (int i = 0; i < RPT; ++i) {
-    const int row = rbase + RSTEP * i;
-    const int m = m0 + row;
-    if (m >= p.M) continue;
-    const int b = m / p.HoWo, pix = m - b * p.HoWo;
-    f32x4 v = *reinterpret_cast<const f32x4 *>(es + row * ELD + 4 * c4);
-#pragma unroll
-    for (int q = 1; q < WK; ++q) v += *reinterpret_cast<const f32x4 *>(es + q * (BM * ELD) + row * ELD + 4 * c4);
-    v = v * sc + bi;
-    f32x4 rv = {0.f, 0.f, 0.f, 0.f};
-    if (d.res_mode == YMI_RES_ADD) {
-      const float *rp = d.res + (size_t)m * d.res_ld + n;
-      if (vec_res) rv = RES_PREFETCH ? rpre[i] : *reinterpret_cast<const f32x4 *>(rp);
-      else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) if (n + e < d.Cout) rv[e] = rp[e];
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], slope * v[e]);
+        if (after) v += rv;
+        o[i] = v;
       }
-    } else if (d.res_mode == YMI_RES_BILINEAR) {
-      const int oy = pix / d.Wo, ox = pix - oy * d.Wo;
-      int y0, y1, x0, x1; float ly, lx;
-      bilin_coord(oy, rscale_h, d.res_H, y0, y1, ly);
-      bilin_coord(ox, rscale_w, d.res_W, x0, x1, lx);
-      const float *rb_ = d.res + (size_t)b * d.res_H * d.res_W * d.res_ld + n;
-      const float *p00 = rb_ + (size_t)(y0 * d.res_W + x0) * d.res_ld, *p01 = rb_ + (size_t)(y0 * d.res_W + x1) * d.res_ld;
-      const float *p10 = rb_ + (size_t)(y1 * d.res_W + x0) * d.res_ld, *p11 = rb_ + (size_t)(y1 * d.res_W + x1) * d.res_ld;
-      f32x4 v00 = rv, v01 = rv, v10 = rv, v11 = rv;
-      if (vec_res) {
-        v00 = *reinterpret_cast<const f32x4 *>(p00); v01 = *reinterpret_cast<const f32x4 *>(p01);
-        v10 = *reinterpret_cast<const f32x4 *>(p10); v11 = *reinterpret_cast<const f32x4 *>(p11);
-      } else {
+      if (n < d.Cout) {
+        float *base = g0.ptr + (size_t)(m0 + rbase) * g0.row_stride + n;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (n + e < d.Cout) { v00[e] = p00[e]; v01[e] = p01[e]; v10[e] = p10[e]; v11[e] = p11[e]; }
+        for (int i = 0; i < RPT; ++i)
+          if (m0 + rbase + RSTEP * i < p.M) *reinterpret_cast<f32x4 *>(base + (size_t)(RSTEP * i) * g0.row_stride) = o[i];
       }
-      rv = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
-    }
-    if (vec_out) {
-      const ymi_conv_seg &sg = d.seg[e_seg[0]];
-      f32x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        o[e] = d.res_after_act ? act_apply(v[e], sg.act) + rv[e] : act_apply(v[e] + rv[e], sg.act);
-      *reinterpret_cast<f32x4 *>(sg.ptr + (size_t)b * sg.batch_stride + (size_t)pix * sg.row_stride + (n - sg.n0)) = o;
     } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (e_seg[e] < 0) continue;
-        const ymi_conv_seg &sg = d.seg[e_seg[e]];
-        const float o = d.res_after_act ? act_apply(v[e], sg.act) + rv[e] : act_apply(v[e] + rv[e], sg.act);
-        sg.ptr[(size_t)b * sg.batch_stride + (size_t)pix * sg.row_stride + (n + e - sg.n0)] = o;
-      }
+      epilogue_general<BM, BN, WK, RPT, RSTEP, RES_PREFETCH>(p, es, sc, bi, rpre, m0, n, c4, rbase, vec_res);
     }
+  }
+  if (p.trace && t == 0) {
+    // HW_REG_HW_ID (4): wave[3:0] simd[5:4] pipe[7:6] cu[11:8] sh[12] se[15:13]...; HW_REG_XCC_ID (20): xcc[3:0]
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
+    unsigned long long *o = p.trace + (size_t)blockIdx.x * 8;
+    o[0] = ((unsigned long long)xcc << 32) | hw;
+    o[1] = tr_t0; o[2] = tr_loop; o[3] = tr_epi; o[4] = __builtin_readcyclecounter(); o[5] = tr_tp; o[6] = tr_c;
   }
 #endif  // __HIP_DEVICE_COMPILE__
 }
@@ -417,34 +557,80 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const KParams p) {
 struct ProfRec { hipEvent_t e0, e1; double flops; int tile; int kind; };
 constexpr int PROF_MAX = 4096;
 ProfRec g_prof[PROF_MAX];
+unsigned long long *g_trace = nullptr;
+long g_trace_cap = 0;
 int g_prof_n = 0, g_prof_alloc = 0, g_prof_on = 0;
 
-template <int WM, int WN, int WK, int TM, int TN>
+// The workgroup dispatcher does not balance a grid that fits in one residency round: it packs up to `occupancy`
+// blocks on a CU while others hold fewer (a 616-block layer ran as if its busiest CU held 4+ blocks, not 3).  When
+// the grid is at most occ*256 blocks we therefore cap residency at k = ceil(grid / 256) blocks per CU by padding
+// the block's LDS allocation with unused dynamic LDS, so no CU can take more than its share.
+constexpr int LDS_PER_CU = 160 * 1024, NUM_CU = 256;
+
+template <int WM, int WN, int WK, int TM, int TN, int NS, bool ALL_LOADERS>
 int launch_cfg(const KParams &kp, int loader, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int ns_eff_bytes = NS * (BM + BN) * BK * WK * 4, epi_bytes = WK * BM * (BN + 4) * 4;
+  constexpr int static_lds = ns_eff_bytes > epi_bytes ? ns_eff_bytes : epi_bytes;
   KParams p = kp;
   const int tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.d.Cout + BN - 1) / BN;
   const int grid = tiles_m * p.tiles_n;
-  if (loader == 0) hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, 0>), dim3(grid), dim3(256), 0, s, p);
-  else if (loader == 1) hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, 1>), dim3(grid), dim3(256), 0, s, p);
-  else if constexpr (WK == 1) hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, 2>), dim3(grid), dim3(256), 0, s, p);
-  else return YMI_EARG;   // the DCN gather has no K-split variant
+  if (p.trace && grid > g_trace_cap) p.trace = nullptr;
+  int dyn = 0;
+  {
+    const int occ = LDS_PER_CU / static_lds;               // LDS-limited residency (VGPRs allow >= this for every tile)
+    const int k = (grid + NUM_CU - 1) / NUM_CU;             // blocks per CU if perfectly spread
+    if (k < occ && !(p.abl & 8)) {
+      const int want = LDS_PER_CU / (k + 1) + 1024;         // > 160K/(k+1)  =>  at most k blocks fit
+      if (want > static_lds && want <= LDS_PER_CU / k) dyn = want - static_lds;
+    }
+  }
+  if (loader == 0) {
+    hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, NS, 0>), dim3(grid), dim3(256), dyn, s, p);
+  } else if constexpr (ALL_LOADERS) {   // stem (Cin = 4) and DCN gather loaders exist for the basic tiles only
+    if (loader == 1) hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, NS, 1>), dim3(grid), dim3(256), dyn, s, p);
+    else hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, NS, 2>), dim3(grid), dim3(256), dyn, s, p);
+  } else {
+    return YMI_EARG;
+  }
   return ymi_launch_status();
 }
 
+// tile id -> (WM, WN, WK, TM, TN, NSTAGE, all loaders?)
+#define YMI_TILE_TABLE(X)                                   \
+  X(YMI_TILE_128x128, 2, 2, 1, 2, 2, 2, true)               \
+  X(YMI_TILE_128x64, 2, 2, 1, 2, 1, 2, true)                \
+  X(YMI_TILE_64x64, 2, 2, 1, 1, 1, 2, true)                 \
+  X(YMI_TILE_128x32, 4, 1, 1, 1, 1, 2, true)                \
+  X(YMI_TILE_64x128, 2, 2, 1, 1, 2, 2, true)                \
+  X(YMI_TILE_32x32_K4, 1, 1, 4, 1, 1, 2, false)             \
+  X(YMI_TILE_64x32_K2, 2, 1, 2, 1, 1, 2, false)             \
+  X(YMI_TILE_32x64_K2, 1, 2, 2, 1, 1, 2, false)             \
+  X(YMI_TILE_64x64_S3, 2, 2, 1, 1, 1, 3, false)             \
+  X(YMI_TILE_64x64_S4, 2, 2, 1, 1, 1, 4, false)             \
+  X(YMI_TILE_64x128_S3, 2, 2, 1, 1, 2, 3, false)            \
+  X(YMI_TILE_128x64_S3, 2, 2, 1, 2, 1, 3, false)            \
+  X(YMI_TILE_32x32_K4_S4, 1, 1, 4, 1, 1, 4, false)          \
+  X(YMI_TILE_64x32_K2_S3, 2, 1, 2, 1, 1, 3, false)          \
+  X(YMI_TILE_32x64_K2_S3, 1, 2, 2, 1, 1, 3, false)
+
 int tile_dims(int tile, int &bm, int &bn) {
   switch (tile) {
-    case YMI_TILE_128x128: bm = 128; bn = 128; return 0;
-    case YMI_TILE_128x64: bm = 128; bn = 64; return 0;
-    case YMI_TILE_64x64: bm = 64; bn = 64; return 0;
-    case YMI_TILE_128x32: bm = 128; bn = 32; return 0;
-    case YMI_TILE_64x128: bm = 64; bn = 128; return 0;
-    case YMI_TILE_32x32_K4: bm = 32; bn = 32; return 0;
-    case YMI_TILE_64x32_K2: bm = 64; bn = 32; return 0;
-    case YMI_TILE_32x64_K2: bm = 32; bn = 64; return 0;
+#define X(id, wm, wn, wk, tm, tn, ns, all) case id: bm = wm * tm * 32; bn = wn * tn * 32; return 0;
+    YMI_TILE_TABLE(X)
+#undef X
   }
   return -1;
+}
+
+bool tile_all_loaders(int tile) {
+  switch (tile) {
+#define X(id, wm, wn, wk, tm, tn, ns, all) case id: return all;
+    YMI_TILE_TABLE(X)
+#undef X
+  }
+  return false;
 }
 
 int pick_tile(const ymi_conv_desc *d) {
@@ -514,9 +700,10 @@ int run_conv(const ymi_conv_desc *d, int loader, const float *offmask, int ldo, 
   kp.offmask = offmask;
   kp.ldo = ldo;
   { const char *e = getenv("YMI_ABLATE"); kp.abl = e ? atoi(e) : 0; }
+  kp.trace = g_trace;
   int tile = d->tile ? d->tile : pick_tile(d);
-  if (loader == 2 && (tile == YMI_TILE_32x32_K4 || tile == YMI_TILE_64x32_K2 || tile == YMI_TILE_32x64_K2)) {
-    if (d->tile) return YMI_EARG;   // explicit request the DCN gather cannot honour
+  if (loader != 0 && !tile_all_loaders(tile)) {
+    if (d->tile) return YMI_EARG;   // explicit request the stem / DCN loaders cannot honour
     tile = YMI_TILE_64x64;
   }
   ProfRec *pr = nullptr;
@@ -527,14 +714,9 @@ int run_conv(const ymi_conv_desc *d, int loader, const float *offmask, int ldo, 
     hipEventRecord(pr->e0, s);
   }
   switch (tile) {
-    case YMI_TILE_128x128: rc = launch_cfg<2, 2, 1, 2, 2>(kp, loader, s); break;
-    case YMI_TILE_128x64: rc = launch_cfg<2, 2, 1, 2, 1>(kp, loader, s); break;
-    case YMI_TILE_64x128: rc = launch_cfg<2, 2, 1, 1, 2>(kp, loader, s); break;
-    case YMI_TILE_64x64: rc = launch_cfg<2, 2, 1, 1, 1>(kp, loader, s); break;
-    case YMI_TILE_128x32: rc = launch_cfg<4, 1, 1, 1, 1>(kp, loader, s); break;
-    case YMI_TILE_32x32_K4: rc = launch_cfg<1, 1, 4, 1, 1>(kp, loader, s); break;
-    case YMI_TILE_64x32_K2: rc = launch_cfg<2, 1, 2, 1, 1>(kp, loader, s); break;
-    case YMI_TILE_32x64_K2: rc = launch_cfg<1, 2, 2, 1, 1>(kp, loader, s); break;
+#define X(id, wm, wn, wk, tm, tn, ns, all) case id: rc = launch_cfg<wm, wn, wk, tm, tn, ns, all>(kp, loader, s); break;
+    YMI_TILE_TABLE(X)
+#undef X
     default: return YMI_EARG;
   }
   if (pr) { hipEventRecord(pr->e1, s); ++g_prof_n; }
@@ -560,6 +742,12 @@ int ymi_dcn_v2_forward_f32(const ymi_dcn_desc *d, void *stream) {
   if (!d || !d->offmask) return YMI_ENULL;
   if (d->ldo < 27) return YMI_ESHAPE;
   return run_conv(&d->conv, 2, d->offmask, d->ldo, (hipStream_t)stream);
+}
+
+int ymi_debug_set_trace(void *buf, long cap_blocks) {
+  g_trace = (unsigned long long *)buf;
+  g_trace_cap = cap_blocks;
+  return YMI_OK;
 }
 
 int ymi_prof_enable(int on) { g_prof_on = on; return YMI_OK; }

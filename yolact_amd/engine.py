@@ -413,13 +413,17 @@ class Plan:
             if key not in cache and str(key) in disk:
                 cache[key] = int(disk[str(key)])     # tuned in an earlier process (e.g. before a rocprofv3 run)
             if key not in cache:
-                ksplit = [L.TILE_32x32_K4, L.TILE_64x32_K2, L.TILE_32x64_K2]
-                if d.Cout <= 32:
-                    cands = [L.TILE_128x32, L.TILE_64x64, L.TILE_32x32_K4, L.TILE_64x32_K2]
+                if d.Cin % 32 != 0:          # stem loader: basic tiles only
+                    cands = [L.TILE_128x64, L.TILE_64x64] if d.Cout <= 64 else list(L.BASIC_TILES)
+                elif d.Cout <= 32:
+                    cands = [L.TILE_128x32, L.TILE_64x64, L.TILE_64x64_S3, L.TILE_32x32_K4, L.TILE_32x32_K4_S4,
+                             L.TILE_64x32_K2, L.TILE_64x32_K2_S3]
                 elif d.Cout <= 64:
-                    cands = [L.TILE_128x64, L.TILE_64x64] + ksplit
+                    cands = [L.TILE_128x64, L.TILE_128x64_S3, L.TILE_64x64, L.TILE_64x64_S3, L.TILE_64x64_S4,
+                             L.TILE_32x32_K4, L.TILE_32x32_K4_S4, L.TILE_64x32_K2, L.TILE_64x32_K2_S3,
+                             L.TILE_32x64_K2, L.TILE_32x64_K2_S3]
                 else:
-                    cands = [L.TILE_128x128, L.TILE_128x64, L.TILE_64x128, L.TILE_64x64] + ksplit
+                    cands = [t for t in sorted(L.TILE_NAMES) if t != L.TILE_128x32]
                 best, best_ms, times = None, 1e30, {}
                 for t in cands:
                     d.tile = t
