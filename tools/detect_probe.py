@@ -1,0 +1,24 @@
+#!/usr/bin/env python
+"""Time Detect (3 kernels) on the dense R50 batch-8 head outputs, with ablations of K2 (YMI_DETECT_ABLATE)."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+dev = torch.device('cuda', 0)
+with torch.no_grad():
+    net, sd = bench.build_model(dev, 550)
+    from yolact_amd.utils.synth import synth_images
+    x = synth_images(8, 550, 550, seed=1234).to(dev)
+    net.forward_device(x)
+    plan = net.plan_for(x)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for abl in (0, 1, 4, 5):
+        os.environ['YMI_DETECT_ABLATE'] = str(abl)
+        for _ in range(2):
+            net.detect.run_device(plan.loc, plan.conf, plan.coef, plan.priors, True)
+        e0.record()
+        for _ in range(10):
+            o = net.detect.run_device(plan.loc, plan.conf, plan.coef, plan.priors, True)
+        e1.record(); e1.synchronize()
+        print('ablate=%d  detect %.1f us  counts %s  num_keep %s' % (abl, e0.elapsed_time(e1) * 100, o['count'].tolist(),
+              net.detect._ws[next(iter(net.detect._ws))]['num_keep'].tolist()))

@@ -4,12 +4,14 @@
 //
 // Whole batch in three launches, no host synchronisation, fixed-capacity outputs + counts:
 //   K1  grid (P/64, B)      softmax over C classes, fg max/argmax, keep = max > conf_thresh, class-major scores
-//   K2  grid (nclass, B)    radix-select the top_k kept priors of a class (ties: lowest prior index first),
-//                           bitonic sort, decode their boxes, IoU upper triangle, keep iou_max <= nms_thresh
-//   K3  grid (B)            radix-select + sort the best max_det survivors over all classes, gather outputs
+//   K2  grid (nclass, B)    select the top_k kept priors of a class (register-resident bisection; ties: lowest prior
+//                           index first), bitonic sort, decode their boxes, folded IoU upper triangle,
+//                           keep iou_max <= nms_thresh
+//   K3  grid (B)            select + sort the best max_det survivors over all classes, gather outputs
 // Tie rule: the reference sorts with the unstable torch.sort; we define stable order (lowest index first),
 // SURVEY §7 hard part 3(iv).  All float math mirrors the reference's op order; build with -ffp-contract=off.
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/yolact_amd.h"
 
 namespace {
@@ -96,8 +98,8 @@ __global__ __launch_bounds__(256) void softmax_keep_k(const float *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Block-wide radix select + sort.  key(i) for i in [0,n): 0 = not a candidate.  Selects the k largest keys,
-// ties broken by lowest i, and leaves them sorted (key desc, i asc) in sh_key/sh_idx[0..k).
+// Block-wide top-k selection + sort.  Keys: order-preserving uint of the score, 0 = not a candidate.  Selects the k
+// largest keys, ties broken by lowest index, and leaves them sorted (key desc, index asc) in sh.comp[0..k).
 struct SelShared {
   unsigned hist[256];
   unsigned long long comp[SORT_N];
@@ -105,64 +107,94 @@ struct SelShared {
   unsigned wave_tot[NT / 64];
 };
 
-template <typename KeyFn>
-__device__ void block_topk_sorted(KeyFn key, int n, int k, SelShared &sh) {
-  const int t = threadIdx.x;
-  unsigned prefix = 0, mask = 0, krem = (unsigned)k, eq_total = 0;
-  for (int shift = 24; shift >= 0; shift -= 8) {
-    sh.hist[t] = 0;  // NT == 256 bins
-    __syncthreads();
-    for (int i = t; i < n; i += NT) {
-      const unsigned kk = key(i);
-      if (kk != 0 && (kk & mask) == prefix) atomicAdd(&sh.hist[(kk >> shift) & 255u], 1u);
-    }
-    __syncthreads();
-    if (t == 0) {
-      unsigned acc = 0; int bin = 255;
-      for (; bin > 0; --bin) { if (acc + sh.hist[bin] >= krem) break; acc += sh.hist[bin]; }
-      sh.prefix = prefix | ((unsigned)bin << shift);
-      sh.krem = krem - acc;
-      sh.cnt_eq = sh.hist[bin];
-    }
-    __syncthreads();
-    prefix = sh.prefix; krem = sh.krem; eq_total = sh.cnt_eq;
-    mask |= 255u << shift;
-    __syncthreads();
-  }
-  const unsigned T = prefix;  // key of the k-th largest; krem of the eq_total elements equal to T are taken
-  sh.comp[t] = 0ull;          // SORT_N == NT
-  if (t == 0) { sh.cnt_gt = 0; sh.sel_eq = 0; }
-  __syncthreads();
-  const unsigned n_gt = (unsigned)k - krem;
-  if (eq_total == krem) {
-    // common case: every element equal to T is taken; slot order is irrelevant (sorted below)
-    for (int i = t; i < n; i += NT) {
-      const unsigned kk = key(i);
-      if (kk != 0 && kk >= T) {
-        const unsigned slot = atomicAdd(&sh.cnt_gt, 1u);
-        sh.comp[slot] = ((unsigned long long)kk << 32) | (unsigned)(0xffffffffu - (unsigned)i);
+// ------------------------------------------------------------------------------------------------
+// Register-resident top-k: every thread holds EPT keys (element i = t + NT*j) in VGPRs and the k-th largest key is
+// found by bisection on its 32 bits (one block-wide count per bit: compares on registers, a wave reduction and ONE
+// barrier) — no memory traffic and no atomics in the search.  The LDS-histogram radix select above needs 4 passes
+// over global memory and serialises on a handful of hot bins (softmax scores share their top byte): 282 us for
+// the 640 (class, image) blocks of a batch-8 step, vs ~25 us this way.
+// Result: the selected elements sorted (key desc, index asc) in sh.comp[0..k) like block_topk_sorted.
+// EPT > 0: keys[] holds element t + NT*j in registers.  EPT == 0 (n too large for the register file): the same
+// algorithm re-evaluates key(i) from memory (L2-resident) on every pass.
+template <int EPT, typename KeyFn>
+__device__ void block_topk_regs(const unsigned (&keys)[EPT > 0 ? EPT : 1], KeyFn key, int n, int k, SelShared &sh) {
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int rounds = EPT > 0 ? EPT : (n + NT - 1) / NT;
+  auto key_at = [&](int j) -> unsigned {          // EPT == 0 only
+    const int i = t + NT * j;
+    return i < n ? key(i) : 0u;
+  };
+  auto block_count = [&](unsigned cand, bool strict, int slot) -> unsigned {
+    // the compare's lane mask IS the ballot: popcount + add run on the scalar unit, no cross-lane traffic
+    unsigned c = 0;
+    if (EPT > 0) {
+#pragma unroll
+      for (int j = 0; j < (EPT > 0 ? EPT : 1); ++j)
+        c += (unsigned)__popcll(__ballot(strict ? keys[j] > cand : keys[j] >= cand));
+    } else {
+      for (int j = 0; j < rounds; ++j) {
+        const unsigned kk = key_at(j);
+        c += (unsigned)__popcll(__ballot(strict ? kk > cand : kk >= cand));
       }
     }
+    if (lane == 0) sh.hist[slot * 4 + w] = c;
+    __syncthreads();
+    return sh.hist[slot * 4] + sh.hist[slot * 4 + 1] + sh.hist[slot * 4 + 2] + sh.hist[slot * 4 + 3];
+  };
+  unsigned T = 0;
+  for (int bit = 31; bit >= 0; --bit) {
+    const unsigned cand = T | (1u << bit);
+    if (block_count(cand, false, bit & 1) >= (unsigned)k) T = cand;   // alternating slots: one barrier per bit
+  }
+  __syncthreads();
+  const unsigned n_gt = block_count(T, true, 0);      // keys strictly above the threshold: all taken
+  const unsigned n_ge = block_count(T, false, 1);
+  const unsigned krem = (unsigned)k - n_gt;            // how many of the keys == T are taken (lowest indices first)
+  sh.comp[t] = 0ull;                                   // SORT_N == NT
+  if (t == 0) { sh.cnt_gt = 0; }
+  __syncthreads();
+  if (n_ge - n_gt == krem) {
+    // common case: every key equal to T is taken; slot order is irrelevant (sorted below)
+    auto take = [&](unsigned kj, int j) {
+      const bool win = kj != 0 && kj >= T;
+      const unsigned long long bal = __ballot(win);
+      if (bal) {                                       // wave-uniform
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(&sh.cnt_gt, (unsigned)__popcll(bal));
+        base = __shfl(base, 0);
+        if (win) {
+          const unsigned slot = base + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+          sh.comp[slot] = ((unsigned long long)kj << 32) | (unsigned)(0xffffffffu - (unsigned)(t + NT * j));
+        }
+      }
+    };
+    if constexpr (EPT > 0) {
+#pragma unroll
+      for (int j = 0; j < EPT; ++j) take(keys[j], j);
+    } else {
+      for (int j = 0; j < rounds; ++j) take(key_at(j), j);
+    }
   } else {
-    // tie on the threshold with more equals than slots: take the lowest indices, in index order
-    unsigned base_eq = 0;  // equals seen in earlier chunks (uniform across the block)
-    for (int c0 = 0; c0 < n; c0 += NT) {
-      const int i = c0 + t;
-      const unsigned kk = i < n ? key(i) : 0u;
+    // tie on the threshold with more equals than slots: index order = (j, wave, lane); rare, one barrier per round
+    unsigned base_eq = 0;
+    for (int j = 0; j < rounds; ++j) {
+      unsigned kk = 0;
+      if (EPT > 0) {
+#pragma unroll
+        for (int jj = 0; jj < (EPT > 0 ? EPT : 1); ++jj) if (jj == j) kk = keys[jj];   // register array: no dynamic indexing
+      } else {
+        kk = key_at(j);
+      }
       const bool gt = kk != 0 && kk > T, eq = kk != 0 && kk == T;
       const unsigned long long bal = __ballot(eq);
-      const int lane = t & 63, w = t >> 6;
       if (lane == 0) sh.wave_tot[w] = (unsigned)__popcll(bal);
       __syncthreads();
       unsigned before = base_eq, tot = 0;
       for (int ww = 0; ww < NT / 64; ++ww) { if (ww < w) before += sh.wave_tot[ww]; tot += sh.wave_tot[ww]; }
       before += (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
-      if (gt) {
-        const unsigned slot = atomicAdd(&sh.cnt_gt, 1u);
-        sh.comp[slot] = ((unsigned long long)kk << 32) | (unsigned)(0xffffffffu - (unsigned)i);
-      } else if (eq && before < krem) {
-        sh.comp[n_gt + before] = ((unsigned long long)kk << 32) | (unsigned)(0xffffffffu - (unsigned)i);
-      }
+      const unsigned long long comp = ((unsigned long long)kk << 32) | (unsigned)(0xffffffffu - (unsigned)(t + NT * j));
+      if (gt) sh.comp[atomicAdd(&sh.cnt_gt, 1u)] = comp;
+      else if (eq && before < krem) sh.comp[n_gt + before] = comp;
       base_eq += tot;
       __syncthreads();
     }
@@ -182,14 +214,38 @@ __device__ void block_topk_sorted(KeyFn key, int n, int k, SelShared &sh) {
   }
 }
 
-// K2: one block per (class, image)
-__global__ __launch_bounds__(NT) void class_topk_nms_k(const float *__restrict__ scores,  // [B,nclass,P]
+// max_{i in [r0,r1)} IoU(box i, box j) exactly as jaccard() evaluates it (box_utils.py:47-51,72-79):
+// inter / (area_i + area_j - inter).  A NaN IoU poisons the column with +inf (the reference's `iou_max <= thresh`
+// is False for NaN).
+__device__ __forceinline__ float iou_colmax(const float (*bx)[4], int j, int r0, int r1) {
+  const float x1 = bx[j][0], y1 = bx[j][1], x2 = bx[j][2], y2 = bx[j][3];
+  const float area_j = (x2 - x1) * (y2 - y1);
+  float m = 0.f;
+  for (int i = r0; i < r1; ++i) {
+    const float ax1 = bx[i][0], ay1 = bx[i][1], ax2 = bx[i][2], ay2 = bx[i][3];
+    float iw = fminf(ax2, x2) - fmaxf(ax1, x1);
+    float ih = fminf(ay2, y2) - fmaxf(ay1, y1);
+    iw = iw < 0.f ? 0.f : iw;
+    ih = ih < 0.f ? 0.f : ih;
+    const float inter = iw * ih;
+    const float area_i = (ax2 - ax1) * (ay2 - ay1);
+    const float iou = inter / ((area_i + area_j) - inter);
+    m = (iou != iou) ? __builtin_inff() : (iou > m ? iou : m);
+  }
+  return m;
+}
+
+// K2: one block per (class, image).  EPT = keys per thread (0: keys stay in memory)
+template <int EPT>
+__global__ __launch_bounds__(NT, (EPT > 80 ? 1 : 2)) void class_topk_nms_k(const float *__restrict__ scores,  // [B,nclass,P]
                                                        const int *__restrict__ keep, const int *__restrict__ num_keep,
                                                        const float *__restrict__ loc, const float *__restrict__ priors,
                                                        int P, int nclass, int top_k, float nms_thresh,
-                                                       float *__restrict__ cand_score, int *__restrict__ cand_prior) {
+                                                       float *__restrict__ cand_score, int *__restrict__ cand_prior,
+                                                       int dbg) {
   __shared__ SelShared sh;
   __shared__ float bx[SORT_N][4];
+  __shared__ float pm_long[SORT_N], pm_short[SORT_N];
   const int c = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
   const int K = num_keep[b];
   float *cs = cand_score + ((size_t)b * nclass + c) * top_k;
@@ -201,7 +257,21 @@ __global__ __launch_bounds__(NT) void class_topk_nms_k(const float *__restrict__
   const int k = K < top_k ? K : top_k;
   const float *sc = scores + ((size_t)b * nclass + c) * P;
   const int *kp = keep + (size_t)b * P;
-  block_topk_sorted([&](int i) -> unsigned { return kp[i] ? f2key(sc[i]) : 0u; }, P, k, sh);
+  if constexpr (EPT > 0) {
+    unsigned keys[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+      const int i = t + NT * j, ii = i < P ? i : 0;   // unconditional, independent loads: all 2*EPT stay in flight
+      const int kf = kp[ii];
+      const float sv = sc[ii];
+      keys[j] = (i < P && kf) ? f2key(sv) : 0u;
+    }
+    if (dbg & 1) { sh.comp[t] = ((unsigned long long)keys[0] << 32) | (unsigned)(0xffffffffu - (unsigned)t); __syncthreads(); }
+    else block_topk_regs<EPT>(keys, [](int) -> unsigned { return 0u; }, P, k, sh);
+  } else {
+    const unsigned none[1] = {0u};
+    block_topk_regs<0>(none, [&](int i) -> unsigned { return kp[i] ? f2key(sc[i]) : 0u; }, P, k, sh);
+  }
 
   // rank t -> prior index, score, decoded box
   int prior = -1;
@@ -213,27 +283,28 @@ __global__ __launch_bounds__(NT) void class_topk_nms_k(const float *__restrict__
     bx[t][0] = bb[0]; bx[t][1] = bb[1]; bx[t][2] = bb[2]; bx[t][3] = bb[3];
   }
   __syncthreads();
+  // iou_max[j] = max_{i<j} IoU(i, j) (0 for j = 0); keep = iou_max <= nms_thresh.  Column j costs j IoUs, so the long
+  // columns j in [k-h, k) are folded with the short columns k-1-j in [0, h), h = k/2, onto two threads of ~h IoUs
+  // each: helper u < h does rows [0, h) of column k-1-u; owner j does its rows [h, j) and the whole column k-1-j.
+  const int h = k / 2;
+  float m_own = 0.f;
+  if (dbg & 4) {
+  } else if (t < h) {
+    pm_long[k - 1 - t] = iou_colmax(bx, k - 1 - t, 0, h);
+  } else if (t < k) {
+    if (t >= k - h) {
+      m_own = iou_colmax(bx, t, h, t);
+      pm_short[k - 1 - t] = iou_colmax(bx, k - 1 - t, 0, k - 1 - t);
+    } else {
+      m_own = iou_colmax(bx, t, 0, t);    // middle column (k odd)
+    }
+  }
+  __syncthreads();
   if (t < top_k) {
     bool kept = false;
     if (t < k) {
-      // iou_max[j] = max_{i<j} IoU(i, j) (0 for j = 0); jaccard(): inter / (area_i + area_j - inter)
-      const float x1 = bx[t][0], y1 = bx[t][1], x2 = bx[t][2], y2 = bx[t][3];
-      const float area_j = (x2 - x1) * (y2 - y1);
-      float m = 0.f;
-      bool nan = false;
-      for (int i = 0; i < t; ++i) {
-        const float ax1 = bx[i][0], ay1 = bx[i][1], ax2 = bx[i][2], ay2 = bx[i][3];
-        float iw = fminf(ax2, x2) - fmaxf(ax1, x1);
-        float ih = fminf(ay2, y2) - fmaxf(ay1, y1);
-        iw = iw < 0.f ? 0.f : iw;
-        ih = ih < 0.f ? 0.f : ih;
-        const float inter = iw * ih;
-        const float area_i = (ax2 - ax1) * (ay2 - ay1);
-        const float iou = inter / ((area_i + area_j) - inter);
-        if (iou != iou) nan = true;
-        m = iou > m ? iou : m;
-      }
-      kept = !nan && (m <= nms_thresh);
+      const float m = t < h ? pm_short[t] : (t >= k - h ? fmaxf(m_own, pm_long[t]) : m_own);
+      kept = m <= nms_thresh;
     }
     cs[t] = kept ? score : -1.f;
     cp[t] = kept ? prior : -1;
@@ -241,7 +312,8 @@ __global__ __launch_bounds__(NT) void class_topk_nms_k(const float *__restrict__
 }
 
 // K3: one block per image: best max_det over all per-class survivors (flattened class-major, rank-minor)
-__global__ __launch_bounds__(NT) void final_topk_k(const float *__restrict__ cand_score, const int *__restrict__ cand_prior,
+template <int EPT>
+__global__ __launch_bounds__(NT, (EPT > 80 ? 1 : 2)) void final_topk_k(const float *__restrict__ cand_score, const int *__restrict__ cand_prior,
                                                    const float *__restrict__ loc, const float *__restrict__ priors,
                                                    const float *__restrict__ coef, const int *__restrict__ argmax,
                                                    int P, int D, int nclass, int top_k, int cap, int cross_class,
@@ -264,7 +336,20 @@ __global__ __launch_bounds__(NT) void final_topk_k(const float *__restrict__ can
   const int k = nv < cap ? nv : cap;
   if (t == 0) out_count[b] = k;
   if (k == 0) return;
-  block_topk_sorted([&](int i) -> unsigned { return cp[i] >= 0 ? f2key(cs[i]) : 0u; }, n, k, sh);
+  if constexpr (EPT > 0) {
+    unsigned keys[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+      const int i = t + NT * j, ii = i < n ? i : 0;
+      const int pf = cp[ii];
+      const float sv = cs[ii];
+      keys[j] = (i < n && pf >= 0) ? f2key(sv) : 0u;
+    }
+    block_topk_regs<EPT>(keys, [](int) -> unsigned { return 0u; }, n, k, sh);
+  } else {
+    const unsigned none[1] = {0u};
+    block_topk_regs<0>(none, [&](int i) -> unsigned { return cp[i] >= 0 ? f2key(cs[i]) : 0u; }, n, k, sh);
+  }
   for (int j = t; j < k; j += NT) {
     const int f = (int)(0xffffffffu - (unsigned)(sh.comp[j] & 0xffffffffull));
     const int prior = cp[f];
@@ -305,14 +390,29 @@ extern "C" int ymi_detect_f32(const ymi_detect_desc *d, void *stream) {
   int rc = ymi_launch_status();
   if (rc) return rc;
   const int nclass = d->cross_class ? 1 : nfg;
+  int dbg = 0;   // diagnostics only (env YMI_DETECT_ABLATE): bit0 skip selection, bit2 skip the IoU triangle
+  { const char *e = getenv("YMI_DETECT_ABLATE"); if (e) dbg = atoi(e); }
   const float *sc = d->cross_class ? d->maxsc : d->scores_t;
-  hipLaunchKernelGGL(class_topk_nms_k, dim3(nclass, d->B), dim3(NT), 0, s, sc, d->keep, d->num_keep, d->loc, d->priors,
-                     d->P, nclass, d->top_k, d->nms_thresh, d->cand_score, d->cand_prior);
+#define YMI_K2(EPT)                                                                                                  \
+  hipLaunchKernelGGL(class_topk_nms_k<EPT>, dim3(nclass, d->B), dim3(NT), 0, s, sc, d->keep, d->num_keep, d->loc,  \
+                     d->priors, d->P, nclass, d->top_k, d->nms_thresh, d->cand_score, d->cand_prior, dbg)
+  // keys per thread: 19 248 priors (550 px) -> 80, 30 963 (700 px) -> 128; beyond that (57 744 for YOLACT++) the keys
+  // stay in memory and every bisection pass re-reads them from L2
+  if (d->P <= NT * 80) YMI_K2(80);
+  else if (d->P <= NT * 128) YMI_K2(128);
+  else YMI_K2(0);
+#undef YMI_K2
   rc = ymi_launch_status();
   if (rc) return rc;
   const int cap = d->cross_class ? d->top_k : d->max_det;
-  hipLaunchKernelGGL(final_topk_k, dim3(d->B), dim3(NT), 0, s, d->cand_score, d->cand_prior, d->loc, d->priors, d->coef,
-                     d->argmax, d->P, d->D, nclass, d->top_k, cap, d->cross_class, d->out_count, d->out_box,
-                     d->out_score, (long long *)d->out_class, d->out_coef, d->out_prior);
+#define YMI_K3(EPT)                                                                                                   \
+  hipLaunchKernelGGL(final_topk_k<EPT>, dim3(d->B), dim3(NT), 0, s, d->cand_score, d->cand_prior, d->loc, d->priors, \
+                     d->coef, d->argmax, d->P, d->D, nclass, d->top_k, cap, d->cross_class, d->out_count, d->out_box, \
+                     d->out_score, (long long *)d->out_class, d->out_coef, d->out_prior)
+  const long ncand = (long)nclass * d->top_k;
+  if (ncand <= NT * 64) YMI_K3(64);
+  else if (ncand <= NT * 128) YMI_K3(128);
+  else YMI_K3(0);
+#undef YMI_K3
   return ymi_launch_status();
 }
