@@ -48,12 +48,17 @@ def roofline(net, x, reps=3):
     lib = L.lib()
     plan = net.plan_for(x)
     names = [n for n, _ in plan.conv_meta]
+    # The timed region overlaps the small P4..P7 / Detect kernels with the P3 branch on a second HIP stream; kernels
+    # that share the GPU have inflated individual durations, so the per-kernel pass runs the SAME op list serialised
+    # on one stream (plan.overlap = False): a kernel's own rate, events recorded on the stream it is launched on.
+    plan.overlap = False
     lib.ymi_prof_reset()
     lib.ymi_prof_enable(1)
     for _ in range(reps):
         net.forward_device(x)
     torch.cuda.synchronize()
     lib.ymi_prof_enable(0)
+    plan.overlap = True
     n = lib.ymi_prof_count()
     per = n // reps
     ms, fl, tile, kind = C.c_float(), C.c_double(), C.c_int32(), C.c_int32()
@@ -75,13 +80,26 @@ def roofline(net, x, reps=3):
               for k, v in by_kernel.items()}
     return {
         'bound': 'mfma', 'kernel': name, 'achieved': round(ach, 2), 'peak': FP32_MFMA_PEAK_TFLOPS,
-        'unit': 'TFLOP/s', 'frac': round(ach / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+        'unit': 'TFLOP/s', 'frac': round(ach / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic_from_profiles(name),
+        'measured': 'HIP events on the launch stream, %d serialised passes right after the timed region' % reps,
         'avg_launch_ms': round(dms / dn, 4), 'flops_per_launch': dfl / dn,
         'all_conv': {'ms_per_step': round(tot_ms / reps, 3), 'tflops': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
                      'gflop_per_step': round(tot_fl / reps / 1e9, 2),
                      'frac': round(tot_fl / (tot_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)},
         'per_kernel': detail,
     }, layers
+
+
+def traffic_from_profiles(kernel):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md; tools/gpu_session_traffic.sh writes
+    profiles/r01_traffic.json).  null when no PMC record exists for that kernel."""
+    path = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        rec = json.load(f).get(kernel)
+    return rec
 
 
 def cpu_baseline(sd, size, budget_s=20.0):
@@ -186,6 +204,8 @@ def main():
                            'postprocess_in_step': bool(args.with_postprocess)},
                 'roofline': rf,
             }
+            result['roofline']['all_conv']['sustained_tflops_in_timed_region'] = round(
+                rf['all_conv']['gflop_per_step'] / (dt / args.steps * 1e3), 2)
             if args.layers:
                 for name, best, times in getattr(net.plan_for(x), 'tune_table', []):
                     print('tune %-20s -> %-8s %s' % (name, best, times), file=sys.stderr)

@@ -1,0 +1,43 @@
+#!/usr/bin/env python
+"""Aggregate two rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE) of bench.py into HBM bytes per launch per conv
+kernel, keyed like bench.py's roofline.kernel.  FETCH_SIZE is doubled (gfx950 counts 128-byte requests as 64 B,
+MI355X_MICROARCH.md "HBM").   python tools/traffic_summary.py FETCH_DIR WRITE_DIR > profiles/r01_traffic.json"""
+import csv, glob, json, os, re, sys
+from collections import defaultdict
+
+TILES = {(2, 2, 1, 2, 2, 2): '128x128', (2, 2, 1, 2, 1, 2): '128x64', (2, 2, 1, 1, 1, 2): '64x64', (4, 1, 1, 1, 1, 2): '128x32',
+         (2, 2, 1, 1, 2, 2): '64x128', (1, 1, 4, 1, 1, 2): '32x32k4', (2, 1, 2, 1, 1, 2): '64x32k2', (1, 2, 2, 1, 1, 2): '32x64k2',
+         (2, 2, 1, 1, 1, 3): '64x64s3', (2, 2, 1, 1, 1, 4): '64x64s4', (2, 2, 1, 1, 2, 3): '64x128s3', (2, 2, 1, 2, 1, 3): '128x64s3',
+         (1, 1, 4, 1, 1, 4): '32x32k4s4', (2, 1, 2, 1, 1, 3): '64x32k2s3', (1, 2, 2, 1, 1, 3): '32x64k2s3'}
+
+
+def collect(root, counter):
+    acc = defaultdict(lambda: [0.0, 0])
+    for f in glob.glob(os.path.join(root, '**', '*counter_collection.csv'), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r['Counter_Name'] != counter:
+                continue
+            m = re.search(r'conv_igemm_f32<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>', r['Kernel_Name'])
+            if not m:
+                continue
+            v = tuple(int(x) for x in m.groups())
+            key = 'conv_igemm_f32<%s,loader%d>' % (TILES.get(v[:6], str(v[:6])), v[6])
+            a = acc[key]
+            a[0] += float(r['Counter_Value']); a[1] += 1
+    return acc
+
+
+def main(fdir, wdir):
+    fe, wr = collect(fdir, 'FETCH_SIZE'), collect(wdir, 'WRITE_SIZE')
+    out = {}
+    for k in sorted(set(fe) | set(wr)):
+        f = fe[k][0] / max(fe[k][1], 1) * 1024 * 2      # KB -> bytes, x2 gfx950 correction
+        w = wr[k][0] / max(wr[k][1], 1) * 1024
+        out[k] = {'hbm_read_bytes_per_launch': round(f), 'hbm_write_bytes_per_launch': round(w),
+                  'bytes_per_launch': round(f + w), 'launches_sampled': fe[k][1],
+                  'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2'}
+    json.dump(out, sys.stdout, indent=1)
+
+
+if __name__ == '__main__':
+    main(sys.argv[1], sys.argv[2])

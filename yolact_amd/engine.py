@@ -120,11 +120,32 @@ class Plan:
         self.arena = Arena(device)
         self.keepalive = []
         self.lib = L.lib()
+        # Two HIP streams: A = the caller's current stream (backbone, P3 branch, protonet), B = a side stream for the
+        # small P4..P7 FPN/head convs and Detect, which are latency-bound and leave most CUs idle when run alone
+        # (profiles/r01_layers_v4.txt: 0.7 ms of < 60 TF/s layers + 0.35 ms of Detect per batch-8 step).
+        self.two_streams = device.type == 'cuda' and os.environ.get('YOLACT_AMD_STREAMS', '2') != '1'
+        self.stream_b = torch.cuda.Stream(device=device) if self.two_streams else None
+        self.overlap = True      # runtime switch: False runs the same op list on ONE stream (serialised kernels), which
+                                 # is what per-kernel timing (bench.py's roofline pass) needs
+        self.events = {}
+        self._cur = 'A'
         self._build()
 
     # ---- op emitters ---------------------------------------------------------------------------
+    def _arena(self):
+        # buffers are recycled only among ops of the SAME stream: program order on one stream makes reuse race-free,
+        # across streams it would not be
+        if self._cur == 'B':
+            if not hasattr(self, 'arena_b'):
+                self.arena_b = Arena(self.device)
+            return self.arena_b
+        return self.arena
+
     def _new(self, B, H, W, C) -> T:
-        return T(self.arena.alloc(B * H * W * C), B, H, W, C)
+        return T(self._arena().alloc(B * H * W * C), B, H, W, C)
+
+    def free(self, t):
+        self._arena().free(t)
 
     def conv(self, name, x: T, pk: Packed, act=L.ACT_NONE, res: Optional[T] = None, res_mode=L.RES_NONE,
              res_after_act=0, out: Optional[T] = None, segs=None, dcn_offmask: Optional[T] = None) -> Optional[T]:
@@ -161,15 +182,28 @@ class Plan:
             dd = L.DcnDesc()
             dd.conv = d
             dd.offmask, dd.ldo = dcn_offmask.ptr, dcn_offmask.C
-            self.ops.append((self.lib.ymi_dcn_v2_forward_f32, C.pointer(dd), name))
+            self.ops.append((self.lib.ymi_dcn_v2_forward_f32, C.pointer(dd), name, self._cur))
             self.conv_meta.append((name, dd.conv))
         else:
-            self.ops.append((self.lib.ymi_conv2d_nhwc_f32, C.pointer(d), name))
+            self.ops.append((self.lib.ymi_conv2d_nhwc_f32, C.pointer(d), name, self._cur))
             self.conv_meta.append((name, d))
         return y
 
     def call(self, fn, *args, name=''):
-        self.ops.append((fn, args, name))
+        self.ops.append((fn, args, name, self._cur))
+
+    # stream control (no-ops in single-stream mode): ops emitted after on('B') go to the side stream
+    def on(self, which):
+        self._cur = which if self.two_streams else 'A'
+
+    def record(self, ev):
+        if self.two_streams:
+            self.events[ev] = torch.cuda.Event()
+            self.ops.append(('record', ev, ev, self._cur))
+
+    def wait(self, ev):
+        if self.two_streams:
+            self.ops.append(('wait', ev, ev, self._cur))
 
     # ---- graph construction --------------------------------------------------------------------
     def _build(self):
@@ -181,7 +215,7 @@ class Plan:
         # input: NCHW fp32 -> NHWC with C padded to 4 (pointer patched per call)
         x4 = self._new(B, H, W, 4)
         self.in_args = [None, x4.ptr, B, 3, H, W]
-        self.ops.append(('input', None, 'nchw_to_nhwc4'))
+        self.ops.append(('input', None, 'nchw_to_nhwc4', 'A'))
 
         bb = net.backbone
         if isinstance(bb, M.ResNetBackbone):
@@ -193,7 +227,7 @@ class Plan:
             if i not in net.backbone_selected and t is not None:
                 ar.free(t)
 
-        # FPN (yolact.py:319-361)
+        # FPN laterals + top-down sums (yolact.py:319-341) on stream A
         fpn = net.fpn
         n = len(sel)
         sums = [None] * n
@@ -208,22 +242,94 @@ class Plan:
             prev = sums[j]
         for t in sel:
             ar.free(t)
-        feats = [None] * n
-        for i in range(n):
-            j = n - 1 - i
-            feats[j] = self.conv('fpn.pred%d' % i, sums[j], pack_module(fpn.pred_layers[i], device=dev), act=L.ACT_RELU)
-        for t in sums:
-            ar.free(t)
-        for i, m in enumerate(fpn.downsample_layers):
-            feats.append(self.conv('fpn.down%d' % i, feats[-1], pack_module(m, device=dev)))
-        self.feat_shapes = [(t.H, t.W) for t in feats]
 
-        # protonet (utils/functions.py:163-213 + yolact.py:588-599); the last conv writes the per-call proto tensor
-        t = feats[net.proto_src]
+        # level geometry (pred convs keep the size, downsample convs are 3x3 / stride 2 / pad 1)
+        shapes = [(t.H, t.W) for t in sums]
+        for _ in fpn.downsample_layers:
+            shapes.append((out_size(shapes[-1][0], 3, 2, 1), out_size(shapes[-1][1], 3, 2, 1)))
+        self.feat_shapes = shapes
+        nlev = len(shapes)
+
+        # prediction heads (yolact.py:133-212), shared weights, one merged GEMM per level writing straight into
+        # the level-concatenated [B,P,k] tensors
+        pm = net.prediction_layers[0]
+        A = pm.num_priors
+        Ccls, D = cfg.num_classes, net.mask_dim
+        cells = [h * w for h, w in shapes]
+        P = sum(cells) * A
+        self.P, self.A, self.D, self.Ccls = P, A, D, Ccls
+        self.loc = torch.empty(B, P, 4, device=dev)
+        self.conf = torch.empty(B, P, Ccls, device=dev)
+        self.coef = torch.empty(B, P, D, device=dev)
+        up_pk = [pack_module(m, device=dev) for m in pm.upfeature if isinstance(m, nn.Conv2d)] \
+            if hasattr(pm, 'upfeature') else []
+        # row order bbox | coef | conf keeps the bbox and coef segments 16-byte aligned (vector stores)
+        wcat = torch.cat([pm.bbox_layer.weight, pm.mask_layer.weight, pm.conf_layer.weight], 0)
+        bcat = torch.cat([pm.bbox_layer.bias, pm.mask_layer.bias, pm.conf_layer.bias], 0)
+        hp = pm.bbox_layer
+        head_pk = Packed(wcat, bcat, None, hp.stride[0], hp.padding[0], None, dev)
+        coef_act = {'tanh': L.ACT_TANH, 'sigmoid': L.ACT_SIGMOID, 'relu': L.ACT_RELU, 'none': L.ACT_NONE}[
+            act_name(cfg.mask_proto_coeff_activation)]
+        n_b, n_c, n_m = A * 4, A * Ccls, A * D
+        offs = [sum(cells[:l]) * A for l in range(nlev)]
+        bbc = cfg.backbone
+        pri = []
+        for lvl, (fh, fw) in enumerate(shapes):
+            pri += make_priors_host(fh, fw, bbc.pred_scales[lvl], bbc.pred_aspect_ratios[lvl], cfg.max_size, bbc)
+
+        def head(lvl, f):
+            off = offs[lvl]
+            u = f
+            for k, pk in enumerate(up_pk):
+                nu = self.conv('head%d.up%d' % (lvl, k), u, pk, act=L.ACT_RELU)
+                if u is not f:
+                    self.free(u)
+                u = nu
+            segs = [
+                (0, n_b, L.ACT_NONE, n_b, P * 4, self.loc.data_ptr() + off * 4 * 4),
+                (n_b, n_b + n_m, coef_act, n_m, P * D, self.coef.data_ptr() + off * D * 4),
+                (n_b + n_m, n_b + n_m + n_c, L.ACT_NONE, n_c, P * Ccls, self.conf.data_ptr() + off * Ccls * 4),
+            ]
+            self.conv('head%d.out' % lvl, u, head_pk, segs=segs)
+            if u is not f:
+                self.free(u)
+
+        def pred(j):   # pred_layers are stored top-down: index n-1-j belongs to level j (yolact.py:286-289)
+            i = n - 1 - j
+            return self.conv('fpn.pred%d' % i, sums[j], pack_module(fpn.pred_layers[i], device=dev), act=L.ACT_RELU)
+
+        assert net.proto_src == 0, 'prototypes are taken from P3 in every shipped config'
+        # ---- fork: the P3 branch (75 % of the remaining FLOPs) stays on A, P4..P7 + Detect go to the side stream B
+        self.record('fork')
+        self.on('B')
+        self.wait('fork')
+        self.on('A')
+        p3 = pred(0)
+        self.free(sums[0])
+        self.on('B')
+        feats_b = [pred(j) for j in range(1, n)]
+        for j in range(1, n):
+            self.free(sums[j])
+        for i, m in enumerate(fpn.downsample_layers):
+            feats_b.append(self.conv('fpn.down%d' % i, feats_b[-1], pack_module(m, device=dev)))
+        self.on('A')
+        head(0, p3)
+        self.record('head0')
+        self.on('B')
+        for lvl in range(1, nlev):
+            head(lvl, feats_b[lvl - 1])
+        for f in feats_b:
+            self.free(f)
+        self.wait('head0')
+        self.ops.append(('detect', None, 'detect', self._cur))
+        self.record('b_done')
+        self.on('A')
+
+        # protonet (utils/functions.py:163-213 + yolact.py:588-599) on A; the last conv writes the per-call proto tensor
+        t = p3
         mods = list(net.proto_net)
         conv_idx = [i for i, m in enumerate(mods) if isinstance(m, nn.Conv2d)]
         self.proto_patch = None
-        first = True
         for i, m in enumerate(mods):
             if isinstance(m, nn.Conv2d):
                 last = i == conv_idx[-1]
@@ -243,9 +349,7 @@ class Plan:
                     nt = None
                 else:
                     nt = self.conv('proto.%d' % i, t, pk, act=a)
-                if not first:
-                    ar.free(t)
-                first = False
+                self.free(t)
                 t = nt
             elif isinstance(m, M.InterpolateModule):
                 s = int(m.scale_factor)
@@ -253,55 +357,10 @@ class Plan:
                 y = self._new(t.B, t.H * s, t.W * s, t.C)
                 self.call(lib.ymi_bilinear_nhwc_f32, t.ptr, y.ptr, t.B, t.H, t.W, t.C, y.H, y.W,
                           C.c_float(1.0 / s), C.c_float(1.0 / s), 1 if has_relu else 0, name='proto.interp')
-                if not first:
-                    ar.free(t)
-                first = False
+                self.free(t)
                 t = y
         assert self.proto_patch is not None
-
-        # prediction heads (yolact.py:133-212), shared weights, one merged GEMM per level writing straight into
-        # the level-concatenated [B,P,k] tensors
-        pm = net.prediction_layers[0]
-        A = pm.num_priors
-        Ccls, D = cfg.num_classes, net.mask_dim
-        cells = [h * w for h, w in self.feat_shapes]
-        P = sum(cells) * A
-        self.P, self.A, self.D, self.Ccls = P, A, D, Ccls
-        self.loc = torch.empty(B, P, 4, device=dev)
-        self.conf = torch.empty(B, P, Ccls, device=dev)
-        self.coef = torch.empty(B, P, D, device=dev)
-        up_pk = [pack_module(m, device=dev) for m in pm.upfeature if isinstance(m, nn.Conv2d)] \
-            if hasattr(pm, 'upfeature') else []
-        # row order bbox | coef | conf keeps the bbox and coef segments 16-byte aligned (vector stores)
-        wcat = torch.cat([pm.bbox_layer.weight, pm.mask_layer.weight, pm.conf_layer.weight], 0)
-        bcat = torch.cat([pm.bbox_layer.bias, pm.mask_layer.bias, pm.conf_layer.bias], 0)
-        hp = pm.bbox_layer
-        head_pk = Packed(wcat, bcat, None, hp.stride[0], hp.padding[0], None, dev)
-        coef_act = {'tanh': L.ACT_TANH, 'sigmoid': L.ACT_SIGMOID, 'relu': L.ACT_RELU, 'none': L.ACT_NONE}[
-            act_name(cfg.mask_proto_coeff_activation)]
-        n_b, n_c, n_m = A * 4, A * Ccls, A * D
-        off = 0
-        pri = []
-        bbc = cfg.backbone
-        for lvl, f in enumerate(feats):
-            u = f
-            for k, pk in enumerate(up_pk):
-                nu = self.conv('head%d.up%d' % (lvl, k), u, pk, act=L.ACT_RELU)
-                if u is not f:
-                    ar.free(u)
-                u = nu
-            segs = [
-                (0, n_b, L.ACT_NONE, n_b, P * 4, self.loc.data_ptr() + off * 4 * 4),
-                (n_b, n_b + n_m, coef_act, n_m, P * D, self.coef.data_ptr() + off * D * 4),
-                (n_b + n_m, n_b + n_m + n_c, L.ACT_NONE, n_c, P * Ccls, self.conf.data_ptr() + off * Ccls * 4),
-            ]
-            self.conv('head%d.out' % lvl, u, head_pk, segs=segs)
-            if u is not f:
-                ar.free(u)
-            off += f.H * f.W * A
-            pri += make_priors_host(f.H, f.W, bbc.pred_scales[lvl], bbc.pred_aspect_ratios[lvl], cfg.max_size, bbc)
-        for f in feats:
-            ar.free(f)
+        self.wait('b_done')
         self.priors = torch.tensor(pri, dtype=torch.float32).view(-1, 4).to(dev)
         assert self.priors.shape[0] == P
 
@@ -371,24 +430,44 @@ class Plan:
         return outs
 
     # ---- execution -------------------------------------------------------------------------------
-    def run(self, x: torch.Tensor):
-        """x [B,3,H,W] fp32 contiguous on the plan's device. Returns the fresh proto tensor; loc/conf/coef are the
-        plan's persistent head buffers (consumed by Detect before the next forward)."""
+    def run(self, x: torch.Tensor, detect=None):
+        """x [B,3,H,W] fp32 contiguous on the plan's device. Returns (proto, detect_result): the fresh proto tensor
+        and whatever `detect(stream_ptr)` returned (None without a callback).  loc/conf/coef are the plan's persistent
+        head buffers.  `detect` is invoked at the point of the op list where every head has been written; its
+        kernels must be launched on the stream it is handed (the side stream in two-stream mode) while its output
+        tensors are allocated by the caller's ambient stream — they are only consumed after the final join."""
         lib = self.lib
-        s = L.stream_ptr()
+        cur = torch.cuda.current_stream(self.device)
+        sa = C.c_void_p(cur.cuda_stream)
+        two = self.two_streams and self.overlap
+        sb = C.c_void_p(self.stream_b.cuda_stream) if two else sa
         proto = torch.empty(self.proto_shape, dtype=torch.float32, device=self.device)
         self.proto_patch.seg[0].ptr = proto.data_ptr()
-        for fn, args, name in self.ops:
+        det = None
+        for fn, args, name, where in self.ops:
+            s = sb if where == 'B' else sa
             if fn == 'input':
                 a = self.in_args
                 rc = lib.ymi_nchw_to_nhwc4_f32(x.data_ptr(), a[1], a[2], a[3], a[4], a[5], s)
+            elif fn == 'record':
+                if two:
+                    self.events[args].record(self.stream_b if where == 'B' else cur)
+                continue
+            elif fn == 'wait':
+                if two:
+                    (self.stream_b if where == 'B' else cur).wait_event(self.events[args])
+                continue
+            elif fn == 'detect':
+                if detect is not None:
+                    det = detect(s)
+                continue
             elif isinstance(args, tuple):
                 rc = fn(*args, s)
             else:
                 rc = fn(args, s)
             if rc != 0:
                 L.check(rc, name)
-        return proto
+        return proto, det
 
     def autotune(self, x: torch.Tensor, reps: int = 3):
         """Measure, don't guess: time every tile configuration of every distinct conv shape on the device (HIP
@@ -405,7 +484,7 @@ class Plan:
         s = L.stream_ptr()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         cache, table = {}, []
-        for fn, dptr, name in self.ops:
+        for fn, dptr, name, _where in self.ops:
             if fn is not self.lib.ymi_conv2d_nhwc_f32:
                 continue
             d = dptr.contents

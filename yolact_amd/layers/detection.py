@@ -49,8 +49,10 @@ class Detect(object):
             self._ws = {key: ws}
         return ws
 
-    def run_device(self, loc, conf, mask, priors, conf_is_logits):
-        """Launch the Detect kernels; returns fixed-capacity device tensors (no host sync)."""
+    def run_device(self, loc, conf, mask, priors, conf_is_logits, stream=None):
+        """Launch the Detect kernels; returns fixed-capacity device tensors (no host sync).  `stream`: raw
+        hipStream_t (ctypes void*) to launch on — the execution plan passes its side stream — default: torch's
+        current stream.  Output tensors are always allocated under the ambient stream."""
         for name, t in (('loc', loc), ('conf', conf), ('mask', mask), ('priors', priors)):
             L.require_cuda(t, name)
         cfg = active_cfg()
@@ -77,7 +79,7 @@ class Detect(object):
         d.out_count, d.out_box, d.out_score = out['count'].data_ptr(), out['box'].data_ptr(), out['score'].data_ptr()
         d.out_class, d.out_coef, d.out_prior = out['cls'].data_ptr(), out['coef'].data_ptr(), out['prior'].data_ptr()
         with torch.cuda.device(dev):
-            L.check(L.lib().ymi_detect_f32(C.byref(d), L.stream_ptr()), 'ymi_detect_f32')
+            L.check(L.lib().ymi_detect_f32(C.byref(d), stream if stream is not None else L.stream_ptr()), 'ymi_detect_f32')
         out['_keepalive'] = (loc, conf, mask, priors)
         return out
 
@@ -92,8 +94,12 @@ class Detect(object):
         else:
             conf, is_logits = predictions['conf'], False
         proto = predictions.get('proto')
+        o = self.run_device(predictions['loc'], conf, predictions['mask'], predictions['priors'], is_logits)
+        return self.finish(o, proto, net)
+
+    def finish(self, o, proto, net):
+        """Fixed-capacity device outputs -> the reference's list of per-image dicts (one host read of the counts)."""
         with _timer_env('Detect'):
-            o = self.run_device(predictions['loc'], conf, predictions['mask'], predictions['priors'], is_logits)
             counts = o['count'].tolist()          # the one host sync per batch
             out = []
             for b, n in enumerate(counts):

@@ -164,10 +164,9 @@ class Yolact(nn.Module):
         with torch.cuda.device(x.device):
             plan = self.plan_for(x)
             with _timer_env('backbone'):
-                proto = plan.run(x)
-            preds = {'loc': plan.loc, 'conf_logits': plan.conf, 'mask': plan.coef, 'priors': plan.priors,
-                     'proto': proto}
-            return self.detect(preds, self)
+                proto, dev_out = plan.run(x, detect=lambda s: self.detect.run_device(
+                    plan.loc, plan.conf, plan.coef, plan.priors, True, stream=s))
+            return self.detect.finish(dev_out, proto, self)
 
     def maskiou_forward(self, masks_lo):
         """FastMaskIoUNet.forward (yolact.py:363-375) on cropped prototype-resolution masks [N,ph,pw] -> [N,80]:
@@ -211,8 +210,8 @@ class Yolact(nn.Module):
         x = x.detach().to(torch.float32).contiguous()
         with torch.cuda.device(x.device):
             plan = self.plan_for(x)
-            proto = plan.run(x)
-            out = self.detect.run_device(plan.loc, plan.conf, plan.coef, plan.priors, True)
+            proto, out = plan.run(x, detect=lambda s: self.detect.run_device(
+                plan.loc, plan.conf, plan.coef, plan.priors, True, stream=s))
             out['proto'] = proto
             return out
 
@@ -222,6 +221,6 @@ class Yolact(nn.Module):
         x = x.detach().to(torch.float32).contiguous()
         with torch.cuda.device(x.device):
             plan = self.plan_for(x)
-            proto = plan.run(x)
+            proto, _ = plan.run(x)
             return {'loc': plan.loc.clone(), 'conf_logits': plan.conf.clone(), 'mask': plan.coef.clone(),
                     'priors': plan.priors, 'proto': proto}
