@@ -107,6 +107,17 @@ struct SelShared {
   unsigned wave_tot[NT / 64];
 };
 
+// Wave64 sum on the DPP data path (quad swaps, row_shr 4/8, row_bcast 15/31); the total lands in lane 63.
+__device__ __forceinline__ unsigned wave_sum_to_lane63(unsigned v) {
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4e, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
+  return v;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Register-resident top-k: every thread holds EPT keys (element i = t + NT*j) in VGPRs and the k-th largest key is
 // found by bisection on its 32 bits (one block-wide count per bit: compares on registers, a wave reduction and ONE
@@ -125,19 +136,22 @@ __device__ void block_topk_regs(const unsigned (&keys)[EPT > 0 ? EPT : 1], KeyFn
     return i < n ? key(i) : 0u;
   };
   auto block_count = [&](unsigned cand, bool strict, int slot) -> unsigned {
-    // the compare's lane mask IS the ballot: popcount + add run on the scalar unit, no cross-lane traffic
+    // per-lane counts (compare + add-with-carry on the VALU), then ONE DPP wave reduction: no LDS crossbar shuffles,
+    // no SGPR pressure (80 ballots per pass made the compiler spill SGPRs through v_writelane)
     unsigned c = 0;
     if (EPT > 0) {
+      unsigned c4[4] = {0u, 0u, 0u, 0u};     // four independent carry chains
 #pragma unroll
-      for (int j = 0; j < (EPT > 0 ? EPT : 1); ++j)
-        c += (unsigned)__popcll(__ballot(strict ? keys[j] > cand : keys[j] >= cand));
+      for (int j = 0; j < (EPT > 0 ? EPT : 1); ++j) c4[j & 3] += (strict ? keys[j] > cand : keys[j] >= cand) ? 1u : 0u;
+      c = (c4[0] + c4[1]) + (c4[2] + c4[3]);
     } else {
       for (int j = 0; j < rounds; ++j) {
         const unsigned kk = key_at(j);
-        c += (unsigned)__popcll(__ballot(strict ? kk > cand : kk >= cand));
+        c += (strict ? kk > cand : kk >= cand) ? 1u : 0u;
       }
     }
-    if (lane == 0) sh.hist[slot * 4 + w] = c;
+    c = wave_sum_to_lane63(c);
+    if (lane == 63) sh.hist[slot * 4 + w] = c;
     __syncthreads();
     return sh.hist[slot * 4] + sh.hist[slot * 4 + 1] + sh.hist[slot * 4 + 2] + sh.hist[slot * 4 + 3];
   };

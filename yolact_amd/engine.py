@@ -306,21 +306,33 @@ class Plan:
         self.on('A')
         p3 = pred(0)
         self.free(sums[0])
+        self.record('p3')
+        split_p3_head = os.environ.get('YOLACT_AMD_HEAD0_STREAM', 'A') == 'B'   # measured: 862 (B) vs 877 (A) images/s
         self.on('B')
         feats_b = [pred(j) for j in range(1, n)]
         for j in range(1, n):
             self.free(sums[j])
         for i, m in enumerate(fpn.downsample_layers):
             feats_b.append(self.conv('fpn.down%d' % i, feats_b[-1], pack_module(m, device=dev)))
-        self.on('A')
-        head(0, p3)
-        self.record('head0')
-        self.on('B')
-        for lvl in range(1, nlev):
-            head(lvl, feats_b[lvl - 1])
+        if split_p3_head and self.two_streams:
+            # the P3 head (0.9 ms) also goes to B: A keeps only the protonet chain, and the two streams' big kernels
+            # fill each other's tails.  P3 is then read by both streams, so its buffer is never recycled.
+            for lvl in range(1, nlev):
+                head(lvl, feats_b[lvl - 1])
+            self.wait('p3')
+            head(0, p3)
+            p3_shared = True
+        else:
+            self.on('A')
+            head(0, p3)
+            self.record('head0')
+            self.on('B')
+            for lvl in range(1, nlev):
+                head(lvl, feats_b[lvl - 1])
+            self.wait('head0')
+            p3_shared = False
         for f in feats_b:
             self.free(f)
-        self.wait('head0')
         self.ops.append(('detect', None, 'detect', self._cur))
         self.record('b_done')
         self.on('A')
@@ -349,7 +361,8 @@ class Plan:
                     nt = None
                 else:
                     nt = self.conv('proto.%d' % i, t, pk, act=a)
-                self.free(t)
+                if not (t is p3 and p3_shared):
+                    self.free(t)
                 t = nt
             elif isinstance(m, M.InterpolateModule):
                 s = int(m.scale_factor)
