@@ -144,6 +144,13 @@ int ymi_mask_upsample_f32(const float *masks_lo, float *out, int N, int ph, int 
 /* boxes [N,4] relative -> int64 absolute pixels via sanitize_coordinates(cast=False) then truncation */
 int ymi_boxes_to_pixels(const float *box, int64_t *out, int N, int w, int h, void *stream);
 
+/* -- FastBaseTransform (utils/augmentations.py:616-658): img [N,H,W,3] float32 BGR -> bilinear (align_corners=False)
+ * resize to (oh, ow) -> normalisation -> RGB.  mean_bgr / std_bgr: HOST pointers to 3 floats in BGR order
+ * (data/config.py:28-29).  mode: 0 (x-mean)/std, 1 x-mean, 2 x/255, 3 none (backbone.transform, data/config.py:181-202).
+ * out_nhwc4 = 0: out [N,3,oh,ow] (the reference's return value); 1: out [N,oh,ow,4] RGB0 = the engine's input layout. */
+int ymi_fast_base_transform_f32(const float *img, float *out, int N, int H, int W, int oh, int ow,
+                                const float *mean_bgr, const float *std_bgr, int mode, int out_nhwc4, void *stream);
+
 /* -- DCNv2 forward (external/DCNv2/src/vision.cpp:5, dcn_v2.h:9-39, dcn_v2_cuda.cu:42-172) ---- */
 typedef struct {
   ymi_conv_desc conv;    /* main 3x3 conv: x, packed w, bias, epilogue, outputs (kh=kw=3, pad=1) */

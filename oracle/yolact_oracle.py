@@ -382,3 +382,31 @@ def postprocess(det: Optional[Dict[str, Tensor]], w: int, h: int, cfg, sd=None, 
     if return_soft:
         return classes, scores, boxes_px, hard, soft
     return classes, scores, boxes_px, hard
+
+
+# ----------------------------------------------------------------------------------------------
+# FastBaseTransform — utils/augmentations.py:630-658
+def fast_base_transform(img: Tensor, cfg, means=(103.94, 116.78, 123.68), std=(57.38, 57.12, 58.40)) -> Tensor:
+    """img [n,h,w,3] float BGR -> [n,3,S,S] normalised RGB.  augmentations.py:637-642 size selection, :644-645 permute +
+    bilinear (align_corners=False), :647-652 transform (data/config.py:181-202), :657 BGR->RGB.  MEANS/STD are in BGR
+    order and applied before the swap (data/config.py:28-29)."""
+    if getattr(cfg, 'preserve_aspect_ratio', False):
+        _, h, w, _ = img.shape
+        ratio = math.sqrt(w / h)                      # Resize.calc_size_preserve_ar, augmentations.py:133-138
+        size = (int(cfg.max_size / ratio), int(cfg.max_size * ratio))
+    else:
+        size = (cfg.max_size, cfg.max_size)
+    x = img.permute(0, 3, 1, 2).contiguous()
+    x = F.interpolate(x, size, mode='bilinear', align_corners=False)
+    mean = torch.tensor(means, dtype=torch.float32).view(1, 3, 1, 1)
+    sd = torch.tensor(std, dtype=torch.float32).view(1, 3, 1, 1)
+    tr = cfg.backbone.transform
+    name = tr if isinstance(tr, str) else ('resnet' if tr.normalize else 'vgg' if tr.subtract_means else
+                                           'darknet' if tr.to_float else 'none')
+    if name == 'resnet':
+        x = (x - mean) / sd
+    elif name == 'vgg':
+        x = x - mean
+    elif name == 'darknet':
+        x = x / 255
+    return x[:, (2, 1, 0), :, :].contiguous()
