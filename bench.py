@@ -99,7 +99,7 @@ def traffic_from_profiles(kernel):
         return None
     with open(path) as f:
         rec = json.load(f).get(kernel)
-    return rec
+    return rec['bytes_per_launch'] if rec else None
 
 
 def cpu_baseline(sd, size, budget_s=20.0):
@@ -132,6 +132,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=8, help='images per GPU')
     ap.add_argument('--size', type=int, default=550)
+    ap.add_argument('--config', default=CONFIG, help='other BASELINE configs (parity-test cases; the metric is quoted on '
+                    'the default yolact_resnet50_config)')
     ap.add_argument('--with-postprocess', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--layers', action='store_true', help='also print the per-layer conv table to stderr')
@@ -154,7 +156,7 @@ def main():
     from yolact_amd.layers.output_utils import postprocess
     from yolact_amd.utils.synth import synth_images
     with torch.no_grad():
-        net, sd = build_model(dev, args.size)
+        net, sd = build_model(dev, args.size, args.config)
         x = synth_images(args.batch, args.size, args.size, seed=1234 + rank).to(dev)   # resident in HBM
 
         def step():
@@ -197,9 +199,10 @@ def main():
                 'value': round(imgs / dt, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
                 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
                 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-                'config': {'workload': 'configs[1]: yolact_resnet50_config, %dx%d, batch %d per GPU, random-init '
+                'config': {'workload': '%s%s, %dx%d, batch %d per GPU, random-init '
                                        'weights (no checkpoint offline), inputs resident in HBM'
-                                       % (args.size, args.size, args.batch),
+                                       % ('configs[1]: ' if args.config == CONFIG else '', args.config, args.size, args.size,
+                                          args.batch),
                            'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
                            'postprocess_in_step': bool(args.with_postprocess)},
                 'roofline': rf,
@@ -212,7 +215,7 @@ def main():
                 for k, (ms, fl, kern) in layers.items():
                     print('%-22s %8.3f ms %8.2f GFLOP %7.1f TF/s  %s' % (k, ms, fl / 1e9, fl / ms / 1e9, kern),
                           file=sys.stderr)
-        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == CONFIG:
             result['cpu_baseline'] = cpu_baseline(sd, args.size)
         if rank == 0:
             print(json.dumps(result))

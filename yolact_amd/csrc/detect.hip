@@ -16,7 +16,8 @@
 
 namespace {
 
-constexpr int NT = 256;          // threads per block for K2/K3
+constexpr int NT = 256;          // threads per block for K3 and the default K2
+constexpr int NT_MAX = 512;      // K2 with 57 744 priors (YOLACT++): 512 threads x 128 keys
 constexpr int SORT_N = 256;      // bitonic capacity (top_k, max_det <= 256)
 
 __device__ __forceinline__ unsigned f2key(float f) {
@@ -101,10 +102,10 @@ __global__ __launch_bounds__(256) void softmax_keep_k(const float *__restrict__ 
 // Block-wide top-k selection + sort.  Keys: order-preserving uint of the score, 0 = not a candidate.  Selects the k
 // largest keys, ties broken by lowest index, and leaves them sorted (key desc, index asc) in sh.comp[0..k).
 struct SelShared {
-  unsigned hist[256];
+  unsigned hist[256];             // [2][NT_MAX / 64] per-wave partial counts of the bisection passes
   unsigned long long comp[SORT_N];
   unsigned prefix, krem, cnt_gt, cnt_eq, sel_eq;
-  unsigned wave_tot[NT / 64];
+  unsigned wave_tot[NT_MAX / 64];
 };
 
 // Wave64 sum on the DPP data path (quad swaps, row_shr 4/8, row_bcast 15/31); the total lands in lane 63.
@@ -127,12 +128,13 @@ __device__ __forceinline__ unsigned wave_sum_to_lane63(unsigned v) {
 // Result: the selected elements sorted (key desc, index asc) in sh.comp[0..k) like block_topk_sorted.
 // EPT > 0: keys[] holds element t + NT*j in registers.  EPT == 0 (n too large for the register file): the same
 // algorithm re-evaluates key(i) from memory (L2-resident) on every pass.
-template <int EPT, typename KeyFn>
+template <int EPT, int NTH, typename KeyFn>
 __device__ void block_topk_regs(const unsigned (&keys)[EPT > 0 ? EPT : 1], KeyFn key, int n, int k, SelShared &sh) {
+  constexpr int NW = NTH / 64;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int rounds = EPT > 0 ? EPT : (n + NT - 1) / NT;
+  const int rounds = EPT > 0 ? EPT : (n + NTH - 1) / NTH;
   auto key_at = [&](int j) -> unsigned {          // EPT == 0 only
-    const int i = t + NT * j;
+    const int i = t + NTH * j;
     return i < n ? key(i) : 0u;
   };
   auto block_count = [&](unsigned cand, bool strict, int slot) -> unsigned {
@@ -151,9 +153,12 @@ __device__ void block_topk_regs(const unsigned (&keys)[EPT > 0 ? EPT : 1], KeyFn
       }
     }
     c = wave_sum_to_lane63(c);
-    if (lane == 63) sh.hist[slot * 4 + w] = c;
+    if (lane == 63) sh.hist[slot * NW + w] = c;
     __syncthreads();
-    return sh.hist[slot * 4] + sh.hist[slot * 4 + 1] + sh.hist[slot * 4 + 2] + sh.hist[slot * 4 + 3];
+    unsigned tot = 0;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) tot += sh.hist[slot * NW + ww];
+    return tot;
   };
   unsigned T = 0;
   for (int bit = 31; bit >= 0; --bit) {
@@ -164,7 +169,7 @@ __device__ void block_topk_regs(const unsigned (&keys)[EPT > 0 ? EPT : 1], KeyFn
   const unsigned n_gt = block_count(T, true, 0);      // keys strictly above the threshold: all taken
   const unsigned n_ge = block_count(T, false, 1);
   const unsigned krem = (unsigned)k - n_gt;            // how many of the keys == T are taken (lowest indices first)
-  sh.comp[t] = 0ull;                                   // SORT_N == NT
+  if (t < SORT_N) sh.comp[t] = 0ull;
   if (t == 0) { sh.cnt_gt = 0; }
   __syncthreads();
   if (n_ge - n_gt == krem) {
@@ -178,7 +183,7 @@ __device__ void block_topk_regs(const unsigned (&keys)[EPT > 0 ? EPT : 1], KeyFn
         base = __shfl(base, 0);
         if (win) {
           const unsigned slot = base + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
-          sh.comp[slot] = ((unsigned long long)kj << 32) | (unsigned)(0xffffffffu - (unsigned)(t + NT * j));
+          sh.comp[slot] = ((unsigned long long)kj << 32) | (unsigned)(0xffffffffu - (unsigned)(t + NTH * j));
         }
       }
     };
@@ -204,9 +209,9 @@ __device__ void block_topk_regs(const unsigned (&keys)[EPT > 0 ? EPT : 1], KeyFn
       if (lane == 0) sh.wave_tot[w] = (unsigned)__popcll(bal);
       __syncthreads();
       unsigned before = base_eq, tot = 0;
-      for (int ww = 0; ww < NT / 64; ++ww) { if (ww < w) before += sh.wave_tot[ww]; tot += sh.wave_tot[ww]; }
+      for (int ww = 0; ww < NW; ++ww) { if (ww < w) before += sh.wave_tot[ww]; tot += sh.wave_tot[ww]; }
       before += (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
-      const unsigned long long comp = ((unsigned long long)kk << 32) | (unsigned)(0xffffffffu - (unsigned)(t + NT * j));
+      const unsigned long long comp = ((unsigned long long)kk << 32) | (unsigned)(0xffffffffu - (unsigned)(t + NTH * j));
       if (gt) sh.comp[atomicAdd(&sh.cnt_gt, 1u)] = comp;
       else if (eq && before < krem) sh.comp[n_gt + before] = comp;
       base_eq += tot;
@@ -218,7 +223,7 @@ __device__ void block_topk_regs(const unsigned (&keys)[EPT > 0 ? EPT : 1], KeyFn
   for (int size = 2; size <= SORT_N; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
       const int partner = t ^ stride;
-      if (partner > t) {
+      if (partner > t && partner < SORT_N) {
         const unsigned long long a = sh.comp[t], b = sh.comp[partner];
         const bool desc = (t & size) == 0;
         if (desc ? (a < b) : (a > b)) { sh.comp[t] = b; sh.comp[partner] = a; }
@@ -250,8 +255,8 @@ __device__ __forceinline__ float iou_colmax(const float (*bx)[4], int j, int r0,
 }
 
 // K2: one block per (class, image).  EPT = keys per thread (0: keys stay in memory)
-template <int EPT>
-__global__ __launch_bounds__(NT, (EPT > 80 ? 1 : 2)) void class_topk_nms_k(const float *__restrict__ scores,  // [B,nclass,P]
+template <int EPT, int NTH>
+__global__ __launch_bounds__(NTH, (NTH / 256) * (EPT > 80 ? 1 : 2)) void class_topk_nms_k(const float *__restrict__ scores,  // [B,nclass,P]
                                                        const int *__restrict__ keep, const int *__restrict__ num_keep,
                                                        const float *__restrict__ loc, const float *__restrict__ priors,
                                                        int P, int nclass, int top_k, float nms_thresh,
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(NT, (EPT > 80 ? 1 : 2)) void class_topk_nms_k(const
   float *cs = cand_score + ((size_t)b * nclass + c) * top_k;
   int *cp = cand_prior + ((size_t)b * nclass + c) * top_k;
   if (K == 0) {
-    for (int i = t; i < top_k; i += NT) { cs[i] = -1.f; cp[i] = -1; }
+    for (int i = t; i < top_k; i += NTH) { cs[i] = -1.f; cp[i] = -1; }
     return;
   }
   const int k = K < top_k ? K : top_k;
@@ -275,16 +280,16 @@ __global__ __launch_bounds__(NT, (EPT > 80 ? 1 : 2)) void class_topk_nms_k(const
     unsigned keys[EPT];
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
-      const int i = t + NT * j, ii = i < P ? i : 0;   // unconditional, independent loads: all 2*EPT stay in flight
+      const int i = t + NTH * j, ii = i < P ? i : 0;   // unconditional, independent loads: all 2*EPT stay in flight
       const int kf = kp[ii];
       const float sv = sc[ii];
       keys[j] = (i < P && kf) ? f2key(sv) : 0u;
     }
     if (dbg & 1) { sh.comp[t] = ((unsigned long long)keys[0] << 32) | (unsigned)(0xffffffffu - (unsigned)t); __syncthreads(); }
-    else block_topk_regs<EPT>(keys, [](int) -> unsigned { return 0u; }, P, k, sh);
+    else block_topk_regs<EPT, NTH>(keys, [](int) -> unsigned { return 0u; }, P, k, sh);
   } else {
     const unsigned none[1] = {0u};
-    block_topk_regs<0>(none, [&](int i) -> unsigned { return kp[i] ? f2key(sc[i]) : 0u; }, P, k, sh);
+    block_topk_regs<0, NTH>(none, [&](int i) -> unsigned { return kp[i] ? f2key(sc[i]) : 0u; }, P, k, sh);
   }
 
   // rank t -> prior index, score, decoded box
@@ -359,10 +364,10 @@ __global__ __launch_bounds__(NT, (EPT > 80 ? 1 : 2)) void final_topk_k(const flo
       const float sv = cs[ii];
       keys[j] = (i < n && pf >= 0) ? f2key(sv) : 0u;
     }
-    block_topk_regs<EPT>(keys, [](int) -> unsigned { return 0u; }, n, k, sh);
+    block_topk_regs<EPT, NT>(keys, [](int) -> unsigned { return 0u; }, n, k, sh);
   } else {
     const unsigned none[1] = {0u};
-    block_topk_regs<0>(none, [&](int i) -> unsigned { return cp[i] >= 0 ? f2key(cs[i]) : 0u; }, n, k, sh);
+    block_topk_regs<0, NT>(none, [&](int i) -> unsigned { return cp[i] >= 0 ? f2key(cs[i]) : 0u; }, n, k, sh);
   }
   for (int j = t; j < k; j += NT) {
     const int f = (int)(0xffffffffu - (unsigned)(sh.comp[j] & 0xffffffffull));
@@ -407,14 +412,15 @@ extern "C" int ymi_detect_f32(const ymi_detect_desc *d, void *stream) {
   int dbg = 0;   // diagnostics only (env YMI_DETECT_ABLATE): bit0 skip selection, bit2 skip the IoU triangle
   { const char *e = getenv("YMI_DETECT_ABLATE"); if (e) dbg = atoi(e); }
   const float *sc = d->cross_class ? d->maxsc : d->scores_t;
-#define YMI_K2(EPT)                                                                                                  \
-  hipLaunchKernelGGL(class_topk_nms_k<EPT>, dim3(nclass, d->B), dim3(NT), 0, s, sc, d->keep, d->num_keep, d->loc,  \
+#define YMI_K2(EPT, NTH)                                                                                             \
+  hipLaunchKernelGGL((class_topk_nms_k<EPT, NTH>), dim3(nclass, d->B), dim3(NTH), 0, s, sc, d->keep, d->num_keep, d->loc, \
                      d->priors, d->P, nclass, d->top_k, d->nms_thresh, d->cand_score, d->cand_prior, dbg)
-  // keys per thread: 19 248 priors (550 px) -> 80, 30 963 (700 px) -> 128; beyond that (57 744 for YOLACT++) the keys
-  // stay in memory and every bisection pass re-reads them from L2
-  if (d->P <= NT * 80) YMI_K2(80);
-  else if (d->P <= NT * 128) YMI_K2(128);
-  else YMI_K2(0);
+  // keys per thread x threads: 19 248 priors (550 px) -> 80 x 256, 30 963 (700 px) -> 128 x 256, 57 744 (YOLACT++) ->
+  // 128 x 512; beyond 65 536 the keys stay in memory and every bisection pass re-reads them from L2
+  if (d->P <= 256 * 80) YMI_K2(80, 256);
+  else if (d->P <= 256 * 128) YMI_K2(128, 256);
+  else if (d->P <= 512 * 128) YMI_K2(128, 512);
+  else YMI_K2(0, 256);
 #undef YMI_K2
   rc = ymi_launch_status();
   if (rc) return rc;

@@ -517,18 +517,26 @@ class Plan:
                 else:
                     cands = [t for t in sorted(L.TILE_NAMES) if t != L.TILE_128x32]
                 best, best_ms, times = None, 1e30, {}
-                for t in cands:
-                    d.tile = t
-                    L.check(fn(dptr, s), name)
-                    e0.record()
-                    for _ in range(reps):
-                        fn(dptr, s)
-                    e1.record()
-                    e1.synchronize()
-                    ms = e0.elapsed_time(e1) / reps
-                    times[L.TILE_NAMES[t]] = round(ms, 4)
-                    if ms < best_ms:
-                        best, best_ms = t, ms
+                ok_cands = []
+                for t in cands:                       # warm every candidate once (code fetch, clocks); skip the
+                    d.tile = t                        # ones this layer cannot use
+                    if fn(dptr, s) == 0:
+                        ok_cands.append(t)
+                for rnd in range(2):                  # two interleaved rounds, keep each tile's best time: a single
+                    for t in ok_cands:                # noisy sample used to flip near-ties and move bench by +-3 %
+                        d.tile = t
+                        e0.record()
+                        for _ in range(reps):
+                            fn(dptr, s)
+                        e1.record()
+                        e1.synchronize()
+                        ms = e0.elapsed_time(e1) / reps
+                        name_t = L.TILE_NAMES[t]
+                        times[name_t] = round(min(ms, times.get(name_t, 1e30)), 4)
+                for t in ok_cands:
+                    if times[L.TILE_NAMES[t]] < best_ms:
+                        best, best_ms = t, times[L.TILE_NAMES[t]]
+                assert best is not None, name
                 cache[key] = best
                 table.append((name, L.TILE_NAMES[best], times))
             d.tile = cache[key]
