@@ -174,7 +174,8 @@ constexpr int conv_occupancy() {
   constexpr int stage_b = ns * (BM + BN) * BK * WK * 4, epi_b = WK * BM * (BN + 4) * 4;
   constexpr int lds_b = stage_b > epi_b ? stage_b : epi_b;
   constexpr int occ = (160 * 1024) / lds_b;
-  return occ > 5 ? 5 : (occ < 1 ? 1 : occ);
+  constexpr int cap = (LOADER == 2) ? 3 : 5;     // the DCN gather keeps per-tap geometry in registers: no spills
+  return occ > cap ? cap : (occ < 1 ? 1 : occ);
 }
 
 template <int WM, int WN, int WK, int TM, int TN, int NSTAGE, int LOADER>
@@ -282,6 +283,8 @@ __global__ __launch_bounds__(256, (conv_occupancy<WM, WN, WK, TM, TN, NSTAGE, LO
   }
 
   f32x4 ra[LOADER == 2 ? RA : 1];
+  int dc_o[LOADER == 2 ? RA : 1][4];      // DCN: corner offsets (elements) and weights (+ modulation) of the current tap
+  float dc_w[LOADER == 2 ? RA : 1][5];
 
   // stage step `st` (chunks st*WK .. st*WK + WK - 1) into LDS stage `buf`
   auto issue_tile = [&](int st, int buf) {
@@ -317,32 +320,45 @@ __global__ __launch_bounds__(256, (conv_occupancy<WM, WN, WK, TM, TN, NSTAGE, LO
         // DCNv2 (dcn_v2_im2col_cuda.cu:143-193): sample point = (oy*s - p + ky + dh, ox*s - p + kx + dw),
         // zero unless -1 < h < H and -1 < w < W; zero-padded bilinear; times sigmoid(mask logit).
         // Thread (kq, r0) produces LOGICAL slot kq of its rows and stores it at the swizzled position.
-        const int tap = nx_ky[j] * 3 + nx_kx[j], c = nx_c[j] + 4 * kq;
+        // The sampling geometry of a row depends on the tap only, so offsets / sigmoid / corner addresses are
+        // resolved once per tap (first channel chunk) and the Cin/32 chunks of the tap issue nothing but their
+        // four independent corner loads: no dependent offmask -> address -> data round trip per K step.
+        if (nx_c[j] == 0) {
+          const int tap = nx_ky[j] * 3 + nx_kx[j];
+#pragma unroll
+          for (int i = 0; i < RA; ++i) {
+            int o1 = 0, o2 = 0, o3 = 0, o4 = 0;
+            float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f, mk = 0.f;
+            if (a_iy0[i] > -(1 << 27)) {
+              const int m = a_base[i];
+              const float *om = p.offmask + (size_t)m * p.ldo;
+              const float dh = om[2 * tap], dw = om[2 * tap + 1];
+              mk = 1.f / (1.f + expf(-om[18 + tap]));
+              const float h = (float)(a_iy0[i] + nx_ky[j]) + dh, w = (float)(a_ix0[i] + nx_kx[j]) + dw;
+              if (h > -1.f && w > -1.f && h < (float)d.H && w < (float)d.W) {
+                const int hl = (int)floorf(h), wl = (int)floorf(w);
+                const int hh = hl + 1, wh = wl + 1;
+                const float lh = h - (float)hl, lw = w - (float)wl, uh = 1.f - lh, uw = 1.f - lw;
+                const int ib = (m / p.HoWo) * d.H * d.W;
+                // an out-of-range corner contributes 0 (dmcn_im2col_bilinear): weight 0 on a safe address
+                if (hl >= 0 && wl >= 0) { o1 = (ib + hl * d.W + wl) * d.ldx; w1 = uh * uw; }
+                if (hl >= 0 && wh <= d.W - 1) { o2 = (ib + hl * d.W + wh) * d.ldx; w2 = uh * lw; }
+                if (hh <= d.H - 1 && wl >= 0) { o3 = (ib + hh * d.W + wl) * d.ldx; w3 = lh * uw; }
+                if (hh <= d.H - 1 && wh <= d.W - 1) { o4 = (ib + hh * d.W + wh) * d.ldx; w4 = lh * lw; }
+              }
+            }
+            dc_o[i][0] = o1; dc_o[i][1] = o2; dc_o[i][2] = o3; dc_o[i][3] = o4;
+            dc_w[i][0] = w1; dc_w[i][1] = w2; dc_w[i][2] = w3; dc_w[i][3] = w4; dc_w[i][4] = mk;
+          }
+        }
+        const float *xc = d.x + nx_c[j] + 4 * kq;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-          f32x4 v = {0.f, 0.f, 0.f, 0.f};
-          if (a_iy0[i] > -(1 << 27)) {
-            const int m = a_base[i];
-            const float *om = p.offmask + (size_t)m * p.ldo;
-            const float dh = om[2 * tap], dw = om[2 * tap + 1];
-            const float mk = 1.f / (1.f + expf(-om[18 + tap]));
-            const float h = (float)(a_iy0[i] + nx_ky[j]) + dh, w = (float)(a_ix0[i] + nx_kx[j]) + dw;
-            if (h > -1.f && w > -1.f && h < (float)d.H && w < (float)d.W) {
-              const int hl = (int)floorf(h), wl = (int)floorf(w);
-              const int hh = hl + 1, wh = wl + 1;
-              const float lh = h - (float)hl, lw = w - (float)wl, uh = 1.f - lh, uw = 1.f - lw;
-              const int b = m / p.HoWo;
-              const float *img = d.x + (size_t)b * d.H * d.W * d.ldx + c;
-              f32x4 v1 = {0.f, 0.f, 0.f, 0.f}, v2 = v1, v3 = v1, v4 = v1;
-              if (hl >= 0 && wl >= 0) v1 = *reinterpret_cast<const f32x4 *>(img + (hl * d.W + wl) * d.ldx);
-              if (hl >= 0 && wh <= d.W - 1) v2 = *reinterpret_cast<const f32x4 *>(img + (hl * d.W + wh) * d.ldx);
-              if (hh <= d.H - 1 && wl >= 0) v3 = *reinterpret_cast<const f32x4 *>(img + (hh * d.W + wl) * d.ldx);
-              if (hh <= d.H - 1 && wh <= d.W - 1) v4 = *reinterpret_cast<const f32x4 *>(img + (hh * d.W + wh) * d.ldx);
-              const float w1 = uh * uw, w2 = uh * lw, w3 = lh * uw, w4 = lh * lw;
-              v = (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4) * mk;
-            }
-          }
-          ra[i] = v;
+          const f32x4 v1 = *reinterpret_cast<const f32x4 *>(xc + dc_o[i][0]);
+          const f32x4 v2 = *reinterpret_cast<const f32x4 *>(xc + dc_o[i][1]);
+          const f32x4 v3 = *reinterpret_cast<const f32x4 *>(xc + dc_o[i][2]);
+          const f32x4 v4 = *reinterpret_cast<const f32x4 *>(xc + dc_o[i][3]);
+          ra[i] = (dc_w[i][0] * v1 + dc_w[i][1] * v2 + dc_w[i][2] * v3 + dc_w[i][3] * v4) * dc_w[i][4];
         }
       }
 #pragma unroll
