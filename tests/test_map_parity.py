@@ -1,0 +1,93 @@
+"""Mask / box mAP parity on pseudo ground truth (BASELINE metric: "mask mAP parity").
+
+tests/golden/map.npz holds, per golden case, pseudo GT (the reference's own top detections) and the mAP table that the
+reference's OWN evaluator (eval.prep_metrics / eval.calc_map, executed in the build container by
+oracle/make_golden_map.py) gives the reference's detections on it.
+  * CPU: oracle/map_eval.py (restated evaluator) on the stored reference detections reproduces that table exactly.
+  * GPU: the HIP path's detections for the same images, scored by the same evaluator on the same GT, give the same
+    table within 0.5 mAP points (a single borderline detection flipping at one IoU threshold moves a class AP by
+    1/(#gt) and the mean over ~10 classes by less than that).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN_DIR, load_golden, case_images
+from oracle import map_eval as ME
+
+CASES = ['r50_dense', 'r50_sparse', 'r101_base', 'darknet53', 'im700', 'plus_r50']
+NUM_CLASSES = 80      # len(cfg.dataset.class_names), data/config.py:129-135 (COCO)
+
+
+def _gold():
+    return np.load(os.path.join(GOLDEN_DIR, 'map.npz'))
+
+
+def _gt(z, name, b, w, h):
+    gt = z['%s_gt%d' % (name, b)]
+    g = gt.shape[0]
+    gm = np.unpackbits(z['%s_gtmaskbits%d' % (name, b)])[: g * h * w].reshape(g, h, w).astype(np.float32)
+    return gt, gm
+
+
+def _table(maps):
+    keys = list(maps['box'].keys())
+    return np.array([maps['box'][k] for k in keys]), np.array([maps['mask'][k] for k in keys])
+
+
+def _ref_post(arrays, b, w, h):
+    classes = torch.from_numpy(arrays['post%d_class' % b])
+    scores = torch.from_numpy(arrays['post%d_score' % b])
+    if ('post%d_score2' % b) in arrays:
+        scores = [scores, torch.from_numpy(arrays['post%d_score2' % b])]
+    boxes = torch.from_numpy(arrays['post%d_box' % b])
+    n = classes.shape[0]
+    masks = torch.from_numpy(np.unpackbits(arrays['post%d_maskbits' % b])[: n * h * w].reshape(n, h, w).astype(np.float32))
+    return classes, scores, boxes, masks
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_restated_evaluator_reproduces_reference_tables(name):
+    z = _gold()
+    meta, arrays = load_golden(name)
+    w, h = meta['post']
+    ap = ME.new_ap_data(NUM_CLASSES)
+    for b, n in enumerate(meta['n']):
+        if n == 0:
+            continue
+        gt, gm = _gt(z, name, b, w, h)
+        ME.prep_metrics(ap, *_ref_post(arrays, b, w, h), gt, gm, h, w)
+    box, mask = _table(ME.calc_map(ap, NUM_CLASSES))
+    # calc_map returns the table rounded to 2 decimals (eval.py:1029)
+    assert np.array_equal(np.round(box, 2), z[name + '_box']) and np.array_equal(np.round(mask, 2), z[name + '_mask'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', CASES)
+def test_hip_path_map_matches_reference(name):
+    from gpu_utils import build_net, DEV
+    from yolact_amd.layers.output_utils import postprocess
+    z = _gold()
+    meta, arrays = load_golden(name)
+    w, h = meta['post']
+    net = build_net(meta)
+    preds = net(case_images(meta).to(DEV))
+    ap = ME.new_ap_data(NUM_CLASSES)
+    for b, n in enumerate(meta['n']):
+        if n == 0:
+            continue
+        gt, gm = _gt(z, name, b, w, h)
+        classes, scores, boxes, masks = postprocess(preds, w, h, batch_idx=b)
+        if isinstance(scores, list):
+            scores = [s.cpu() for s in scores]
+        else:
+            scores = scores.cpu()
+        ME.prep_metrics(ap, classes.cpu(), scores, boxes.cpu(), masks.cpu(), gt, gm, h, w)
+    box, mask = _table(ME.calc_map(ap, NUM_CLASSES))
+    rb, rm = z[name + '_box'], z[name + '_mask']
+    print('%s  box mAP ref %.2f hip %.2f | mask mAP ref %.2f hip %.2f' % (name, rb[0], box[0], rm[0], mask[0]))
+    assert np.abs(box - rb).max() <= 0.5, (box, rb)
+    assert np.abs(mask - rm).max() <= 0.5, (mask, rm)
