@@ -69,7 +69,9 @@ enum { YMI_TILE_AUTO = 0, YMI_TILE_128x128 = 1, YMI_TILE_128x64 = 2, YMI_TILE_64
        YMI_TILE_64x128 = 5, YMI_TILE_32x32_K4 = 6, YMI_TILE_64x32_K2 = 7, YMI_TILE_32x64_K2 = 8,
        /* _Sn = n-stage LDS pipeline (n-1 K steps of LDS-DMA in flight); Cin % 32 == 0 layers only */
        YMI_TILE_64x64_S3 = 9, YMI_TILE_64x64_S4 = 10, YMI_TILE_64x128_S3 = 11, YMI_TILE_128x64_S3 = 12,
-       YMI_TILE_32x32_K4_S4 = 13, YMI_TILE_64x32_K2_S3 = 14, YMI_TILE_32x64_K2_S3 = 15 };
+       YMI_TILE_32x32_K4_S4 = 13, YMI_TILE_64x32_K2_S3 = 14, YMI_TILE_32x64_K2_S3 = 15,
+       /* _W8 = 512-thread blocks (8 waves): half the global->LDS traffic per FLOP of the 4-wave tile of equal wave tile */
+       YMI_TILE_128x128_W8 = 16, YMI_TILE_256x128_W8 = 17, YMI_TILE_128x256_W8 = 18 };
 
 int ymi_abi_version(void);
 const char *ymi_strerror(int code);

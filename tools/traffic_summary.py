@@ -8,7 +8,8 @@ from collections import defaultdict
 TILES = {(2, 2, 1, 2, 2, 2): '128x128', (2, 2, 1, 2, 1, 2): '128x64', (2, 2, 1, 1, 1, 2): '64x64', (4, 1, 1, 1, 1, 2): '128x32',
          (2, 2, 1, 1, 2, 2): '64x128', (1, 1, 4, 1, 1, 2): '32x32k4', (2, 1, 2, 1, 1, 2): '64x32k2', (1, 2, 2, 1, 1, 2): '32x64k2',
          (2, 2, 1, 1, 1, 3): '64x64s3', (2, 2, 1, 1, 1, 4): '64x64s4', (2, 2, 1, 1, 2, 3): '64x128s3', (2, 2, 1, 2, 1, 3): '128x64s3',
-         (1, 1, 4, 1, 1, 4): '32x32k4s4', (2, 1, 2, 1, 1, 3): '64x32k2s3', (1, 2, 2, 1, 1, 3): '32x64k2s3'}
+         (1, 1, 4, 1, 1, 4): '32x32k4s4', (2, 1, 2, 1, 1, 3): '64x32k2s3', (1, 2, 2, 1, 1, 3): '32x64k2s3',
+         (4, 2, 1, 1, 2, 2): '128x128w8', (4, 2, 1, 2, 2, 2): '256x128w8', (4, 2, 1, 1, 4, 2): '128x256w8'}
 
 
 def collect(root, counter):

@@ -179,11 +179,15 @@ constexpr int conv_occupancy() {
 }
 
 template <int WM, int WN, int WK, int TM, int TN, int NSTAGE, int LOADER>
-__global__ __launch_bounds__(256, (conv_occupancy<WM, WN, WK, TM, TN, NSTAGE, LOADER>())) void conv_igemm_f32(const KParams p) {
+__global__ __launch_bounds__(64 * WM * WN * WK, (conv_occupancy<WM, WN, WK, TM, TN, NSTAGE, LOADER>() * (WM * WN * WK) / 4))
+void conv_igemm_f32(const KParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // host pass: empty body.  hipcc (ROCm 7.2) silently drops the host launch stub of a
                                       // templated kernel whose body uses the buffer-resource LDS-DMA builtins.
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr int RA = BM / 32, RB = BN / 32;  // 8-row DMA pieces per wave per chunk for the A / B tile
+  constexpr int NWAVE = WM * WN * WK, NTHR = 64 * NWAVE;   // 4 waves (256 threads) or 8 waves (512 threads)
+  constexpr int RPP = NTHR / 8;               // tile rows staged by one pass of the block (8 lanes per row)
+  constexpr int RA = BM / RPP, RB = BN / RPP;  // 8-row DMA pieces per wave per chunk for the A / B tile
+  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the rows per staging pass");
   constexpr int SUB = (BM + BN) * BK;        // floats per chunk image [BM + BN rows][32]
   constexpr int STAGE = SUB * WK;            // floats per pipeline stage
   constexpr int NS = (LOADER == 2) ? 2 : NSTAGE;   // the register-staged DCN gather keeps the simple 2-stage drain
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(256, (conv_occupancy<WM, WN, WK, TM, TN, NSTAGE, LO
   constexpr int ELD = BN + 4;                // epilogue tile row stride
   constexpr int LDS_FLOATS = (NS * STAGE > WK * BM * ELD) ? NS * STAGE : WK * BM * ELD;
   static_assert(DMA_PER_STEP * (NS - 2) <= 63, "vmcnt is a 6-bit counter");
-  static_assert(WM * WN * WK == 4, "4 waves per block");
+  static_assert(WM * WN * WK == 4 || WM * WN * WK == 8, "4 or 8 waves per block");
   static_assert(LOADER != 2 || WK == 1, "DCN gather runs without the K split");
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(256, (conv_occupancy<WM, WN, WK, TM, TN, NSTAGE, LO
   // NOW, so its HBM latency overlaps the whole K loop instead of serialising behind it in the epilogue (the
   // K <= 128 1x1 layers at 138x138 are HBM-bound: 2.3 TB/s before this, profiles/r01_*).
   constexpr int C4 = BN / 4;        // float4 columns per tile row
-  constexpr int RSTEP = 256 / C4;   // rows covered by one pass of the block
+  constexpr int RSTEP = NTHR / C4;  // rows covered by one pass of the block
   constexpr int RPT = BM / RSTEP;   // rows per thread
   constexpr bool RES_PREFETCH = RPT <= 8;
   const int c4 = t % C4, rbase = t / C4;
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(256, (conv_occupancy<WM, WN, WK, TM, TN, NSTAGE, LO
   int a_iy0[RA], a_ix0[RA], a_base[RA];        // a_base: byte offset of (pixel, channel 4*sl) for tap (0,0)
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
-    const int m = m0 + r0 + 32 * i;
+    const int m = m0 + r0 + RPP * i;
     if (m < p.M) {
       const int b = m / p.HoWo, pix = m - b * p.HoWo;
       const int oy = pix / d.Wo, ox = pix - oy * d.Wo;
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(256, (conv_occupancy<WM, WN, WK, TM, TN, NSTAGE, LO
   }
   unsigned b_off[RB];                           // byte offset of (filter row, k-slot sl) for chunk 0
 #pragma unroll
-  for (int i = 0; i < RB; ++i) b_off[i] = (unsigned)(((n0 + r0 + 32 * i) * d.Kpad + 4 * sl) * 4);
+  for (int i = 0; i < RB; ++i) b_off[i] = (unsigned)(((n0 + r0 + RPP * i) * d.Kpad + 4 * sl) * 4);
 
   // incremental (tap, channel-chunk) state of the next chunk to stage for each of the WK chunk slots (LOADER 0 / 2)
   int nx_c[WK], nx_ky[WK], nx_kx[WK];
@@ -302,7 +306,7 @@ __global__ __launch_bounds__(256, (conv_occupancy<WM, WN, WK, TM, TN, NSTAGE, LO
           const bool ok = live && (unsigned)(a_iy0[i] + nx_ky[j]) < (unsigned)d.H &&
                           (unsigned)(a_ix0[i] + nx_kx[j]) < (unsigned)d.W;
           const unsigned voff = ok ? (unsigned)(a_base[i] + koff) : OOB;
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(As + (wave * 8 + 32 * i) * BK), 16, voff, 0, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(As + (wave * 8 + RPP * i) * BK), 16, voff, 0, 0, 0);
         }
       } else if (LOADER == 1) {
         const int tap = kc * 8 + sl;
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(256, (conv_occupancy<WM, WN, WK, TM, TN, NSTAGE, LO
           const bool ok = live && tap_ok && (unsigned)(a_iy0[i] + ky) < (unsigned)d.H &&
                           (unsigned)(a_ix0[i] + kx) < (unsigned)d.W;
           const unsigned voff = ok ? (unsigned)(a_base[i] + koff) : OOB;
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(As + (wave * 8 + 32 * i) * BK), 16, voff, 0, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(As + (wave * 8 + RPP * i) * BK), 16, voff, 0, 0, 0);
         }
       } else {
         // DCNv2 (dcn_v2_im2col_cuda.cu:143-193): sample point = (oy*s - p + ky + dh, ox*s - p + kx + dw),
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(256, (conv_occupancy<WM, WN, WK, TM, TN, NSTAGE, LO
       }
 #pragma unroll
       for (int i = 0; i < RB; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(Bs + (wave * 8 + 32 * i) * BK), 16,
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(Bs + (wave * 8 + RPP * i) * BK), 16,
                                                  live ? b_off[i] : OOB, live ? kc * (BK * 4) : 0, 0, 0);
       if (LOADER != 1) {  // this slot's next chunk is WK chunks further
 #pragma unroll
@@ -376,7 +380,7 @@ __global__ __launch_bounds__(256, (conv_occupancy<WM, WN, WK, TM, TN, NSTAGE, LO
     if (LOADER == 2) {
       float *As = lds + buf * STAGE;
 #pragma unroll
-      for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4 *>(As + (r0 + 32 * i) * BK + 4 * sl) = ra[i];
+      for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4 *>(As + (r0 + RPP * i) * BK + 4 * sl) = ra[i];
     }
   };
 
@@ -603,10 +607,10 @@ int launch_cfg(const KParams &kp, int loader, hipStream_t s) {
     }
   }
   if (loader == 0) {
-    hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, NS, 0>), dim3(grid), dim3(256), dyn, s, p);
+    hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, NS, 0>), dim3(grid), dim3(64 * WM * WN * WK), dyn, s, p);
   } else if constexpr (ALL_LOADERS) {   // stem (Cin = 4) and DCN gather loaders exist for the basic tiles only
-    if (loader == 1) hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, NS, 1>), dim3(grid), dim3(256), dyn, s, p);
-    else hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, NS, 2>), dim3(grid), dim3(256), dyn, s, p);
+    if (loader == 1) hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, NS, 1>), dim3(grid), dim3(64 * WM * WN * WK), dyn, s, p);
+    else hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, NS, 2>), dim3(grid), dim3(64 * WM * WN * WK), dyn, s, p);
   } else {
     return YMI_EARG;
   }
@@ -629,7 +633,10 @@ int launch_cfg(const KParams &kp, int loader, hipStream_t s) {
   X(YMI_TILE_128x64_S3, 2, 2, 1, 2, 1, 3, false)            \
   X(YMI_TILE_32x32_K4_S4, 1, 1, 4, 1, 1, 4, false)          \
   X(YMI_TILE_64x32_K2_S3, 2, 1, 2, 1, 1, 3, false)          \
-  X(YMI_TILE_32x64_K2_S3, 1, 2, 2, 1, 1, 3, false)
+  X(YMI_TILE_32x64_K2_S3, 1, 2, 2, 1, 1, 3, false)          \
+  X(YMI_TILE_128x128_W8, 4, 2, 1, 1, 2, 2, false)           \
+  X(YMI_TILE_256x128_W8, 4, 2, 1, 2, 2, 2, false)           \
+  X(YMI_TILE_128x256_W8, 4, 2, 1, 1, 4, 2, false)
 
 int tile_dims(int tile, int &bm, int &bn) {
   switch (tile) {

@@ -516,6 +516,8 @@ class Plan:
                              L.TILE_32x64_K2, L.TILE_32x64_K2_S3]
                 else:
                     cands = [t for t in sorted(L.TILE_NAMES) if t != L.TILE_128x32]
+                    if d.Cout < 256:
+                        cands = [t for t in cands if t != L.TILE_128x256_W8]
                 best, best_ms, times = None, 1e30, {}
                 ok_cands = []
                 for t in cands:                       # warm every candidate once (code fetch, clocks); skip the
