@@ -153,6 +153,12 @@ int ymi_boxes_to_pixels(const float *box, int64_t *out, int N, int w, int h, voi
 int ymi_fast_base_transform_f32(const float *img, float *out, int N, int H, int W, int oh, int ow,
                                 const float *mean_bgr, const float *std_bgr, int mode, int out_nhwc4, void *stream);
 
+/* -- mask_iou (layers/box_utils.py:98-113; consumer: eval.py:376-384,435-440 prep_metrics) --------------------------
+ * masks_a [A,n], masks_b [B,n] float32 (n = h*w) -> iou [A,B] = inter / (area_a + area_b - inter), or inter / area_a when
+ * iscrowd.  ws: caller-allocated workspace of A*B + A + B floats.  Exact for 0/1 masks (integer partial sums). */
+int ymi_mask_iou_f32(const float *masks_a, const float *masks_b, int A, int B, long n, int iscrowd, float *ws, float *iou,
+                     void *stream);
+
 /* -- DCNv2 forward (external/DCNv2/src/vision.cpp:5, dcn_v2.h:9-39, dcn_v2_cuda.cu:42-172) ---- */
 typedef struct {
   ymi_conv_desc conv;    /* main 3x3 conv: x, packed w, bias, epilogue, outputs (kh=kw=3, pad=1) */

@@ -32,8 +32,24 @@ def jaccard(box_a, box_b, iscrowd: bool = False):
 
 
 def mask_iou(masks_a, masks_b, iscrowd=False):
+    """box_utils.py:98-113.  GPU tensors go through the HIP kernel (csrc/metrics.hip: split-K MFMA intersection + areas
+    in one pass over the masks, exact for 0/1 masks); CPU tensors (eval.py --cuda=False bookkeeping) keep the
+    reference's torch expression."""
     a = masks_a.reshape(masks_a.size(0), -1)
     b = masks_b.reshape(masks_b.size(0), -1)
+    if a.is_cuda and b.is_cuda and a.size(0) > 0 and b.size(0) > 0:
+        import ctypes as C
+        from .. import _lib as L
+        a, b = a.float().contiguous(), b.float().contiguous()
+        A, B, n = a.size(0), b.size(0), a.size(1)
+        if b.size(1) != n:
+            raise RuntimeError('mask_iou: masks have %d and %d pixels' % (n, b.size(1)))
+        ws = torch.empty(A * B + A + B, dtype=torch.float32, device=a.device)
+        out = torch.empty(A, B, dtype=torch.float32, device=a.device)
+        with torch.cuda.device(a.device):
+            L.check(L.lib().ymi_mask_iou_f32(a.data_ptr(), b.data_ptr(), A, B, n, 1 if iscrowd else 0, ws.data_ptr(),
+                                             out.data_ptr(), L.stream_ptr()), 'ymi_mask_iou_f32')
+        return out
     inter = a @ b.t()
     area_a, area_b = a.sum(1).unsqueeze(1), b.sum(1).unsqueeze(0)
     return inter / (area_a + area_b - inter) if not iscrowd else inter / area_a
