@@ -159,6 +159,12 @@ int ymi_fast_base_transform_f32(const float *img, float *out, int N, int H, int 
 int ymi_mask_iou_f32(const float *masks_a, const float *masks_b, int A, int B, long n, int iscrowd, float *ws, float *iou,
                      void *stream);
 
+/* -- prep_display, GPU half (eval.py:186-209,228): alpha-composite n instance masks onto a frame.
+ * img [h,w,3] float32 0..255 (channel order as given), masks [n,h,w] float32, colors [n,3] float32 0..1 (device, same
+ * channel order as img), out [h,w,3] uint8.  n = 0 just converts the frame. */
+int ymi_composite_masks_u8(const float *img, const float *masks, const float *colors, int n, int h, int w, float alpha,
+                           unsigned char *out, void *stream);
+
 /* -- DCNv2 forward (external/DCNv2/src/vision.cpp:5, dcn_v2.h:9-39, dcn_v2_cuda.cu:42-172) ---- */
 typedef struct {
   ymi_conv_desc conv;    /* main 3x3 conv: x, packed w, bias, epilogue, outputs (kh=kw=3, pad=1) */

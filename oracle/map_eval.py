@@ -167,3 +167,42 @@ def pseudo_gt(classes, scores, boxes, masks, w, h, max_gt=10, max_overlap=0.3):
         b = boxes[i].double().numpy()
         gt[r] = [b[0] / w, b[1] / h, b[2] / w, b[3] / h, int(classes[i])]
     return gt, masks[chosen].numpy().astype(np.uint8)
+
+
+# ----------------------------------------------------------------------------------------------
+# prep_display, GPU half — eval.py:135-209,228 with undo_transform=False
+COLORS = ((244, 67, 54), (233, 30, 99), (156, 39, 176), (103, 58, 183), (63, 81, 181), (33, 150, 243), (3, 169, 244),
+          (0, 188, 212), (0, 150, 136), (76, 175, 80), (139, 195, 74), (205, 220, 57), (255, 235, 59), (255, 193, 7),
+          (255, 152, 0), (255, 87, 34), (121, 85, 72), (158, 158, 158), (96, 125, 139))      # data/config.py:6-24
+
+
+def prep_display_masks(post, img, mask_alpha=0.45, top_k=5, score_threshold=0, class_color=False):
+    """post = postprocess() outputs (classes, scores, boxes, masks [n,h,w]); img [h,w,3] float 0..255.
+    eval.py:141-142 (img/255), :155-165 (top-k by score, threshold), :169-184 (colours, BGR swap), :189-209 (cumprod
+    compositing), :228 (uint8)."""
+    img_gpu = img / 255.0
+    classes, scores, boxes, masks = post
+    idx = scores.argsort(0, descending=True)[:top_k]
+    masks = masks[idx]
+    classes, scores = classes[idx].numpy(), scores[idx].numpy()
+    n = min(top_k, classes.shape[0])
+    for j in range(n):
+        if scores[j] < score_threshold:
+            n = j
+            break
+    if n > 0:
+        masks = masks[:n, :, :, None]
+        cols = []
+        for j in range(n):
+            c = COLORS[(classes[j] * 5 if class_color else j * 5) % len(COLORS)]
+            cols.append(torch.Tensor((c[2], c[1], c[0])).float() / 255.)
+        colors = torch.cat([c.view(1, 1, 1, 3) for c in cols], dim=0)
+        masks_color = masks.repeat(1, 1, 1, 3) * colors * mask_alpha
+        inv_alph_masks = masks * (-mask_alpha) + 1
+        masks_color_summand = masks_color[0]
+        if n > 1:
+            inv_alph_cumul = inv_alph_masks[:(n - 1)].cumprod(dim=0)
+            masks_color_cumul = masks_color[1:] * inv_alph_cumul
+            masks_color_summand += masks_color_cumul.sum(dim=0)
+        img_gpu = img_gpu * inv_alph_masks.prod(dim=0) + masks_color_summand
+    return (img_gpu * 255).byte()

@@ -104,3 +104,52 @@ extern "C" int ymi_mask_iou_f32(const float *masks_a, const float *masks_b, int 
   hipLaunchKernelGGL(mask_iou_final_k, dim3((A * B + 255) / 256), dim3(256), 0, s, inter, area_a, area_b, iou, A, B, iscrowd);
   return ymi_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// prep_display's GPU half: alpha-composite the top-k instance masks onto the frame.
+// Reference: eval.py:186-209 (+ :228 the uint8 conversion) —
+//   img = frame / 255;  mc_j = (m_j * color_j) * alpha;  inv_j = m_j * (-alpha) + 1
+//   out = img * prod_j inv_j + mc_0 + sum_{j>=1} mc_j * prod_{i<j} inv_i ;  result = uint8(out * 255)
+// (= painting detection n-1 first and detection 0 last).  One pass: the frame and the n masks are read once, the
+// uint8 frame is written once.
+namespace {
+
+__global__ __launch_bounds__(256) void composite_masks_k(const float *__restrict__ img, const float *__restrict__ masks,
+                                                         const float *__restrict__ colors, int n, long hw, float alpha,
+                                                         unsigned char *__restrict__ out) {
+  for (long p = blockIdx.x * 256L + threadIdx.x; p < hw; p += (long)gridDim.x * 256L) {
+    float px[3] = {img[p * 3 + 0] / 255.f, img[p * 3 + 1] / 255.f, img[p * 3 + 2] / 255.f};
+    float cum = 1.f;                       // prod_{i<j} inv_i
+    float first[3] = {0.f, 0.f, 0.f}, rest[3] = {0.f, 0.f, 0.f};
+    for (int j = 0; j < n; ++j) {
+      const float m = masks[(long)j * hw + p];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float mc = (m * colors[j * 3 + c]) * alpha;
+        if (j == 0) first[c] = mc;
+        else rest[c] += mc * cum;
+      }
+      cum = cum * (m * (-alpha) + 1.f);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float v = (px[c] * cum + (n > 1 ? first[c] + rest[c] : first[c])) * 255.f;
+      out[p * 3 + c] = (unsigned char)(int)v;      // torch .byte(): truncation toward zero (values are in [0, 255])
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int ymi_composite_masks_u8(const float *img, const float *masks, const float *colors, int n, int h, int w,
+                                      float alpha, unsigned char *out, void *stream) {
+  if (!img || !out) return YMI_ENULL;
+  if (n < 0 || h <= 0 || w <= 0) return YMI_EARG;
+  if (n > 0 && (!masks || !colors)) return YMI_ENULL;
+  const long hw = (long)h * w;
+  long g = (hw + 255) / 256;
+  if (g > 256L * 16) g = 256L * 16;
+  hipLaunchKernelGGL(composite_masks_k, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, img, masks, colors, n, hw,
+                     alpha, out);
+  return ymi_launch_status();
+}
