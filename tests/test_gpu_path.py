@@ -302,3 +302,24 @@ def test_yolact_plus_postprocess_maskiou_rescoring():
         assert torch.is_tensor(s2) and (s2.cpu() - rs[1]).abs().max().item() < 1e-4 * max(1.0, rs[1].abs().max().item())
     finally:
         yolact_amd.active_cfg().rescore_bbox = False
+
+
+@pytest.mark.gpu
+def test_runs_under_cuda_default_device():
+    """eval.py --cuda sets torch.set_default_tensor_type('torch.cuda.FloatTensor') (eval.py:1077-1081): every
+    device-less factory call lands on the GPU.  The shim must not depend on the default device either way."""
+    from gpu_utils import build_net
+    from yolact_amd.layers.output_utils import postprocess
+    meta, _ = load_golden('r50_sparse')
+    net = build_net(meta)
+    x = case_images(meta).to(DEV)
+    ref = net(x)
+    torch.set_default_device('cuda')
+    try:
+        out = net(x)
+        classes, scores, boxes, masks = postprocess(out, 96, 128)
+        assert classes.is_cuda and boxes.dtype == torch.int64 and masks.shape[1:] == (128, 96)
+        assert torch.equal(out[0]['detection']['score'], ref[0]['detection']['score'])
+        assert torch.equal(out[0]['detection']['class'], ref[0]['detection']['class'])
+    finally:
+        torch.set_default_device('cpu')
