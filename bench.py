@@ -46,6 +46,8 @@ def roofline(net, x, reps=3):
     """Per-launch HIP-event timing of every conv launch (events recorded on the launch stream by the library)."""
     from yolact_amd import _lib as L
     lib = L.lib()
+    split = os.environ.get('YOLACT_AMD_BATCH_SPLIT')
+    os.environ['YOLACT_AMD_BATCH_SPLIT'] = '1'      # per-kernel pass: one full-batch plan, serialised
     plan = net.plan_for(x)
     names = [n for n, _ in plan.conv_meta]
     # The timed region overlaps the small P4..P7 / Detect kernels with the P3 branch on a second HIP stream; kernels
@@ -59,6 +61,8 @@ def roofline(net, x, reps=3):
     torch.cuda.synchronize()
     lib.ymi_prof_enable(0)
     plan.overlap = True
+    if split is not None:
+        os.environ['YOLACT_AMD_BATCH_SPLIT'] = split
     n = lib.ymi_prof_count()
     per = n // reps
     ms, fl, tile, kind = C.c_float(), C.c_double(), C.c_int32(), C.c_int32()

@@ -35,8 +35,8 @@ class Detect(object):
         self.use_fast_nms = True   # the reference defaults to False and eval.py:871 turns it on; see __call__
         self._ws = {}
 
-    def _workspace(self, B, P, C, D, cap, dev):
-        key = (B, P, C, D, cap, dev)
+    def _workspace(self, B, P, C, D, cap, dev, slot=0):
+        key = (B, P, C, D, cap, dev, slot)
         ws = self._ws.get(key)
         if ws is None:
             nfg = C - 1
@@ -46,10 +46,12 @@ class Detect(object):
                 argmax=torch.empty(B, P, dtype=torch.int32, device=dev),
                 cand_score=torch.empty(B, nfg * self.top_k, device=dev),
                 cand_prior=torch.empty(B, nfg * self.top_k, dtype=torch.int32, device=dev))
-            self._ws = {key: ws}
+            if len(self._ws) > 4:
+                self._ws.clear()
+            self._ws[key] = ws
         return ws
 
-    def run_device(self, loc, conf, mask, priors, conf_is_logits, stream=None):
+    def run_device(self, loc, conf, mask, priors, conf_is_logits, stream=None, slot=0):
         """Launch the Detect kernels; returns fixed-capacity device tensors (no host sync).  `stream`: raw
         hipStream_t (ctypes void*) to launch on — the execution plan passes its side stream — default: torch's
         current stream.  Output tensors are always allocated under the ambient stream."""
@@ -61,7 +63,7 @@ class Detect(object):
         dev = conf.device
         max_det = int(cfg.max_num_detections)
         cap = self.top_k if self.use_cross_class_nms else max_det
-        ws = self._workspace(B, P, Ccls, D, cap, dev)
+        ws = self._workspace(B, P, Ccls, D, cap, dev, slot)
         out = dict(count=torch.empty(B, dtype=torch.int32, device=dev), box=torch.empty(B, cap, 4, device=dev),
                    score=torch.empty(B, cap, device=dev), cls=torch.empty(B, cap, dtype=torch.int64, device=dev),
                    coef=torch.empty(B, cap, D, device=dev), prior=torch.empty(B, cap, dtype=torch.int32, device=dev))
