@@ -309,6 +309,7 @@ def test_runs_under_cuda_default_device():
     """eval.py --cuda sets torch.set_default_tensor_type('torch.cuda.FloatTensor') (eval.py:1077-1081): every
     device-less factory call lands on the GPU.  The shim must not depend on the default device either way."""
     from gpu_utils import build_net
+    from helpers import case_images
     from yolact_amd.layers.output_utils import postprocess
     meta, _ = load_golden('r50_sparse')
     net = build_net(meta)

@@ -384,6 +384,43 @@ void conv_igemm_f32(const KParams p) {
     }
   };
 
+  // The same staging, one 8-row piece (one DMA instruction + its address math) at a time: the main loop drops these
+  // between the MFMA groups of the current step, so the ~60 staging instructions of a step issue in the shadow of
+  // this wave's own MFMAs instead of ahead of them (ablation: the staging block cost 9 % of the big layers,
+  // 130 -> 143 TFLOP/s with it removed).  q enumerates slot j = q / (RA+RB), then the A pieces, then the B pieces.
+  constexpr int NP = WK * (RA + RB);
+  auto issue_piece = [&](int st, int buf, int q) {
+    const int j = q / (RA + RB), r = q - j * (RA + RB);
+    const int kc = st * WK + j;
+    const bool live = (WK == 1) || (kc < p.nk);
+    float *As = lds + buf * STAGE + j * SUB;
+    float *Bs = As + BM * BK;
+    if (r < RA) {
+      const int i = r;
+      bool ok;
+      int koff;
+      if (LOADER == 0) {
+        koff = ((nx_ky[j] * d.W + nx_kx[j]) * d.ldx + nx_c[j]) * 4;
+        ok = live && (unsigned)(a_iy0[i] + nx_ky[j]) < (unsigned)d.H && (unsigned)(a_ix0[i] + nx_kx[j]) < (unsigned)d.W;
+      } else {   // LOADER == 1
+        const int tap = kc * 8 + sl;
+        const int ky = tap / d.kw, kx = tap - ky * d.kw;
+        koff = ((ky * d.W + kx) * d.ldx - 4 * sl) * 4;
+        ok = live && tap < d.kh * d.kw && (unsigned)(a_iy0[i] + ky) < (unsigned)d.H && (unsigned)(a_ix0[i] + kx) < (unsigned)d.W;
+      }
+      const unsigned voff = ok ? (unsigned)(a_base[i] + koff) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(As + (wave * 8 + RPP * i) * BK), 16, voff, 0, 0, 0);
+    } else {
+      const int i = r - RA;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(Bs + (wave * 8 + RPP * i) * BK), 16,
+                                               live ? b_off[i] : OOB, live ? kc * (BK * 4) : 0, 0, 0);
+      if (r == RA + RB - 1 && LOADER != 1) {   // last piece of slot j: its next chunk is WK chunks further
+#pragma unroll
+        for (int a = 0; a < WK; ++a) advance(j);
+      }
+    }
+  };
+
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -412,23 +449,40 @@ void conv_igemm_f32(const KParams p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) fb[slot][j] = *reinterpret_cast<const f32x4 *>(Bs + j * 32 * BK + fo[g]);
   };
-  auto compute = [&](int buf) {
+  // hook h (0..15) sits behind the TM*TN MFMAs of k-pair step h = 4*g + s; piece q goes to hook (16*q) / NP
+  auto compute = [&](int buf, bool stage_next, int nst, int nbuf) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int slot = g & 1;
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+      for (int s = 0; s < 4; ++s) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][i][s], fb[slot][j][s], acc[i][j], 0, 0, 0);
+        if (LOADER != 2) {
+#pragma unroll
+          for (int q = 0; q < NP; ++q) {
+            if ((16 * q) / NP == 4 * g + s) {
+              __builtin_amdgcn_sched_barrier(0);
+              if (stage_next) issue_piece(nst, nbuf, q);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+      }
       if (g + 2 < 4) {
         __builtin_amdgcn_sched_barrier(0);   // keep the prefetch right behind the MFMAs that free its registers
         load_frag(buf, g + 2, slot);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+  };
+  // a wave without a chunk of its own in a ragged K-split step still stages its share
+  auto stage_only = [&](int nst, int nbuf) {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) issue_piece(nst, nbuf, q);
   };
 
   // ---- main loop ---------------------------------------------------------------------------
@@ -451,9 +505,16 @@ void conv_igemm_f32(const KParams p) {
         load_frag(cur, 1, 1);
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (more && !(p.abl & 1)) issue_tile(st + 1, cur ^ 1);
-      __builtin_amdgcn_sched_barrier(0);
-      if (mine) compute(cur);
+      const bool stage = more && !(p.abl & 1);
+      if (LOADER == 2) {
+        if (stage) issue_tile(st + 1, cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(cur, false, 0, 0);
+      } else if (mine) {
+        compute(cur, stage, st + 1, cur ^ 1);
+      } else if (stage) {
+        stage_only(st + 1, cur ^ 1);
+      }
       if (more) store_a_regs(cur ^ 1);
       if (!(p.abl & 4)) __syncthreads();
     }
@@ -480,9 +541,9 @@ void conv_igemm_f32(const KParams p) {
         load_frag(cur, 1, 1);
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (st + NS - 1 < nsteps && !(p.abl & 1)) issue_tile(st + NS - 1, nxt);
-      __builtin_amdgcn_sched_barrier(0);
-      if (mine) compute(cur);
+      const bool stage = st + NS - 1 < nsteps && !(p.abl & 1);
+      if (mine) compute(cur, stage, st + NS - 1, nxt);
+      else if (stage) stage_only(st + NS - 1, nxt);
       if (st + 1 < nsteps) {
         const int rem = nsteps - 2 - st;                        // steps issued beyond st+1
         const int fl = rem < NS - 2 ? rem : NS - 2;
