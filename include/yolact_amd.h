@@ -83,6 +83,26 @@ double ymi_conv_flops(const ymi_conv_desc *d);
 /* which tile the auto heuristic picks (YMI_TILE_*) */
 int ymi_conv_pick_tile(const ymi_conv_desc *d);
 
+/* Winograd F(2x2,3x3) variant of ymi_conv2d_nhwc_f32 for kh = kw = 3, stride 1, pad 1, Cin % 32 == 0, Cout % 4 == 0, no
+ * residual, one dense output, activation none / ReLU / LeakyReLU (nn.Conv2d 3x3 + BN + ReLU of backbone.py:37-57,
+ * yolact.py:319-361, utils/functions.py:163-213).  2.25x fewer multiplications; results differ from the direct kernel by
+ * fp32 rounding of the transforms only (<= 2e-6 relative).
+ * u: transformed filters [16][CoutPad][C] (U = G g G^T, CoutPad % 128 == 0, zero padded), V / M: caller workspaces of
+ * 16*T*C and 16*T*Cout floats with T = B*ceil(H/2)*ceil(W/2). */
+typedef struct {
+  const float *x;       /* [B,H,W,C] NHWC */
+  const float *u;
+  const float *scale;   /* [Cout] or NULL */
+  const float *bias;    /* [Cout] or NULL */
+  float *y;             /* [B,H,W,Cout] */
+  float *V, *M;
+  int32_t B, H, W, C, Cout;
+  int32_t act;          /* YMI_ACT_NONE / RELU / LEAKY01 */
+  int32_t tile;         /* tile of the 16-group GEMM (0 = auto) */
+  int32_t _pad0;
+} ymi_wino_desc;
+int ymi_conv3x3_winograd_f32(const ymi_wino_desc *d, void *stream);
+
 /* -- layout / pooling / resize ---------------------------------------------------------- */
 /* x [B,C,H,W] (C<=4) -> y [B,H,W,4], zero-filled channels C..3.  Entry of Yolact.forward (yolact.py:564). */
 int ymi_nchw_to_nhwc4_f32(const float *x, float *y, int B, int C, int H, int W, void *stream);

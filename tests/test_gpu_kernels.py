@@ -219,3 +219,33 @@ def test_dcn_known_answers():
     om2[:, 18:] = 40.0      # sigmoid(40) == 1 in fp32
     y2 = run_conv(x, w2, None, None, 1, 1, dcn_offmask=om2)
     assert torch.allclose(y2, F.conv2d(x, w2, None, 1, 1), atol=2e-5)
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 9, 11, 96), (1, 32, 69, 69, 64), (3, 128, 6, 5, 132), (1, 256, 18, 18, 256)])
+@pytest.mark.parametrize('tile', [L.TILE_AUTO, L.TILE_64x64, L.TILE_64x128, L.TILE_128x128_W8, L.TILE_32x64_K2])
+def test_winograd_matches_direct(shape, tile):
+    """Winograd F(2x2,3x3) path (csrc/winograd.hip) vs torch's conv and vs the direct implicit-GEMM kernel: odd sizes
+    (partial last tile row / column), BN fold + ReLU epilogue, every GEMM tile the plan may pick."""
+    from gpu_utils import run_conv, run_wino, rel_err
+    import torch.nn as nn
+    B, Cin, H, W, Cout = shape
+    g = _g(B * 100 + Cin + Cout + H)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    bn = nn.BatchNorm2d(Cout).eval()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(Cout, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(Cout, generator=g) * 0.1)
+        bn.running_mean.copy_(torch.randn(Cout, generator=g) * 0.1)
+        bn.running_var.copy_(torch.rand(Cout, generator=g) + 0.5)
+        ref = F.relu(bn(F.conv2d(x, w, None, 1, 1)))
+    y = run_wino(x, w, None, bn, L.ACT_RELU, tile)
+    assert y.shape == ref.shape
+    assert rel_err(y, ref) < 2e-5
+    direct = run_conv(x, w, None, bn, 1, 1, act=L.ACT_RELU)
+    assert rel_err(y, direct) < 1e-5
+
+
+def test_winograd_rejects_unsupported():
+    d = L.WinoDesc()
+    assert L.lib().ymi_conv3x3_winograd_f32(C.byref(d), L.stream_ptr()) != 0

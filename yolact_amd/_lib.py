@@ -42,6 +42,13 @@ class ConvDesc(C.Structure):
                 ('seg', ConvSeg * 3)]
 
 
+class WinoDesc(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('u', C.c_void_p), ('scale', C.c_void_p), ('bias', C.c_void_p), ('y', C.c_void_p),
+                ('V', C.c_void_p), ('M', C.c_void_p),
+                ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('C', C.c_int32), ('Cout', C.c_int32),
+                ('act', C.c_int32), ('tile', C.c_int32), ('_pad0', C.c_int32)]
+
+
 class DcnDesc(C.Structure):
     _fields_ = [('conv', ConvDesc), ('offmask', C.c_void_p), ('ldo', C.c_int32)]
 
@@ -64,6 +71,7 @@ SYMBOLS = [
     ('ymi_abi_version', C.c_int, []),
     ('ymi_strerror', C.c_char_p, [C.c_int]),
     ('ymi_conv2d_nhwc_f32', C.c_int, [C.POINTER(ConvDesc), _P]),
+    ('ymi_conv3x3_winograd_f32', C.c_int, [C.POINTER(WinoDesc), _P]),
     ('ymi_conv_flops', C.c_double, [C.POINTER(ConvDesc)]),
     ('ymi_conv_pick_tile', C.c_int, [C.POINTER(ConvDesc)]),
     ('ymi_nchw_to_nhwc4_f32', C.c_int, [_P, _P, _I, _I, _I, _I, _P]),

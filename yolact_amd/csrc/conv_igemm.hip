@@ -43,6 +43,7 @@ struct KParams {
   unsigned x_bytes, w_bytes;      // buffer-resource sizes
   const float *offmask;           // DCN only
   int ldo;
+  long x_gs, w_gs, y_gs;          // grouped GEMM (gridDim.y groups, Winograd): element strides of x / w / seg[0].ptr per group
   unsigned long long *trace;      // diagnostics only (ymi_debug_set_trace): per block {hw id, t0, t_loop, t_epi, t1, t_transposed}
   int abl;                        // diagnostics only (env YMI_ABLATE): bit0 skip the staging of chunks > 0,
                                   // bit2 skip barriers in the K loop — wrong results, used to attribute stall time;
@@ -155,6 +156,8 @@ __device__ __forceinline__ void epilogue_general(const KParams &p, const float *
 // LOADER: 0 = Cin % 32 == 0 (a K chunk lies inside one filter tap; tap is block-uniform)
 //         1 = Cin == 4 (stem; a K chunk = 8 taps x 4 channels; tap is per-lane)
 //         2 = DCNv2 modulated deformable gather (Cin % 32 == 0, 3x3, pad 1): A through registers, B by DMA (WK == 1)
+//         3 = loader 0 instantiated separately for the grouped (Winograd, gridDim.y = 16) launches, so that profilers
+//             list them under their own kernel name
 // WK:     waves along K.  WM*WN*WK == 4.  With WK > 1 a pipeline stage holds WK consecutive 32-deep chunks and wave
 //         (wm, wn, wk) multiplies chunk wk of every stage; the WK partial tiles are summed (fixed order) in the
 //         epilogue's LDS tile.  This quarters the block tile (32x32 with WK = 4) without an inter-block reduction:
@@ -213,8 +216,11 @@ void conv_igemm_f32(const KParams p) {
   const int tile_n = logical % p.tiles_n, tile_m = logical / p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)d.x, 0, (int)p.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)d.w, 0, (int)p.w_bytes, 0x00020000);
+  const int grp = blockIdx.y;    // group of a grouped GEMM (the 16 Winograd components); 0 otherwise
+  const __amdgpu_buffer_rsrc_t xrs =
+      __builtin_amdgcn_make_buffer_rsrc((void *)(d.x + (size_t)grp * p.x_gs), 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs =
+      __builtin_amdgcn_make_buffer_rsrc((void *)(d.w + (size_t)grp * p.w_gs), 0, (int)p.w_bytes, 0x00020000);
 
   // ---- epilogue thread mapping + residual prefetch -----------------------------------------------
   // Each thread owns 4 consecutive output channels of RPT rows.  A plain residual (bottleneck shortcut) is fetched
@@ -299,7 +305,7 @@ void conv_igemm_f32(const KParams p) {
                                                      // step issues the same number of DMAs (vmcnt accounting)
       float *As = lds + buf * STAGE + j * SUB;
       float *Bs = As + BM * BK;
-      if (LOADER == 0) {
+      if (LOADER == 0 || LOADER == 3) {
         const int koff = ((nx_ky[j] * d.W + nx_kx[j]) * d.ldx + nx_c[j]) * 4;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
@@ -399,7 +405,7 @@ void conv_igemm_f32(const KParams p) {
       const int i = r;
       bool ok;
       int koff;
-      if (LOADER == 0) {
+      if (LOADER == 0 || LOADER == 3) {
         koff = ((nx_ky[j] * d.W + nx_kx[j]) * d.ldx + nx_c[j]) * 4;
         ok = live && (unsigned)(a_iy0[i] + nx_ky[j]) < (unsigned)d.H && (unsigned)(a_ix0[i] + nx_kx[j]) < (unsigned)d.W;
       } else {   // LOADER == 1
@@ -614,7 +620,7 @@ void conv_igemm_f32(const KParams p) {
         o[i] = v;
       }
       if (n < d.Cout) {
-        float *base = g0.ptr + (size_t)(m0 + rbase) * g0.row_stride + n;
+        float *base = g0.ptr + (size_t)grp * p.y_gs + (size_t)(m0 + rbase) * g0.row_stride + n;
 #pragma unroll
         for (int i = 0; i < RPT; ++i)
           if (m0 + rbase + RSTEP * i < p.M) *reinterpret_cast<f32x4 *>(base + (size_t)(RSTEP * i) * g0.row_stride) = o[i];
@@ -649,7 +655,7 @@ int g_prof_n = 0, g_prof_alloc = 0, g_prof_on = 0;
 constexpr int LDS_PER_CU = 160 * 1024, NUM_CU = 256;
 
 template <int WM, int WN, int WK, int TM, int TN, int NS, bool ALL_LOADERS>
-int launch_cfg(const KParams &kp, int loader, hipStream_t s) {
+int launch_cfg(const KParams &kp, int loader, hipStream_t s, int groups) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int ns_eff_bytes = NS * (BM + BN) * BK * WK * 4, epi_bytes = WK * BM * (BN + 4) * 4;
   constexpr int static_lds = ns_eff_bytes > epi_bytes ? ns_eff_bytes : epi_bytes;
@@ -657,21 +663,23 @@ int launch_cfg(const KParams &kp, int loader, hipStream_t s) {
   const int tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.d.Cout + BN - 1) / BN;
   const int grid = tiles_m * p.tiles_n;
-  if (p.trace && grid > g_trace_cap) p.trace = nullptr;
+  if (p.trace && (grid > g_trace_cap || groups > 1)) p.trace = nullptr;
   int dyn = 0;
   {
     const int occ = LDS_PER_CU / static_lds;               // LDS-limited residency (VGPRs allow >= this for every tile)
-    const int k = (grid + NUM_CU - 1) / NUM_CU;             // blocks per CU if perfectly spread
+    const int k = (grid * groups + NUM_CU - 1) / NUM_CU;    // blocks per CU if perfectly spread
     if (k < occ && !(p.abl & 8)) {
       const int want = LDS_PER_CU / (k + 1) + 1024;         // > 160K/(k+1)  =>  at most k blocks fit
       if (want > static_lds && want <= LDS_PER_CU / k) dyn = want - static_lds;
     }
   }
-  if (loader == 0) {
-    hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, NS, 0>), dim3(grid), dim3(64 * WM * WN * WK), dyn, s, p);
+  if (loader == 0 && groups > 1) {
+    hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, NS, 3>), dim3(grid, groups), dim3(64 * WM * WN * WK), dyn, s, p);
+  } else if (loader == 0) {
+    hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, NS, 0>), dim3(grid, groups), dim3(64 * WM * WN * WK), dyn, s, p);
   } else if constexpr (ALL_LOADERS) {   // stem (Cin = 4) and DCN gather loaders exist for the basic tiles only
-    if (loader == 1) hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, NS, 1>), dim3(grid), dim3(64 * WM * WN * WK), dyn, s, p);
-    else hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, NS, 2>), dim3(grid), dim3(64 * WM * WN * WK), dyn, s, p);
+    if (loader == 1) hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, NS, 1>), dim3(grid, groups), dim3(64 * WM * WN * WK), dyn, s, p);
+    else hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, NS, 2>), dim3(grid, groups), dim3(64 * WM * WN * WK), dyn, s, p);
   } else {
     return YMI_EARG;
   }
@@ -767,8 +775,15 @@ int validate(const ymi_conv_desc *d, int loader) {
   return YMI_OK;
 }
 
-int run_conv(const ymi_conv_desc *d, int loader, const float *offmask, int ldo, hipStream_t s) {
+int run_conv(const ymi_conv_desc *d, int loader, const float *offmask, int ldo, hipStream_t s, int groups = 1, long x_gs = 0,
+             long w_gs = 0, long y_gs = 0, double prof_flops = -1.0, int prof_kind = -1) {
   int rc = validate(d, loader);
+  // grouped launches take the fast-path epilogue only (it applies the group's output offset)
+  if (rc == YMI_OK && groups > 1 &&
+      (loader != 0 || d->nseg != 1 || groups > 65535 || (d->Cout & 3) || d->res_mode != YMI_RES_NONE ||
+       d->seg[0].act > YMI_ACT_LEAKY01 || d->seg[0].n0 != 0 || (d->seg[0].row_stride & 3) ||
+       d->seg[0].batch_stride != (int64_t)d->Ho * d->Wo * d->seg[0].row_stride))
+    rc = YMI_EARG;
   if (rc) return rc;
   KParams kp;
   kp.d = *d;
@@ -783,6 +798,7 @@ int run_conv(const ymi_conv_desc *d, int loader, const float *offmask, int ldo, 
   }
   kp.offmask = offmask;
   kp.ldo = ldo;
+  kp.x_gs = x_gs; kp.w_gs = w_gs; kp.y_gs = y_gs;
   { const char *e = getenv("YMI_ABLATE"); kp.abl = e ? atoi(e) : 0; }
   kp.trace = g_trace;
   int tile = d->tile ? d->tile : pick_tile(d);
@@ -794,11 +810,11 @@ int run_conv(const ymi_conv_desc *d, int loader, const float *offmask, int ldo, 
   if (g_prof_on && g_prof_n < PROF_MAX) {
     pr = &g_prof[g_prof_n];
     if (g_prof_n >= g_prof_alloc) { hipEventCreate(&pr->e0); hipEventCreate(&pr->e1); g_prof_alloc = g_prof_n + 1; }
-    pr->flops = ymi_conv_flops(d); pr->tile = tile; pr->kind = loader;
+    pr->flops = prof_flops >= 0 ? prof_flops : ymi_conv_flops(d); pr->tile = tile; pr->kind = prof_kind >= 0 ? prof_kind : loader;
     hipEventRecord(pr->e0, s);
   }
   switch (tile) {
-#define X(id, wm, wn, wk, tm, tn, ns, all) case id: rc = launch_cfg<wm, wn, wk, tm, tn, ns, all>(kp, loader, s); break;
+#define X(id, wm, wn, wk, tm, tn, ns, all) case id: rc = launch_cfg<wm, wn, wk, tm, tn, ns, all>(kp, loader, s, groups); break;
     YMI_TILE_TABLE(X)
 #undef X
     default: return YMI_EARG;
@@ -808,6 +824,27 @@ int run_conv(const ymi_conv_desc *d, int loader, const float *offmask, int ldo, 
 }
 
 }  // namespace
+
+// internal (not part of the C ABI): profiling brackets for composite ops (csrc/winograd.hip): a record that spans
+// several launches.  Returns the record index or -1 when profiling is off.
+int ymi_internal_prof_begin(double flops, int tile, int kind, hipStream_t s) {
+  if (!g_prof_on || g_prof_n >= PROF_MAX) return -1;
+  ProfRec *pr = &g_prof[g_prof_n];
+  if (g_prof_n >= g_prof_alloc) { hipEventCreate(&pr->e0); hipEventCreate(&pr->e1); g_prof_alloc = g_prof_n + 1; }
+  pr->flops = flops; pr->tile = tile; pr->kind = kind;
+  hipEventRecord(pr->e0, s);
+  return g_prof_n++;
+}
+void ymi_internal_prof_end(int idx, hipStream_t s) {
+  if (idx >= 0) hipEventRecord(g_prof[idx].e1, s);
+}
+
+// internal (not part of the C ABI): grouped GEMM for csrc/winograd.hip — `groups` independent 1x1 GEMMs that share the
+// descriptor's shape; group g reads x + g*x_gs, w + g*w_gs and writes seg[0].ptr + g*y_gs.
+int ymi_internal_grouped_gemm(const ymi_conv_desc *d, int groups, long x_gs, long w_gs, long y_gs, double prof_flops,
+                              int prof_kind, hipStream_t s) {
+  return run_conv(d, 0, nullptr, 0, s, groups, x_gs, w_gs, y_gs, prof_flops, prof_kind);
+}
 
 extern "C" {
 

@@ -40,6 +40,7 @@ class Packed:
         wp = torch.zeros(self.CoutPad, self.Kpad, dtype=torch.float32, device=weight.device)
         wp[:Cout, :K] = w.reshape(Cout, K)
         self.w = wp.to(device).contiguous()
+        self.weight_oihw = weight if (kh == 3 and kw == 3) else None     # Winograd transform source
         self.Cin, self.Cout, self.kh, self.kw, self.stride, self.pad = cin_p, Cout, kh, kw, stride, pad
         self.cin_alg = Cin
         scale = shift = None
@@ -54,6 +55,27 @@ class Packed:
             shift = bias.detach().float()
         self.scale = scale.to(device).contiguous() if scale is not None else None
         self.bias = shift.to(device).contiguous() if shift is not None else None
+
+
+class WinoPacked:
+    """Winograd F(2x2,3x3) filters U = G g G^T, layout [16][CoutPad][C] (csrc/winograd.hip), computed in fp64."""
+
+    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
+
+    def __init__(self, weight, device):
+        w = weight.detach().to(torch.float64).cpu()                 # [Cout, Cin, 3, 3]
+        Cout, Cin = w.shape[:2]
+        u = torch.einsum('ai,ncij,bj->abnc', self.G, w, self.G)      # [4,4,Cout,Cin]
+        self.CoutPad = _ceil(Cout, 128)
+        up = torch.zeros(16, self.CoutPad, Cin, dtype=torch.float32)
+        up[:, :Cout] = u.reshape(16, Cout, Cin).to(torch.float32)
+        self.u = up.to(device).contiguous()
+
+
+def wino_eligible(pk, res, segs, act, x_C):
+    return (pk.kh == 3 and pk.kw == 3 and pk.stride == 1 and pk.pad == 1 and pk.Cin % 32 == 0 and pk.Cout % 4 == 0
+            and pk.cin_alg == pk.Cin and x_C == pk.Cin and res is None and segs is None
+            and act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LEAKY01))
 
 
 def pack_module(conv: nn.Conv2d, bn=None, device=None, cin_pad=None) -> Packed:
@@ -129,7 +151,10 @@ class Plan:
                                  # is what per-kernel timing (bench.py's roofline pass) needs
         self.events = {}
         self._cur = 'A'
+        self.use_winograd = device.type == 'cuda' and os.environ.get('YOLACT_AMD_WINOGRAD', '1') != '0'
+        self.wino_alt, self._wino_packed, self._wino_ws = {}, {}, {}
         self._build()
+        self._bind_wino_workspaces()
 
     # ---- op emitters ---------------------------------------------------------------------------
     def _arena(self):
@@ -178,6 +203,10 @@ class Plan:
             for i, s in enumerate(segs):
                 d.seg[i] = L.ConvSeg(*s)
         self.keepalive.append(pk)
+        wino = None
+        if (self.use_winograd and dcn_offmask is None and out is None and pk.weight_oihw is not None
+                and wino_eligible(pk, res, segs, act, x.C)):
+            wino = self._wino_op(x, pk, act, y, name)
         if dcn_offmask is not None:
             dd = L.DcnDesc()
             dd.conv = d
@@ -187,7 +216,38 @@ class Plan:
         else:
             self.ops.append((self.lib.ymi_conv2d_nhwc_f32, C.pointer(d), name, self._cur))
             self.conv_meta.append((name, d))
+            if wino is not None:
+                self.wino_alt[len(self.ops) - 1] = wino      # op index -> alternative; autotune picks the faster one
         return y
+
+    def _wino_op(self, x: T, pk: Packed, act, y: T, name):
+        """Winograd alternative of a 3x3 / stride-1 conv: descriptor + per-stream workspaces (V, M)."""
+        key = id(pk)
+        wp = self._wino_packed.get(key)
+        if wp is None:
+            wp = self._wino_packed[key] = WinoPacked(pk.weight_oihw, self.device)
+        th, tw = (x.H + 1) // 2, (x.W + 1) // 2
+        Tn = x.B * th * tw
+        if Tn * max(pk.Cin, pk.Cout) >= (1 << 29):
+            return None
+        need_v, need_m = 16 * Tn * pk.Cin, 16 * Tn * pk.Cout
+        ws = self._wino_ws.setdefault(self._cur, [None, None])
+        if ws[0] is None or ws[0].numel() < need_v:
+            ws[0] = torch.empty(need_v, dtype=torch.float32, device=self.device)
+        if ws[1] is None or ws[1].numel() < need_m:
+            ws[1] = torch.empty(need_m, dtype=torch.float32, device=self.device)
+        d = L.WinoDesc()
+        d.x, d.u, d.y = x.ptr, wp.u.data_ptr(), y.ptr
+        d.scale = pk.scale.data_ptr() if pk.scale is not None else None
+        d.bias = pk.bias.data_ptr() if pk.bias is not None else None
+        d.B, d.H, d.W, d.C, d.Cout, d.act, d.tile = x.B, x.H, x.W, pk.Cin, pk.Cout, act, L.TILE_AUTO
+        return d
+
+    def _bind_wino_workspaces(self):
+        """Workspaces may have been re-allocated (grown) while the plan was built: point every descriptor at the final ones."""
+        for idx, d in self.wino_alt.items():
+            ws = self._wino_ws[self.ops[idx][3]]
+            d.V, d.M = ws[0].data_ptr(), ws[1].data_ptr()
 
     def call(self, fn, *args, name=''):
         self.ops.append((fn, args, name, self._cur))
@@ -542,12 +602,59 @@ class Plan:
                 cache[key] = best
                 table.append((name, L.TILE_NAMES[best], times))
             d.tile = cache[key]
+        self._autotune_winograd(e0, e1, s, reps, disk, cache_path)
         self.tune_table = table
         if cache_path and table:
             disk.update({str(k): v for k, v in cache.items()})
             with open(cache_path, 'w') as f:
                 json.dump(disk, f)
         return table
+
+    def _autotune_winograd(self, e0, e1, s, reps, disk, cache_path):
+        """Per eligible layer: best GEMM tile of the Winograd path, then Winograd vs the (already tuned) direct kernel.
+        The winner replaces the op in the list."""
+        lib = self.lib
+        wtiles = [L.TILE_64x64, L.TILE_64x128, L.TILE_128x64, L.TILE_128x128_W8, L.TILE_64x128_S3, L.TILE_32x64_K2]
+        memo = {}
+        self.wino_table = []
+        for idx, wd in sorted(self.wino_alt.items()):
+            fn, dptr, name, where = self.ops[idx]
+            if fn is not lib.ymi_conv2d_nhwc_f32:
+                continue
+            key = 'wino' + str((wd.B, wd.H, wd.W, wd.C, wd.Cout, wd.act))
+            if key in disk:
+                memo[key] = tuple(disk[key])
+            if key not in memo:
+                def timed(f, arg):
+                    f(arg, s)
+                    best = 1e30
+                    for _ in range(2):
+                        e0.record()
+                        for _ in range(reps):
+                            f(arg, s)
+                        e1.record()
+                        e1.synchronize()
+                        best = min(best, e0.elapsed_time(e1) / reps)
+                    return best
+                t_direct = timed(fn, dptr)
+                best_t, best_ms = 0, 1e30
+                for t in wtiles:
+                    wd.tile = t
+                    if lib.ymi_conv3x3_winograd_f32(C.byref(wd), s) != 0:
+                        continue
+                    ms = timed(lib.ymi_conv3x3_winograd_f32, C.pointer(wd))
+                    if ms < best_ms:
+                        best_t, best_ms = t, ms
+                memo[key] = (best_t, round(t_direct, 4), round(best_ms, 4))
+                disk[key] = list(memo[key])
+            best_t, t_direct, t_wino = memo[key]
+            self.wino_table.append((name, L.TILE_NAMES.get(best_t, '-'), t_direct, t_wino))
+            if best_t and t_wino < 0.97 * t_direct:
+                wd.tile = best_t
+                self.ops[idx] = (lib.ymi_conv3x3_winograd_f32, C.pointer(wd), name + '[wino]', where)
+        if cache_path and self.wino_table:
+            with open(cache_path, 'w') as f:
+                json.dump(disk, f)
 
     def conv_flops(self):
         return sum(self.lib.ymi_conv_flops(C.byref(d)) for _, d in self.conv_meta)
