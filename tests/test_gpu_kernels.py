@@ -246,6 +246,47 @@ def test_winograd_matches_direct(shape, tile):
     assert rel_err(y, direct) < 1e-5
 
 
+def test_winograd_head_segments_and_tanh():
+    """Segmented Winograd output transform: the shared prediction-head conv (Cout = A*(4+81+32) = 351, not a multiple
+    of 4) scattering to loc / conf / coef with a level offset, tanh on the coefficients (yolact.py:169-193)."""
+    from gpu_utils import nhwc, DEV
+    from yolact_amd.engine import Packed, WinoPacked
+    g = _g(29)
+    B, Cin, H, W, A, Ccls, D = 2, 64, 7, 5, 3, 81, 32
+    x = torch.randn(B, Cin, H, W, generator=g)
+    wb, wc, wm = (torch.randn(A * k, Cin, 3, 3, generator=g) / 24 for k in (4, Ccls, D))
+    bb, bc, bm = (torch.randn(A * k, generator=g) for k in (4, Ccls, D))
+    wcat = torch.cat([wb, wc, wm])
+    pk = Packed(wcat, torch.cat([bb, bc, bm]), None, 1, 1, None, DEV)
+    wp = WinoPacked(wcat, DEV)
+    P, off = H * W * A + 17, 17
+    loc = torch.zeros(B, P, 4, device=DEV)
+    conf = torch.zeros(B, P, Ccls, device=DEV)
+    coef = torch.zeros(B, P, D, device=DEV)
+    xd = nhwc(x).to(DEV)
+    T = B * ((H + 1) // 2) * ((W + 1) // 2)
+    Ng = (pk.Cout + 3) // 4 * 4
+    V = torch.empty(16 * T * Cin, device=DEV)
+    Mw = torch.empty(16 * T * Ng, device=DEV)
+    d = L.WinoDesc()
+    d.x, d.u, d.bias, d.V, d.M = xd.data_ptr(), wp.u.data_ptr(), pk.bias.data_ptr(), V.data_ptr(), Mw.data_ptr()
+    d.B, d.H, d.W, d.C, d.Cout = B, H, W, Cin, pk.Cout
+    d.nseg = 3
+    n_b, n_c, n_m = A * 4, A * Ccls, A * D
+    d.seg[0] = L.ConvSeg(0, n_b, L.ACT_NONE, n_b, P * 4, loc.data_ptr() + off * 4 * 4)
+    d.seg[1] = L.ConvSeg(n_b, n_b + n_c, L.ACT_NONE, n_c, P * Ccls, conf.data_ptr() + off * Ccls * 4)
+    d.seg[2] = L.ConvSeg(n_b + n_c, n_b + n_c + n_m, L.ACT_TANH, n_m, P * D, coef.data_ptr() + off * D * 4)
+    L.check(L.lib().ymi_conv3x3_winograd_f32(C.byref(d), L.stream_ptr()), 'winograd')
+    torch.cuda.synchronize()
+    rl = F.conv2d(x, wb, bb, 1, 1).permute(0, 2, 3, 1).reshape(B, -1, 4)
+    rc = F.conv2d(x, wc, bc, 1, 1).permute(0, 2, 3, 1).reshape(B, -1, Ccls)
+    rm = torch.tanh(F.conv2d(x, wm, bm, 1, 1).permute(0, 2, 3, 1).reshape(B, -1, D))
+    assert torch.allclose(loc.cpu()[:, off:], rl, atol=2e-5)
+    assert torch.allclose(conf.cpu()[:, off:], rc, atol=2e-5)
+    assert torch.allclose(coef.cpu()[:, off:], rm, atol=2e-5)
+    assert loc.cpu()[:, :off].abs().max() == 0 and conf.cpu()[:, :off].abs().max() == 0
+
+
 def test_winograd_rejects_unsupported():
     d = L.WinoDesc()
     assert L.lib().ymi_conv3x3_winograd_f32(C.byref(d), L.stream_ptr()) != 0

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Final measurement pass of the round: full GPU test suite, smoke, bench (default + batch 1), single-stream rocprof stats.
-O=gpurun_out/final; mkdir -p $O
+O=gpurun_out/final8; mkdir -p $O
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; tail -2 $O/pytest.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1

@@ -73,9 +73,12 @@ class WinoPacked:
 
 
 def wino_eligible(pk, res, segs, act, x_C):
-    return (pk.kh == 3 and pk.kw == 3 and pk.stride == 1 and pk.pad == 1 and pk.Cin % 32 == 0 and pk.Cout % 4 == 0
-            and pk.cin_alg == pk.Cin and x_C == pk.Cin and res is None and segs is None
-            and act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LEAKY01))
+    if not (pk.kh == 3 and pk.kw == 3 and pk.stride == 1 and pk.pad == 1 and pk.Cin % 32 == 0
+            and pk.cin_alg == pk.Cin and x_C == pk.Cin and res is None):
+        return False
+    if segs is not None:                       # segmented scatter (prediction heads): any Cout / activation
+        return len(segs) <= 3
+    return pk.Cout % 4 == 0 and act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LEAKY01)
 
 
 def pack_module(conv: nn.Conv2d, bn=None, device=None, cin_pad=None) -> Packed:
@@ -206,7 +209,7 @@ class Plan:
         wino = None
         if (self.use_winograd and dcn_offmask is None and out is None and pk.weight_oihw is not None
                 and wino_eligible(pk, res, segs, act, x.C)):
-            wino = self._wino_op(x, pk, act, y, name)
+            wino = self._wino_op(x, pk, act, y, name, segs)
         if dcn_offmask is not None:
             dd = L.DcnDesc()
             dd.conv = d
@@ -220,7 +223,7 @@ class Plan:
                 self.wino_alt[len(self.ops) - 1] = wino      # op index -> alternative; autotune picks the faster one
         return y
 
-    def _wino_op(self, x: T, pk: Packed, act, y: T, name):
+    def _wino_op(self, x: T, pk: Packed, act, y: Optional[T], name, segs=None):
         """Winograd alternative of a 3x3 / stride-1 conv: descriptor + per-stream workspaces (V, M)."""
         key = id(pk)
         wp = self._wino_packed.get(key)
@@ -228,16 +231,23 @@ class Plan:
             wp = self._wino_packed[key] = WinoPacked(pk.weight_oihw, self.device)
         th, tw = (x.H + 1) // 2, (x.W + 1) // 2
         Tn = x.B * th * tw
-        if Tn * max(pk.Cin, pk.Cout) >= (1 << 29):
+        Ng = _ceil(pk.Cout, 4)
+        if Tn * max(pk.Cin, Ng) >= (1 << 29):
             return None
-        need_v, need_m = 16 * Tn * pk.Cin, 16 * Tn * pk.Cout
+        need_v, need_m = 16 * Tn * pk.Cin, 16 * Tn * Ng
         ws = self._wino_ws.setdefault(self._cur, [None, None])
         if ws[0] is None or ws[0].numel() < need_v:
             ws[0] = torch.empty(need_v, dtype=torch.float32, device=self.device)
         if ws[1] is None or ws[1].numel() < need_m:
             ws[1] = torch.empty(need_m, dtype=torch.float32, device=self.device)
         d = L.WinoDesc()
-        d.x, d.u, d.y = x.ptr, wp.u.data_ptr(), y.ptr
+        d.x, d.u = x.ptr, wp.u.data_ptr()
+        if segs is None:
+            d.y = y.ptr
+        else:
+            d.nseg = len(segs)
+            for i, s in enumerate(segs):
+                d.seg[i] = L.ConvSeg(*s)
         d.scale = pk.scale.data_ptr() if pk.scale is not None else None
         d.bias = pk.bias.data_ptr() if pk.bias is not None else None
         d.B, d.H, d.W, d.C, d.Cout, d.act, d.tile = x.B, x.H, x.W, pk.Cin, pk.Cout, act, L.TILE_AUTO
@@ -621,7 +631,7 @@ class Plan:
             fn, dptr, name, where = self.ops[idx]
             if fn is not lib.ymi_conv2d_nhwc_f32:
                 continue
-            key = 'wino' + str((wd.B, wd.H, wd.W, wd.C, wd.Cout, wd.act))
+            key = 'wino' + str((wd.B, wd.H, wd.W, wd.C, wd.Cout, wd.act, wd.nseg))
             if key in disk:
                 memo[key] = tuple(disk[key])
             if key not in memo:
