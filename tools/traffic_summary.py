@@ -12,12 +12,26 @@ TILES = {(2, 2, 1, 2, 2, 2): '128x128', (2, 2, 1, 2, 1, 2): '128x64', (2, 2, 1, 
          (4, 2, 1, 1, 2, 2): '128x128w8', (4, 2, 1, 2, 2, 2): '256x128w8', (4, 2, 1, 1, 4, 2): '128x256w8'}
 
 
+def steady_rows(f, counter):
+    """Rows of one process in dispatch order, cut to the trailing part that repeats with the plan's period (the bench
+    passes), so that launches made while autotuning (other tiles, other layers) do not pollute the per-kernel means."""
+    rows = [r for r in csv.DictReader(open(f)) if r['Counter_Name'] == counter and 'conv_igemm' in r['Kernel_Name']]
+    rows.sort(key=lambda r: int(r['Dispatch_Id']))
+    names = [r['Kernel_Name'] for r in rows]
+    for L in range(20, 400):
+        if 3 * L <= len(names) and names[-L:] == names[-2 * L:-L] == names[-3 * L:-2 * L]:
+            n = 3
+            while (n + 1) * L <= len(names) and names[-(n + 1) * L:-n * L] == names[-L:]:
+                n += 1
+            return rows[-n * L:]
+    return rows
+
+
 def collect(root, counter):
     acc = defaultdict(lambda: [0.0, 0])
-    for f in glob.glob(os.path.join(root, '**', '*counter_collection.csv'), recursive=True):
-        for r in csv.DictReader(open(f)):
-            if r['Counter_Name'] != counter:
-                continue
+    files = sorted(glob.glob(os.path.join(root, '**', '*counter_collection.csv'), recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:                      # the newest run only (gpurun_out/ accumulates earlier sessions)
+        for r in steady_rows(f, counter):
             m = re.search(r'conv_igemm_f32<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>', r['Kernel_Name'])
             if not m:
                 continue
