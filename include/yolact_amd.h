@@ -188,6 +188,17 @@ int ymi_mask_iou_f32(const float *masks_a, const float *masks_b, int A, int B, l
 int ymi_composite_masks_u8(const float *img, const float *masks, const float *colors, int n, int h, int w, float alpha,
                            unsigned char *out, void *stream);
 
+/* -- COCO result wire format (eval.py:320-324 Detections.add_mask -> pycocotools.mask.encode; maskApi.c rleEncode,
+ * rleToString): run lengths of the COLUMN-major flattening of each mask, starting with a (possibly empty) run of zeros.
+ * masks [N,h,w] float32 (nonzero = foreground; the path's masks are exactly {0,1}), w <= 2048.
+ * counts [N,cap] uint32, nruns [N] = true number of runs of each mask (a mask with nruns > cap was truncated: retry
+ * with a larger cap). */
+int ymi_mask_rle_f32(const float *masks, int N, int h, int w, uint32_t *counts, int32_t *nruns, int cap, void *stream);
+/* counts -> the ASCII string pycocotools stores in 'counts' (delta to counts[i-2] for i > 2, 5 bits per character,
+ * 0x20 = continuation, + 48).  str [N,cap_chars] bytes, nchars [N] = true length (> cap_chars: truncated). */
+int ymi_rle_to_string(const uint32_t *counts, const int32_t *nruns, int N, int cap, uint8_t *str, int32_t *nchars,
+                      int cap_chars, void *stream);
+
 /* -- DCNv2 forward (external/DCNv2/src/vision.cpp:5, dcn_v2.h:9-39, dcn_v2_cuda.cu:42-172) ---- */
 typedef struct {
   ymi_conv_desc conv;    /* main 3x3 conv: x, packed w, bias, epilogue, outputs (kh=kw=3, pad=1) */

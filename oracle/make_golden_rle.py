@@ -6,8 +6,10 @@ add_bbox rounded (eval.py:306-318).  They are the only outputs of that third-par
 pin oracle/coco_rle.py.  Run in the build container:  python oracle/make_golden_rle.py
 Checks EVERY string of the sampled files (decode -> size, inside-box, re-encode identical) and commits a small sample.
 """
+import ast
 import json
 import os
+import re
 import sys
 
 import numpy as np
@@ -52,9 +54,12 @@ def main():
             nruns, area = check(det)
             sample.append({'file': f, 'image_id': image_id, 'bbox': det['bbox'], 'score': det['score'],
                            'size': det['mask']['size'], 'counts': det['mask']['counts'], 'nruns': nruns, 'area': area})
+    # the category-id table get_coco_cat() inverts (data/config.py:46-55), read as data
+    src = open('/root/reference/data/config.py').read()
+    label_map = ast.literal_eval(re.search(r'COCO_LABEL_MAP\s*=\s*(\{.*?\})', src, re.S).group(1))
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', 'rle_web.json')
     json.dump({'source': 'reference web/dets/*.json (eval.py --output_web_json with the official weights)',
-               'checked_total': total, 'sample': sample}, open(out, 'w'))
+               'checked_total': total, 'label_map': {str(k): v for k, v in label_map.items()}, 'sample': sample}, open(out, 'w'))
     print('checked %d reference RLE strings, wrote %d samples -> %s (%d bytes)' % (total, len(sample), out,
                                                                                 os.path.getsize(out)))
 

@@ -87,6 +87,8 @@ SYMBOLS = [
     ('ymi_dcn_v2_forward_f32', C.c_int, [C.POINTER(DcnDesc), _P]),
     ('ymi_composite_masks_u8', C.c_int, [_P, _P, _P, _I, _I, _I, _F, _P, _P]),
     ('ymi_mask_iou_f32', C.c_int, [_P, _P, _I, _I, C.c_long, _I, _P, _P, _P]),
+    ('ymi_mask_rle_f32', C.c_int, [_P, _I, _I, _I, _P, _P, _I, _P]),
+    ('ymi_rle_to_string', C.c_int, [_P, _P, _I, _I, _P, _P, _I, _P]),
     ('ymi_fast_base_transform_f32', C.c_int, [_P, _P, _I, _I, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _I, _I, _P]),
     ('ymi_debug_set_trace', C.c_int, [_P, C.c_long]),
     ('ymi_prof_enable', C.c_int, [_I]),
