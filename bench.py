@@ -65,9 +65,9 @@ def roofline(net, x, reps=3):
         os.environ['YOLACT_AMD_BATCH_SPLIT'] = split
     n = lib.ymi_prof_count()
     ms, fl, tile, kind = C.c_float(), C.c_double(), C.c_int32(), C.c_int32()
-    # record kinds: 0/1/2 = one direct conv launch (loader id); 3 = a whole Winograd layer (input transform + 16-group
-    # GEMM + output transform, ALGORITHMIC conv FLOPs); 5 = the Winograd GEMM launch alone (the FLOPs it executes).
-    # Layer table / all_conv: kinds 0-3.  Single-kernel roofline: kinds 0-2 and 5.
+    # record kinds: 0/1/2 = one direct conv launch (loader id); 3 / 4 = a whole Winograd F(2x2) / F(4x4) layer (input
+    # transform + 16- / 36-group GEMM + output transform, ALGORITHMIC conv FLOPs); 5 / 6 = the Winograd GEMM launch alone
+    # (the FLOPs it executes).  Layer table / all_conv: kinds 0-4.  Single-kernel roofline: kinds 0-2, 5 and 6.
     by_kernel, layers = {}, {}
     tot_ms = tot_fl = 0.0
     li = -1
@@ -75,16 +75,16 @@ def roofline(net, x, reps=3):
     for i in range(n):
         L.check(lib.ymi_prof_read(i, C.byref(ms), C.byref(fl), C.byref(tile), C.byref(kind)))
         tname = L.TILE_NAMES.get(tile.value, '?')
-        if kind.value != 5:
+        if kind.value not in (5, 6):
             li += 1
-            lkey = ('winograd F(2x2,3x3) <gemm %s> (3 launches)' % tname) if kind.value == 3 else \
-                'conv_igemm_f32<%s,loader%d>' % (tname, kind.value)
+            lkey = ('winograd F(%dx%d,3x3) <gemm %s> (3 launches)' % (2 * kind.value - 4, 2 * kind.value - 4, tname)) \
+                if kind.value in (3, 4) else 'conv_igemm_f32<%s,loader%d>' % (tname, kind.value)
             la = layers.setdefault(names[li % nl], [0.0, fl.value, lkey])
             la[0] += ms.value / reps
             la[2] = lkey
             tot_ms += ms.value; tot_fl += fl.value
-        if kind.value != 3:
-            key = ('conv_igemm_f32<%s,winograd 16-group GEMM>' % tname) if kind.value == 5 else \
+        if kind.value not in (3, 4):
+            key = ('conv_igemm_f32<%s,winograd grouped GEMM>' % tname) if kind.value in (5, 6) else \
                 'conv_igemm_f32<%s,loader%d>' % (tname, kind.value)
             a = by_kernel.setdefault(key, [0.0, 0.0, 0])
             a[0] += ms.value; a[1] += fl.value; a[2] += 1
@@ -94,22 +94,23 @@ def roofline(net, x, reps=3):
     ach = dfl / (dms * 1e-3) / 1e12
     detail = {k: {'ms_per_step': v[0] / reps, 'tflops': v[1] / (v[0] * 1e-3) / 1e12, 'launches_per_step': v[2] // reps}
               for k, v in by_kernel.items()}
-    wino_layers = sum(1 for v in layers.values() if v[2].startswith('winograd'))
+    wino2 = sum(1 for v in layers.values() if v[2].startswith('winograd F(2x2'))
+    wino4 = sum(1 for v in layers.values() if v[2].startswith('winograd F(4x4'))
     return {
         'bound': 'mfma', 'kernel': name, 'achieved': round(ach, 2), 'peak': FP32_MFMA_PEAK_TFLOPS,
         'unit': 'TFLOP/s', 'frac': round(ach / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic_from_profiles(name),
         'measured': 'HIP events on the launch stream, %d serialised passes right after the timed region' % reps,
         'flops_basis': 'FLOPs the launch executes on the matrix cores (for a direct conv launch = the algorithmic conv '
-                       'FLOPs; for the Winograd GEMM launch = 16 GEMMs [T x C] x [C x Cout], i.e. the layer\'s '
-                       'algorithmic FLOPs / 2.25)',
+                       'FLOPs; for the Winograd GEMM launch = 16 (F(2x2,3x3)) or 36 (F(4x4,3x3)) GEMMs [T x C] x [C x Cout], '
+                       'i.e. the layer\'s algorithmic FLOPs / 2.25 resp. / 4)',
         'avg_launch_ms': round(dms / dn, 4), 'flops_per_launch': dfl / dn,
         'all_conv': {'ms_per_step': round(tot_ms / reps, 3), 'tflops': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
                      'gflop_per_step': round(tot_fl / reps / 1e9, 2),
                      'frac': round(tot_fl / (tot_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                      'basis': 'ALGORITHMIC conv FLOPs (SURVEY 8(d): 118.28 GFLOP/image) over the summed durations of '
-                              'every conv-layer launch incl. the Winograd transforms; %d of %d layers run Winograd '
-                              'F(2x2,3x3) (2.25x fewer multiplications), so this figure can exceed what the matrix '
-                              'cores execute' % (wino_layers, len(layers))},
+                              'every conv-layer launch incl. the Winograd transforms; of %d layers %d run Winograd '
+                              'F(2x2,3x3) (2.25x fewer multiplications) and %d F(4x4,3x3) (4x fewer), so this figure '
+                              'can exceed what the matrix cores execute' % (len(layers), wino2, wino4)},
         'per_kernel': detail,
     }, layers
 
@@ -236,6 +237,9 @@ def main():
             if args.layers:
                 for name, best, times in getattr(net.plan_for(x), 'tune_table', []):
                     print('tune %-20s -> %-8s %s' % (name, best, times), file=sys.stderr)
+                for name, best, t_dir, t_win, t_f2, t_f4 in getattr(net.plan_for(x), 'wino_table', []):
+                    print('wino %-20s -> %-14s direct %.4f ms  F(2x2) %.4f  F(4x4) %.4f%s' % (
+                        name, best, t_dir, t_f2, t_f4, '' if t_win < 0.97 * t_dir else '   (kept direct)'), file=sys.stderr)
                 for k, (ms, fl, kern) in layers.items():
                     print('%-22s %8.3f ms %8.2f GFLOP %7.1f TF/s  %s' % (k, ms, fl / 1e9, fl / ms / 1e9, kern),
                           file=sys.stderr)

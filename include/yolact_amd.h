@@ -87,8 +87,9 @@ int ymi_conv_pick_tile(const ymi_conv_desc *d);
  * residual, one dense output, activation none / ReLU / LeakyReLU (nn.Conv2d 3x3 + BN + ReLU of backbone.py:37-57,
  * yolact.py:319-361, utils/functions.py:163-213).  2.25x fewer multiplications; results differ from the direct kernel by
  * fp32 rounding of the transforms only (<= 2e-6 relative).
- * u: transformed filters [16][CoutPad][C] (U = G g G^T, CoutPad % 128 == 0, zero padded), V / M: caller workspaces of
- * 16*T*C and 16*T*ceil(Cout/4)*4 floats with T = B*ceil(H/2)*ceil(W/2).  With nseg > 0 the output transform scatters
+ * u: transformed filters [G][CoutPad][C] (U = G g G^T, CoutPad % 128 == 0, zero padded), V / M: caller workspaces of
+ * G*T*C and G*T*ceil(Cout/4)*4 floats with T = B*ceil(H/m)*ceil(W/m), G = (m+2)^2 = 16 (m = 2) or 36 (m = 4; 4x fewer
+ * multiplications than the direct kernel, fp32 rounding ~4x that of m = 2, still <= 1e-5 relative).  With nseg > 0 the output transform scatters
  * to segments (the shared prediction-head conv, yolact.py:169-193). */
 typedef struct {
   const float *x;       /* [B,H,W,C] NHWC */
@@ -102,6 +103,8 @@ typedef struct {
   int32_t tile;         /* tile of the 16-group GEMM (0 = auto) */
   int32_t nseg;         /* 0: dense y (Cout % 4 == 0, act none/ReLU/LeakyReLU).  1..3: scatter to seg[] like ymi_conv_desc
                          * (any Cout, any YMI_ACT_* per segment; `y` and `act` are ignored) */
+  int32_t m;            /* output tile edge: 0 or 2 = F(2x2,3x3) (16 GEMMs), 4 = F(4x4,3x3) (36 GEMMs) */
+  int32_t _pad0;
   ymi_conv_seg seg[3];
 } ymi_wino_desc;
 int ymi_conv3x3_winograd_f32(const ymi_wino_desc *d, void *stream);

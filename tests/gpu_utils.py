@@ -71,23 +71,24 @@ def build_net(meta, device=DEV):
     return net.to(device)
 
 
-def run_wino(x, weight, bias=None, bn=None, act=L.ACT_NONE, tile=L.TILE_AUTO):
+def run_wino(x, weight, bias=None, bn=None, act=L.ACT_NONE, tile=L.TILE_AUTO, m=2):
     """3x3 / stride 1 / pad 1 conv through ymi_conv3x3_winograd_f32. x: CPU NCHW. Returns CPU NCHW."""
     from yolact_amd.engine import WinoPacked
     pk = Packed(weight, bias, bn, 1, 1, None, DEV)          # folded scale / bias
-    wp = WinoPacked(weight, DEV)
+    wp = WinoPacked(weight, DEV, m)
     xd = nhwc(x).to(DEV)
     B, H, W, Cc = xd.shape
     Cout = weight.shape[0]
-    T = B * ((H + 1) // 2) * ((W + 1) // 2)
-    V = torch.empty(16 * T * Cc, device=DEV)
-    Mw = torch.empty(16 * T * Cout, device=DEV)
+    T = B * ((H + m - 1) // m) * ((W + m - 1) // m)
+    g = (m + 2) ** 2
+    V = torch.empty(g * T * Cc, device=DEV)
+    Mw = torch.empty(g * T * Cout, device=DEV)
     y = torch.full((B, H, W, Cout), float('nan'), device=DEV)
     d = L.WinoDesc()
     d.x, d.u, d.y, d.V, d.M = xd.data_ptr(), wp.u.data_ptr(), y.data_ptr(), V.data_ptr(), Mw.data_ptr()
     d.scale = pk.scale.data_ptr() if pk.scale is not None else None
     d.bias = pk.bias.data_ptr() if pk.bias is not None else None
-    d.B, d.H, d.W, d.C, d.Cout, d.act, d.tile = B, H, W, Cc, Cout, act, tile
+    d.B, d.H, d.W, d.C, d.Cout, d.act, d.tile, d.m = B, H, W, Cc, Cout, act, tile, m
     L.check(L.lib().ymi_conv3x3_winograd_f32(C.byref(d), L.stream_ptr()), 'winograd')
     torch.cuda.synchronize()
     return nchw(y.cpu())

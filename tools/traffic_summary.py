@@ -36,7 +36,7 @@ def collect(root, counter):
             if not m:
                 continue
             v = tuple(int(x) for x in m.groups())
-            key = ('conv_igemm_f32<%s,winograd 16-group GEMM>' % TILES.get(v[:6], str(v[:6]))) if v[6] == 3 else \
+            key = ('conv_igemm_f32<%s,winograd grouped GEMM>' % TILES.get(v[:6], str(v[:6]))) if v[6] == 3 else \
                 'conv_igemm_f32<%s,loader%d>' % (TILES.get(v[:6], str(v[:6])), v[6])
             a = acc[key]
             a[0] += float(r['Counter_Value']); a[1] += 1

@@ -46,7 +46,8 @@ class WinoDesc(C.Structure):
     _fields_ = [('x', C.c_void_p), ('u', C.c_void_p), ('scale', C.c_void_p), ('bias', C.c_void_p), ('y', C.c_void_p),
                 ('V', C.c_void_p), ('M', C.c_void_p),
                 ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('C', C.c_int32), ('Cout', C.c_int32),
-                ('act', C.c_int32), ('tile', C.c_int32), ('nseg', C.c_int32), ('seg', ConvSeg * 3)]
+                ('act', C.c_int32), ('tile', C.c_int32), ('nseg', C.c_int32), ('m', C.c_int32), ('_pad0', C.c_int32),
+                ('seg', ConvSeg * 3)]
 
 
 class DcnDesc(C.Structure):

@@ -185,6 +185,160 @@ __global__ __launch_bounds__(256) void wino_out_seg_k(const float *__restrict__ 
   }
 }
 
+// ---- F(4x4, 3x3): 36 multiplications per 4x4 output tile instead of 144 (4x fewer MFMA FLOPs than direct, 1.78x fewer
+// than F(2x2)); V / M hold 36 values per 16 pixels (2.25x the activation bytes instead of 4x).  Transform matrices of
+// Lavin & Gray (interpolation points 0, +-1, +-2, inf); the filter transform G g G^T is done on the host in fp64.
+// Rounding: coefficients up to 8 amplify fp32 rounding ~4x over F(2x2); end to end on the golden cases the heads move by
+// <= 8e-6 relative (direct kernels: 2e-6), an order of magnitude inside the 1e-4 budget.
+
+// t = B^T v for one column / row of six values;  B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0;
+//                                                      0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+__device__ __forceinline__ void bt6(const f32x4 v0, const f32x4 v1, const f32x4 v2, const f32x4 v3, const f32x4 v4, const f32x4 v5,
+                                    f32x4 &t0, f32x4 &t1, f32x4 &t2, f32x4 &t3, f32x4 &t4, f32x4 &t5) {
+  const f32x4 a = v4 - v2 * 4.f, b = v3 - v1 * 4.f;       // shared terms
+  const f32x4 c = v4 - v2, e = (v3 - v1) * 2.f;
+  t0 = (v0 * 4.f - v2 * 5.f) + v4;
+  t1 = a + b;
+  t2 = a - b;
+  t3 = c + e;
+  t4 = c - e;
+  t5 = (v1 * 4.f - v3 * 5.f) + v5;
+}
+
+// one thread = one 6x6 input patch (tile) x 4 channels.  x [B,H,W,C] NHWC, V [36][T][C]
+__global__ __launch_bounds__(256) void wino43_in_k(const float *__restrict__ x, float *__restrict__ V, int H, int W, int C4,
+                                                   int th, int tw, long T, long total) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    const int c4 = (int)(i % C4);
+    const long t = i / C4;
+    const int tx = (int)(t % tw);
+    const long r = t / tw;
+    const int ty = (int)(r % th);
+    const long b = r / th;
+    const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
+    const float *base = x + ((b * H) * (long)W) * (C4 * 4L) + c4 * 4;
+    f32x4 u[6][6];                         // u = B^T d, built column by column
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int xx = x0 + j;
+      const bool xok = (unsigned)xx < (unsigned)W;
+      f32x4 dcol[6];
+#pragma unroll
+      for (int iy = 0; iy < 6; ++iy) {
+        const int yy = y0 + iy;
+        const bool ok = xok && (unsigned)yy < (unsigned)H;
+        dcol[iy] = ld4(base + ((long)(ok ? yy : 0) * W + (ok ? xx : 0)) * (C4 * 4L), ok);
+      }
+      bt6(dcol[0], dcol[1], dcol[2], dcol[3], dcol[4], dcol[5], u[0][j], u[1][j], u[2][j], u[3][j], u[4][j], u[5][j]);
+    }
+    const long stride_e = T * (C4 * 4L);
+    float *o = V + t * (C4 * 4L) + c4 * 4;
+#pragma unroll
+    for (int iy = 0; iy < 6; ++iy) {       // rows: v = u B
+      f32x4 v[6];
+      bt6(u[iy][0], u[iy][1], u[iy][2], u[iy][3], u[iy][4], u[iy][5], v[0], v[1], v[2], v[3], v[4], v[5]);
+#pragma unroll
+      for (int l = 0; l < 6; ++l) *reinterpret_cast<f32x4 *>(o + (iy * 6 + l) * stride_e) = v[l];
+    }
+  }
+}
+
+// s = A^T v for six values;  A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+__device__ __forceinline__ void at6(const f32x4 v0, const f32x4 v1, const f32x4 v2, const f32x4 v3, const f32x4 v4, const f32x4 v5,
+                                    f32x4 &s0, f32x4 &s1, f32x4 &s2, f32x4 &s3) {
+  const f32x4 p12 = v1 + v2, m12 = v1 - v2, p34 = v3 + v4, m34 = v3 - v4;
+  s0 = (v0 + p12) + p34;
+  s1 = m12 + m34 * 2.f;
+  s2 = p12 + p34 * 4.f;
+  s3 = (m12 + m34 * 8.f) + v5;
+}
+
+// o[4][4] = A^T M A of tile t, 4 output channels.  M [36][T][N]
+__device__ __forceinline__ void wino43_out_tile(const float *__restrict__ src, long stride_e, f32x4 (&o)[4][4]) {
+  f32x4 s[4][6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    f32x4 mc[6];
+#pragma unroll
+    for (int iy = 0; iy < 6; ++iy) mc[iy] = *reinterpret_cast<const f32x4 *>(src + (iy * 6 + j) * stride_e);
+    at6(mc[0], mc[1], mc[2], mc[3], mc[4], mc[5], s[0][j], s[1][j], s[2][j], s[3][j]);
+  }
+#pragma unroll
+  for (int iy = 0; iy < 4; ++iy) at6(s[iy][0], s[iy][1], s[iy][2], s[iy][3], s[iy][4], s[iy][5], o[iy][0], o[iy][1], o[iy][2], o[iy][3]);
+}
+
+__global__ __launch_bounds__(256) void wino43_out_k(const float *__restrict__ Mm, float *__restrict__ y,
+                                                    const float *__restrict__ scale, const float *__restrict__ bias, int Ho,
+                                                    int Wo, int N4, int th, int tw, long T, int act, long total) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    const int n4 = (int)(i % N4);
+    const long t = i / N4;
+    const int tx = (int)(t % tw);
+    const long r = t / tw;
+    const int ty = (int)(r % th);
+    const long b = r / th;
+    f32x4 o[4][4];
+    wino43_out_tile(Mm + t * (N4 * 4L) + n4 * 4, T * (N4 * 4L), o);
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+    if (scale) sc = *reinterpret_cast<const f32x4 *>(scale + n4 * 4);
+    if (bias) bi = *reinterpret_cast<const f32x4 *>(bias + n4 * 4);
+    const float slope = act == YMI_ACT_RELU ? 0.f : (act == YMI_ACT_LEAKY01 ? 0.1f : 1.f);
+#pragma unroll
+    for (int iy = 0; iy < 4; ++iy) {
+      const int oy = 4 * ty + iy;
+      if (oy >= Ho) continue;
+#pragma unroll
+      for (int ix = 0; ix < 4; ++ix) {
+        const int ox = 4 * tx + ix;
+        if (ox >= Wo) continue;
+        f32x4 v = o[iy][ix] * sc + bi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], slope * v[e]);
+        *reinterpret_cast<f32x4 *>(y + ((b * Ho + oy) * (long)Wo + ox) * (N4 * 4L) + n4 * 4) = v;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void wino43_out_seg_k(const float *__restrict__ Mm, const SegTab st,
+                                                        const float *__restrict__ scale, const float *__restrict__ bias,
+                                                        int Ho, int Wo, int N4, int Cout, int th, int tw, long T, long total) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    const int n4 = (int)(i % N4);
+    const long t = i / N4;
+    const int tx = (int)(t % tw);
+    const long r = t / tw;
+    const int ty = (int)(r % th);
+    const long b = r / th;
+    f32x4 o[4][4];
+    wino43_out_tile(Mm + t * (N4 * 4L) + n4 * 4, T * (N4 * 4L), o);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n = n4 * 4 + e;
+      if (n >= Cout) continue;
+      float *ptr = nullptr; long bs = 0; int rs = 0, act = 0, n0 = 0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (k < st.nseg && n >= st.seg[k].n0 && n < st.seg[k].n1) {
+          ptr = st.seg[k].ptr; bs = st.seg[k].batch_stride; rs = st.seg[k].row_stride; act = st.seg[k].act; n0 = st.seg[k].n0;
+        }
+      if (!ptr) continue;
+      const float sc = scale ? scale[n] : 1.f, bi = bias ? bias[n] : 0.f;
+#pragma unroll
+      for (int iy = 0; iy < 4; ++iy) {
+        const int oy = 4 * ty + iy;
+        if (oy >= Ho) continue;
+#pragma unroll
+        for (int ix = 0; ix < 4; ++ix) {
+          const int ox = 4 * tx + ix;
+          if (ox >= Wo) continue;
+          ptr[b * bs + ((long)oy * Wo + ox) * rs + (n - n0)] = wino_act(o[iy][ix][e] * sc + bi, act);
+        }
+      }
+    }
+  }
+}
+
 unsigned grid_for(long total) {
   long g = (total + 255) / 256;
   const long cap = 256L * 64;
@@ -199,19 +353,25 @@ extern "C" int ymi_conv3x3_winograd_f32(const ymi_wino_desc *d, void *stream) {
   if (d->nseg == 0 && (!d->y || (d->Cout & 3) || d->act > YMI_ACT_LEAKY01 || d->act < 0)) return YMI_ESHAPE;
   for (int k = 0; k < d->nseg; ++k) if (!d->seg[k].ptr) return YMI_ENULL;
   if (d->C & 31) return YMI_ESHAPE;
+  if (d->m != 0 && d->m != 2 && d->m != 4) return YMI_EARG;
+  const int mt = d->m == 4 ? 4 : 2;           // output tile edge: F(2x2,3x3) or F(4x4,3x3)
+  const int ng = (mt + 2) * (mt + 2);         // independent GEMMs (16 or 36)
   const int Ng = (d->Cout + 3) / 4 * 4;       // GEMM width: zero filter rows up to a multiple of 4
   hipStream_t s = (hipStream_t)stream;
-  const int th = (d->H + 1) / 2, tw = (d->W + 1) / 2;      // output size == input size (3x3, stride 1, pad 1)
+  const int th = (d->H + mt - 1) / mt, tw = (d->W + mt - 1) / mt;      // output size == input size (3x3, stride 1, pad 1)
   const long T = (long)d->B * th * tw;
   if (T * (long)(d->C > Ng ? d->C : Ng) >= (1L << 29)) return YMI_ESHAPE;   // per-group tensors < 2 GiB
   const int C4 = d->C / 4, N4 = Ng / 4;
-  // profiling: record kind 3 = the whole layer (3 launches) with the layer's ALGORITHMIC FLOPs (2*9*C*Cout per output
-  // pixel, like the direct kernel); record kind 5 (inside the GEMM launch) = the 16-group GEMM alone with the FLOPs it
-  // executes (2*16*T*C*Cout = algorithmic / 2.25 for even sizes)
+  // profiling: record kind 3 (F(2x2)) / 4 (F(4x4)) = the whole layer (3 launches) with the layer's ALGORITHMIC FLOPs (2*9*C*Cout per output
+  // pixel, like the direct kernel); record kind 5 / 6 (inside the GEMM launch) = the 16- / 36-group GEMM alone with the FLOPs
+  // it executes (2*ng*T*C*Cout = algorithmic / 2.25 resp. / 4 for sizes that are multiples of the tile)
   const double alg = 2.0 * d->B * d->H * d->W * (double)d->Cout * 9.0 * d->C;
-  const double exe = 2.0 * 16.0 * (double)T * d->C * Ng;
-  const int outer = ymi_internal_prof_begin(alg, d->tile ? d->tile : YMI_TILE_64x64, 3, s);
-  hipLaunchKernelGGL(wino_in_k, dim3(grid_for(T * C4)), dim3(256), 0, s, d->x, d->V, d->H, d->W, C4, th, tw, T, T * C4);
+  const double exe = 2.0 * ng * (double)T * d->C * Ng;
+  const int outer = ymi_internal_prof_begin(alg, d->tile ? d->tile : YMI_TILE_64x64, mt == 4 ? 4 : 3, s);
+  if (mt == 4)
+    hipLaunchKernelGGL(wino43_in_k, dim3(grid_for(T * C4)), dim3(256), 0, s, d->x, d->V, d->H, d->W, C4, th, tw, T, T * C4);
+  else
+    hipLaunchKernelGGL(wino_in_k, dim3(grid_for(T * C4)), dim3(256), 0, s, d->x, d->V, d->H, d->W, C4, th, tw, T, T * C4);
   int rc = ymi_launch_status();
   if (rc) return rc;
   ymi_conv_desc g = {};
@@ -223,20 +383,28 @@ extern "C" int ymi_conv3x3_winograd_f32(const ymi_wino_desc *d, void *stream) {
   g.seg[0].n0 = 0; g.seg[0].n1 = Ng; g.seg[0].act = YMI_ACT_NONE; g.seg[0].row_stride = Ng;
   g.seg[0].batch_stride = T * Ng; g.seg[0].ptr = d->M;
   const long cout_pad = ((long)d->Cout + 127) / 128 * 128;
-  rc = ymi_internal_grouped_gemm(&g, 16, T * d->C, cout_pad * d->C, T * Ng, exe, 5 /* kind: winograd GEMM */, s);
+  rc = ymi_internal_grouped_gemm(&g, ng, T * d->C, cout_pad * d->C, T * Ng, exe, mt == 4 ? 6 : 5 /* kind: winograd GEMM */, s);
   if (rc) return rc;
   if (d->nseg > 0) {
     SegTab st;
     st.nseg = d->nseg;
     for (int k = 0; k < 3; ++k) st.seg[k] = d->seg[k];
-    hipLaunchKernelGGL(wino_out_seg_k, dim3(grid_for(T * N4)), dim3(256), 0, s, d->M, st, d->scale, d->bias, d->H, d->W, N4,
-                       d->Cout, th, tw, T, T * N4);
+    if (mt == 4)
+      hipLaunchKernelGGL(wino43_out_seg_k, dim3(grid_for(T * N4)), dim3(256), 0, s, d->M, st, d->scale, d->bias, d->H, d->W,
+                         N4, d->Cout, th, tw, T, T * N4);
+    else
+      hipLaunchKernelGGL(wino_out_seg_k, dim3(grid_for(T * N4)), dim3(256), 0, s, d->M, st, d->scale, d->bias, d->H, d->W, N4,
+                         d->Cout, th, tw, T, T * N4);
     rc = ymi_launch_status();
     ymi_internal_prof_end(outer, s);
     return rc;
   }
-  hipLaunchKernelGGL(wino_out_k, dim3(grid_for(T * N4)), dim3(256), 0, s, d->M, d->y, d->scale, d->bias, d->H, d->W, N4, th,
-                     tw, T, d->act, T * N4);
+  if (mt == 4)
+    hipLaunchKernelGGL(wino43_out_k, dim3(grid_for(T * N4)), dim3(256), 0, s, d->M, d->y, d->scale, d->bias, d->H, d->W, N4, th,
+                       tw, T, d->act, T * N4);
+  else
+    hipLaunchKernelGGL(wino_out_k, dim3(grid_for(T * N4)), dim3(256), 0, s, d->M, d->y, d->scale, d->bias, d->H, d->W, N4, th,
+                       tw, T, d->act, T * N4);
   rc = ymi_launch_status();
   ymi_internal_prof_end(outer, s);
   return rc;

@@ -58,17 +58,23 @@ class Packed:
 
 
 class WinoPacked:
-    """Winograd F(2x2,3x3) filters U = G g G^T, layout [16][CoutPad][C] (csrc/winograd.hip), computed in fp64."""
+    """Winograd filters U = G g G^T in fp64 -> fp32, layout [(m+2)^2][CoutPad][C] (csrc/winograd.hip); m = 2: F(2x2,3x3),
+    m = 4: F(4x4,3x3) (matrices of Lavin & Gray, interpolation points 0, +-1, +-2, inf)."""
 
-    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
+    G2 = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
+    G4 = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
+                       [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=torch.float64)
 
-    def __init__(self, weight, device):
+    def __init__(self, weight, device, m=2):
         w = weight.detach().to(torch.float64).cpu()                 # [Cout, Cin, 3, 3]
         Cout, Cin = w.shape[:2]
-        u = torch.einsum('ai,ncij,bj->abnc', self.G, w, self.G)      # [4,4,Cout,Cin]
+        G = self.G4 if m == 4 else self.G2
+        a = m + 2
+        u = torch.einsum('ai,ncij,bj->abnc', G, w, G)                # [a,a,Cout,Cin]
+        self.m = m
         self.CoutPad = _ceil(Cout, 128)
-        up = torch.zeros(16, self.CoutPad, Cin, dtype=torch.float32)
-        up[:, :Cout] = u.reshape(16, Cout, Cin).to(torch.float32)
+        up = torch.zeros(a * a, self.CoutPad, Cin, dtype=torch.float32)
+        up[:, :Cout] = u.reshape(a * a, Cout, Cin).to(torch.float32)
         self.u = up.to(device).contiguous()
 
 
@@ -154,7 +160,10 @@ class Plan:
                                  # is what per-kernel timing (bench.py's roofline pass) needs
         self.events = {}
         self._cur = 'A'
-        self.use_winograd = device.type == 'cuda' and os.environ.get('YOLACT_AMD_WINOGRAD', '1') != '0'
+        # YOLACT_AMD_WINOGRAD: 0 = direct kernels only, 2 = F(2x2,3x3) only, 4 = F(4x4,3x3) only, default both (autotuned)
+        wsel = os.environ.get('YOLACT_AMD_WINOGRAD', '1')
+        self.use_winograd = device.type == 'cuda' and wsel != '0'
+        self.wino_variants = (2,) if wsel == '2' else (4,) if wsel == '4' else (2, 4)
         self.wino_alt, self._wino_packed, self._wino_ws = {}, {}, {}
         self._build()
         self._bind_wino_workspaces()
@@ -209,7 +218,8 @@ class Plan:
         wino = None
         if (self.use_winograd and dcn_offmask is None and out is None and pk.weight_oihw is not None
                 and wino_eligible(pk, res, segs, act, x.C)):
-            wino = self._wino_op(x, pk, act, y, name, segs)
+            wino = [w for w in (self._wino_op(x, pk, act, y, name, segs, m) for m in self.wino_variants) if w is not None]
+            wino = wino or None
         if dcn_offmask is not None:
             dd = L.DcnDesc()
             dd.conv = d
@@ -223,18 +233,19 @@ class Plan:
                 self.wino_alt[len(self.ops) - 1] = wino      # op index -> alternative; autotune picks the faster one
         return y
 
-    def _wino_op(self, x: T, pk: Packed, act, y: Optional[T], name, segs=None):
+    def _wino_op(self, x: T, pk: Packed, act, y: Optional[T], name, segs=None, m=2):
         """Winograd alternative of a 3x3 / stride-1 conv: descriptor + per-stream workspaces (V, M)."""
-        key = id(pk)
+        key = (id(pk), m)
         wp = self._wino_packed.get(key)
         if wp is None:
-            wp = self._wino_packed[key] = WinoPacked(pk.weight_oihw, self.device)
-        th, tw = (x.H + 1) // 2, (x.W + 1) // 2
+            wp = self._wino_packed[key] = WinoPacked(pk.weight_oihw, self.device, m)
+        th, tw = (x.H + m - 1) // m, (x.W + m - 1) // m
         Tn = x.B * th * tw
         Ng = _ceil(pk.Cout, 4)
         if Tn * max(pk.Cin, Ng) >= (1 << 29):
             return None
-        need_v, need_m = 16 * Tn * pk.Cin, 16 * Tn * Ng
+        g = (m + 2) * (m + 2)
+        need_v, need_m = g * Tn * pk.Cin, g * Tn * Ng
         ws = self._wino_ws.setdefault(self._cur, [None, None])
         if ws[0] is None or ws[0].numel() < need_v:
             ws[0] = torch.empty(need_v, dtype=torch.float32, device=self.device)
@@ -250,14 +261,15 @@ class Plan:
                 d.seg[i] = L.ConvSeg(*s)
         d.scale = pk.scale.data_ptr() if pk.scale is not None else None
         d.bias = pk.bias.data_ptr() if pk.bias is not None else None
-        d.B, d.H, d.W, d.C, d.Cout, d.act, d.tile = x.B, x.H, x.W, pk.Cin, pk.Cout, act, L.TILE_AUTO
+        d.B, d.H, d.W, d.C, d.Cout, d.act, d.tile, d.m = x.B, x.H, x.W, pk.Cin, pk.Cout, act, L.TILE_AUTO, m
         return d
 
     def _bind_wino_workspaces(self):
         """Workspaces may have been re-allocated (grown) while the plan was built: point every descriptor at the final ones."""
-        for idx, d in self.wino_alt.items():
+        for idx, alts in self.wino_alt.items():
             ws = self._wino_ws[self.ops[idx][3]]
-            d.V, d.M = ws[0].data_ptr(), ws[1].data_ptr()
+            for d in alts:
+                d.V, d.M = ws[0].data_ptr(), ws[1].data_ptr()
 
     def call(self, fn, *args, name=''):
         self.ops.append((fn, args, name, self._cur))
@@ -627,11 +639,12 @@ class Plan:
         wtiles = [L.TILE_64x64, L.TILE_64x128, L.TILE_128x64, L.TILE_128x128_W8, L.TILE_64x128_S3, L.TILE_32x64_K2]
         memo = {}
         self.wino_table = []
-        for idx, wd in sorted(self.wino_alt.items()):
+        for idx, alts in sorted(self.wino_alt.items()):
             fn, dptr, name, where = self.ops[idx]
             if fn is not lib.ymi_conv2d_nhwc_f32:
                 continue
-            key = 'wino' + str((wd.B, wd.H, wd.W, wd.C, wd.Cout, wd.act, wd.nseg))
+            w0 = alts[0]
+            key = 'wino' + str((w0.B, w0.H, w0.W, w0.C, w0.Cout, w0.act, w0.nseg, tuple(a.m for a in alts)))
             if key in disk:
                 memo[key] = tuple(disk[key])
             if key not in memo:
@@ -647,19 +660,23 @@ class Plan:
                         best = min(best, e0.elapsed_time(e1) / reps)
                     return best
                 t_direct = timed(fn, dptr)
-                best_t, best_ms = 0, 1e30
-                for t in wtiles:
-                    wd.tile = t
-                    if lib.ymi_conv3x3_winograd_f32(C.byref(wd), s) != 0:
-                        continue
-                    ms = timed(lib.ymi_conv3x3_winograd_f32, C.pointer(wd))
-                    if ms < best_ms:
-                        best_t, best_ms = t, ms
-                memo[key] = (best_t, round(t_direct, 4), round(best_ms, 4))
+                best_m, best_t, best_ms, per_m = 0, 0, 1e30, {}
+                for wd in alts:
+                    for t in wtiles:
+                        wd.tile = t
+                        if lib.ymi_conv3x3_winograd_f32(C.byref(wd), s) != 0:
+                            continue
+                        ms = timed(lib.ymi_conv3x3_winograd_f32, C.pointer(wd))
+                        per_m[wd.m] = min(ms, per_m.get(wd.m, 1e30))
+                        if ms < best_ms:
+                            best_m, best_t, best_ms = wd.m, t, ms
+                memo[key] = (best_m, best_t, round(t_direct, 4), round(best_ms, 4),
+                             round(per_m.get(2, 0.0), 4), round(per_m.get(4, 0.0), 4))
                 disk[key] = list(memo[key])
-            best_t, t_direct, t_wino = memo[key]
-            self.wino_table.append((name, L.TILE_NAMES.get(best_t, '-'), t_direct, t_wino))
+            best_m, best_t, t_direct, t_wino, t_f2, t_f4 = memo[key]
+            self.wino_table.append((name, 'F%d/%s' % (best_m, L.TILE_NAMES.get(best_t, '-')), t_direct, t_wino, t_f2, t_f4))
             if best_t and t_wino < 0.97 * t_direct:
+                wd = [a for a in alts if a.m == best_m][0]
                 wd.tile = best_t
                 self.ops[idx] = (lib.ymi_conv3x3_winograd_f32, C.pointer(wd), name + '[wino]', where)
         if cache_path and self.wino_table:
