@@ -111,6 +111,12 @@ def roofline(net, x, reps=3):
                               'every conv-layer launch incl. the Winograd transforms; of %d layers %d run Winograd '
                               'F(2x2,3x3) (2.25x fewer multiplications) and %d F(4x4,3x3) (4x fewer), so this figure '
                               'can exceed what the matrix cores execute' % (len(layers), wino2, wino4)},
+        'engine': {'kernel': 'conv_igemm_f32<*> (every instantiation: direct loaders + grouped Winograd GEMM)',
+                   'ms_per_step': round(sum(v[0] for v in by_kernel.values()) / reps, 3),
+                   'executed_tflops': round(sum(v[1] for v in by_kernel.values()) / (sum(v[0] for v in by_kernel.values()) * 1e-3) / 1e12, 2),
+                   'frac': round(sum(v[1] for v in by_kernel.values()) / (sum(v[0] for v in by_kernel.values()) * 1e-3) / 1e12
+                                 / FP32_MFMA_PEAK_TFLOPS, 4),
+                   'basis': 'FLOPs executed on the matrix cores by all GEMM launches of a step / their summed durations'},
         'per_kernel': detail,
     }, layers
 

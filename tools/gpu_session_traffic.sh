@@ -3,7 +3,7 @@
 O=gpurun_out/traffic; mkdir -p $O
 export TMPDIR=/tmp YOLACT_AMD_TUNE_CACHE=$PWD/$O/tune.json YOLACT_AMD_STREAMS=1
 R=$GRAFT_REPO_ROOT
-cp profiles/r01_tune_v8.json $O/tune.json      # the tile / Winograd choices of the committed bench run
+cp profiles/r01_tune_v9.json $O/tune.json      # the tile / Winograd choices of the committed bench run
 CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline"
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex conv_igemm -f csv -d $R/$O/fetch -- bash -c "cd $R && $CMD" > $R/$O/fetch.log 2>&1)
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --kernel-include-regex conv_igemm -f csv -d $R/$O/write -- bash -c "cd $R && $CMD" > $R/$O/write.log 2>&1)
