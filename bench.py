@@ -48,6 +48,7 @@ def roofline(net, x, reps=3):
     lib = L.lib()
     split = os.environ.get('YOLACT_AMD_BATCH_SPLIT')
     os.environ['YOLACT_AMD_BATCH_SPLIT'] = '1'      # per-kernel pass: one full-batch plan, serialised
+    graph = os.environ.pop('YOLACT_AMD_GRAPH', None)  # ... launched eagerly (a replayed hipGraph records no events)
     plan = net.plan_for(x)
     names = [n for n, _ in plan.conv_meta]
     # The timed region overlaps the small P4..P7 / Detect kernels with the P3 branch on a second HIP stream; kernels
@@ -63,6 +64,8 @@ def roofline(net, x, reps=3):
     plan.overlap = True
     if split is not None:
         os.environ['YOLACT_AMD_BATCH_SPLIT'] = split
+    if graph is not None:
+        os.environ['YOLACT_AMD_GRAPH'] = graph
     n = lib.ymi_prof_count()
     ms, fl, tile, kind = C.c_float(), C.c_double(), C.c_int32(), C.c_int32()
     # record kinds: 0/1/2 = one direct conv launch (loader id); 3 / 4 = a whole Winograd F(2x2) / F(4x4) layer (input

@@ -204,10 +204,38 @@ class Yolact(nn.Module):
 
     def _forward_device_one(self, x, slot=0):
         plan = self.plan_for(x, slot)
+        if os.environ.get('YOLACT_AMD_GRAPH', '0') == '1':
+            return self._forward_device_graph(plan, x, slot)
         proto, out = plan.run(x, detect=lambda s: self.detect.run_device(
             plan.loc, plan.conf, plan.coef, plan.priors, True, stream=s, slot=slot))
         out['proto'] = proto
         return out
+
+    def _forward_device_graph(self, plan, x, slot):
+        """YOLACT_AMD_GRAPH=1: the whole op list of the plan (both streams, ~190 launches incl. Detect) is captured once
+        into a hipGraph and replayed per batch — one submission instead of ~190 launches, which is what bounds small
+        batches (batch 1: the GPU idles between 10-20 us kernels while Python issues the next one).  The graph owns a
+        static input and static outputs; every call copies x in and clones the results out, so returned tensors keep
+        the eager path's lifetime rules."""
+        key = ('graph', tuple(x.shape), x.device, slot)
+        rec = self._plans.get(key)
+        if rec is None:
+            def body(inp):
+                proto, out = plan.run(inp, detect=lambda s: self.detect.run_device(
+                    plan.loc, plan.conf, plan.coef, plan.priors, True, stream=s, slot=slot))
+                out['proto'] = proto
+                return out
+            static_x = x.clone()
+            body(static_x)                                   # eager warm-up: workspaces, lazy module state
+            torch.cuda.synchronize(x.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = body(static_x)
+            rec = self._plans[key] = (graph, static_x, static_out)
+        graph, static_x, static_out = rec
+        static_x.copy_(x)
+        graph.replay()
+        return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in static_out.items()}
 
     def forward_device(self, x):
         """Forward + Detect with NO host synchronisation: fixed-capacity device tensors
