@@ -46,8 +46,6 @@ def roofline(net, x, reps=3):
     """Per-launch HIP-event timing of every conv launch (events recorded on the launch stream by the library)."""
     from yolact_amd import _lib as L
     lib = L.lib()
-    split = os.environ.get('YOLACT_AMD_BATCH_SPLIT')
-    os.environ['YOLACT_AMD_BATCH_SPLIT'] = '1'      # per-kernel pass: one full-batch plan, serialised
     graph = os.environ.pop('YOLACT_AMD_GRAPH', None)  # ... launched eagerly (a replayed hipGraph records no events)
     plan = net.plan_for(x)
     names = [n for n, _ in plan.conv_meta]
@@ -62,8 +60,6 @@ def roofline(net, x, reps=3):
     torch.cuda.synchronize()
     lib.ymi_prof_enable(0)
     plan.overlap = True
-    if split is not None:
-        os.environ['YOLACT_AMD_BATCH_SPLIT'] = split
     if graph is not None:
         os.environ['YOLACT_AMD_GRAPH'] = graph
     n = lib.ymi_prof_count()

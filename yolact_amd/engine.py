@@ -164,6 +164,7 @@ class Plan:
         wsel = os.environ.get('YOLACT_AMD_WINOGRAD', '1')
         self.use_winograd = device.type == 'cuda' and wsel != '0'
         self.wino_variants = (2,) if wsel == '2' else (4,) if wsel == '4' else (2, 4)
+        self.down_on_side_stream = os.environ.get('YOLACT_AMD_DOWN_STREAM', 'B') == 'B'      # measured +1 %
         self.wino_alt, self._wino_packed, self._wino_ws = {}, {}, {}
         self._build()
         self._bind_wino_workspaces()
@@ -388,31 +389,20 @@ class Plan:
         self.on('A')
         p3 = pred(0)
         self.free(sums[0])
-        self.record('p3')
-        split_p3_head = os.environ.get('YOLACT_AMD_HEAD0_STREAM', 'A') == 'B'   # measured: 862 (B) vs 877 (A) images/s
         self.on('B')
         feats_b = [pred(j) for j in range(1, n)]
         for j in range(1, n):
             self.free(sums[j])
         for i, m in enumerate(fpn.downsample_layers):
             feats_b.append(self.conv('fpn.down%d' % i, feats_b[-1], pack_module(m, device=dev)))
-        if split_p3_head and self.two_streams:
-            # the P3 head (0.9 ms) also goes to B: A keeps only the protonet chain, and the two streams' big kernels
-            # fill each other's tails.  P3 is then read by both streams, so its buffer is never recycled.
-            for lvl in range(1, nlev):
-                head(lvl, feats_b[lvl - 1])
-            self.wait('p3')
-            head(0, p3)
-            p3_shared = True
-        else:
-            self.on('A')
-            head(0, p3)
-            self.record('head0')
-            self.on('B')
-            for lvl in range(1, nlev):
-                head(lvl, feats_b[lvl - 1])
-            self.wait('head0')
-            p3_shared = False
+        # the P3 head stays on A (moving it to B as well measured 862 vs 877 images/s)
+        self.on('A')
+        head(0, p3)
+        self.record('head0')
+        self.on('B')
+        for lvl in range(1, nlev):
+            head(lvl, feats_b[lvl - 1])
+        self.wait('head0')
         for f in feats_b:
             self.free(f)
         self.ops.append(('detect', None, 'detect', self._cur))
@@ -443,8 +433,7 @@ class Plan:
                     nt = None
                 else:
                     nt = self.conv('proto.%d' % i, t, pk, act=a)
-                if not (t is p3 and p3_shared):
-                    self.free(t)
+                self.free(t)
                 t = nt
             elif isinstance(m, M.InterpolateModule):
                 s = int(m.scale_factor)
@@ -471,6 +460,16 @@ class Plan:
         for li, layer in enumerate(bb.layers):
             for bi, blk in enumerate(layer):
                 nm = 'layer%d.%d' % (li, bi)
+                side_down = blk.downsample is not None and self.two_streams and self.down_on_side_stream
+                if side_down:
+                    # the projection shortcut only depends on the block input: run it on the side stream while A does
+                    # conv1 / conv2 (fills their tails); A picks it up before conv3
+                    self.record(nm + '.in')
+                    self.on('B')
+                    self.wait(nm + '.in')
+                    res = self.conv(nm + '.down', x, pack_module(blk.downsample[0], blk.downsample[1], dev))
+                    self.record(nm + '.down')
+                    self.on('A')
                 o1 = self.conv(nm + '.conv1', x, pack_module(blk.conv1, blk.bn1, dev), act=L.ACT_RELU)
                 if blk.use_dcn:
                     dcn = blk.conv2
@@ -481,14 +480,20 @@ class Plan:
                 else:
                     o2 = self.conv(nm + '.conv2', o1, pack_module(blk.conv2, blk.bn2, dev), act=L.ACT_RELU)
                 ar.free(o1)
-                if blk.downsample is not None:
+                if side_down:
+                    self.wait(nm + '.down')
+                elif blk.downsample is not None:
                     res = self.conv(nm + '.down', x, pack_module(blk.downsample[0], blk.downsample[1], dev))
                 else:
                     res = x
                 y = self.conv(nm + '.conv3', o2, pack_module(blk.conv3, blk.bn3, dev), act=L.ACT_RELU, res=res,
                               res_mode=L.RES_ADD)
                 ar.free(o2)
-                if res is not x:
+                if side_down:
+                    self.on('B')          # back to the side stream's pool: its next op waits for a later event of A
+                    self.free(res)
+                    self.on('A')
+                elif res is not x:
                     ar.free(res)
                 ar.free(x)
                 x = y

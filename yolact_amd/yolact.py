@@ -240,30 +240,11 @@ class Yolact(nn.Module):
     def forward_device(self, x):
         """Forward + Detect with NO host synchronisation: fixed-capacity device tensors
         (count [B], box [B,cap,4], score, cls, coef, prior) + 'proto'. Used by the data-parallel path
-        (yolact_amd.parallel) and by throughput runs that keep results on the GPU.
-
-        YOLACT_AMD_BATCH_SPLIT=2 (experimental): the batch is run as two half-batches on two HIP streams, so each
-        half's kernel tails / prologues overlap the other half's kernels (images are independent in eval mode)."""
+        (yolact_amd.parallel) and by throughput runs that keep results on the GPU."""
         L.require_cuda(x, 'input batch')
         x = x.detach().to(torch.float32).contiguous()
         with torch.cuda.device(x.device):
-            B = x.shape[0]
-            if os.environ.get('YOLACT_AMD_BATCH_SPLIT', '1') != '2' or B < 4 or B % 2:
-                return self._forward_device_one(x)
-            if not hasattr(self, '_split_streams'):
-                self._split_streams = [torch.cuda.Stream(device=x.device) for _ in range(2)]
-                self._split_events = [torch.cuda.Event() for _ in range(3)]
-            cur = torch.cuda.current_stream(x.device)
-            self._split_events[2].record(cur)
-            halves = []
-            for i, st in enumerate(self._split_streams):
-                st.wait_event(self._split_events[2])
-                with torch.cuda.stream(st):
-                    halves.append(self._forward_device_one(x[i * (B // 2):(i + 1) * (B // 2)].contiguous(), slot=i))
-                    self._split_events[i].record(st)
-            for i in range(2):
-                cur.wait_event(self._split_events[i])
-            return {k: torch.cat([h[k] for h in halves], 0) for k in halves[0] if k != '_keepalive'}
+            return self._forward_device_one(x)
 
     def forward_raw(self, x):
         """Head outputs before Detect (for parity tests): loc, conf (logits), mask, priors, proto — clones."""
