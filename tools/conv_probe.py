@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Time representative YOLACT conv shapes through the C ABI: every tile shape x ablation mask (YMI_ABLATE).
+"""Time representative YOLACT conv shapes through the C ABI: every tile shape x ablation mask (YMI_ABLATE; needs the
+diagnostics build: make -C yolact_amd/csrc clean all DIAG=1 — the product build ignores the variable).
 
     python tools/conv_probe.py [--ablate 0,1,3,7] [--reps 20]
 

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Time Detect (3 kernels) on the dense R50 batch-8 head outputs, with ablations of K2 (YMI_DETECT_ABLATE)."""
+"""Time Detect (3 kernels) on the dense R50 batch-8 head outputs, with ablations of K2 (YMI_DETECT_ABLATE; needs the
+diagnostics build: make -C yolact_amd/csrc clean all DIAG=1)."""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

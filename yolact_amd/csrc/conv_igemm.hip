@@ -799,7 +799,10 @@ int run_conv(const ymi_conv_desc *d, int loader, const float *offmask, int ldo, 
   kp.offmask = offmask;
   kp.ldo = ldo;
   kp.x_gs = x_gs; kp.w_gs = w_gs; kp.y_gs = y_gs;
+  kp.abl = 0;
+#ifdef YMI_DIAGNOSTICS   // `make DIAG=1`: ablation switches for tools/conv_probe.py — they produce WRONG results by design
   { const char *e = getenv("YMI_ABLATE"); kp.abl = e ? atoi(e) : 0; }
+#endif
   kp.trace = g_trace;
   int tile = d->tile ? d->tile : pick_tile(d);
   if (loader != 0 && !tile_all_loaders(tile)) {

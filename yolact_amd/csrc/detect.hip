@@ -410,7 +410,9 @@ extern "C" int ymi_detect_f32(const ymi_detect_desc *d, void *stream) {
   if (rc) return rc;
   const int nclass = d->cross_class ? 1 : nfg;
   int dbg = 0;   // diagnostics only (env YMI_DETECT_ABLATE): bit0 skip selection, bit2 skip the IoU triangle
+#ifdef YMI_DIAGNOSTICS   // `make DIAG=1` only (tools/detect_probe.py): wrong results by design
   { const char *e = getenv("YMI_DETECT_ABLATE"); if (e) dbg = atoi(e); }
+#endif
   const float *sc = d->cross_class ? d->maxsc : d->scores_t;
 #define YMI_K2(EPT, NTH)                                                                                             \
   hipLaunchKernelGGL((class_topk_nms_k<EPT, NTH>), dim3(nclass, d->B), dim3(NTH), 0, s, sc, d->keep, d->num_keep, d->loc, \
