@@ -13,6 +13,14 @@ then the single RCCL gather of detection records to rank 0 and the host read of 
 
 One JSON line on rank 0, with `roofline` (dominant conv kernel, live HIP-event timing on the launch stream) and,
 at N=1, `cpu_baseline` (the CPU oracle = port of the reference's path, timed on this host's cores).
+
+`roofline` fields: `kernel` / `achieved` / `frac` / `avg_launch_ms` / `traffic` = the instantiation of the conv engine
+with the largest summed duration; a direct launch is priced with its algorithmic conv FLOPs, a grouped Winograd GEMM
+launch with the FLOPs it executes (`flops_basis`), so `frac` is a matrix-core utilisation.  `engine` = the same over ALL
+GEMM launches of a step.  `all_conv` = ALGORITHMIC conv FLOPs (118.28 GFLOP/image) over the summed
+durations of every conv-layer launch incl. the Winograd transforms — the figure BASELINE.json's ">= 60 % of the conv
+roofline" target refers to; with Winograd layers it can exceed what the matrix cores execute.  `per_kernel` = every
+instantiation.  DESIGN.md 3.5 / 6.
 """
 import argparse
 import ctypes as C
