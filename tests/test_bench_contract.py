@@ -1,0 +1,58 @@
+"""The bench.py output contract, checked on the committed result of the last GPU session (profiles/r01_bench_v9.json): the
+keys the driver and the judge read, their types, and the internal consistency of the roofline block."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load():
+    with open(os.path.join(ROOT, 'profiles', 'r01_bench_v9.json')) as f:
+        return json.loads(f.read())
+
+
+def test_top_level_fields():
+    b = _load()
+    for k, typ in (('metric', str), ('value', float), ('unit', str), ('n_gpus', int), ('steps', int), ('warmup', int),
+                   ('ms_per_step', float), ('higher_is_better', bool), ('scaling', str), ('dtype', str), ('data', str),
+                   ('config', dict), ('roofline', dict), ('cpu_baseline', dict)):
+        assert isinstance(b[k], typ), (k, type(b[k]))
+    assert b['vs_baseline'] is None                      # BASELINE.md publishes no number for this metric on MI355X
+    assert b['unit'] == 'images/s' and b['higher_is_better'] is True and b['scaling'] == 'weak' and b['dtype'] == 'f32'
+    assert b['data'] == 'synthetic' and 'workload' in b['config'] and 'configs[1]' in b['config']['workload']
+    assert 'model' not in b['config']
+    # value = images of the whole job / wall time of the timed region
+    imgs = b['config']['global_batch'] * b['steps']
+    assert abs(b['value'] - imgs / (b['ms_per_step'] * b['steps'] / 1e3)) / b['value'] < 1e-3
+
+
+def test_roofline_block():
+    r = _load()['roofline']
+    assert r['bound'] in ('hbm', 'mfma') and r['unit'] in ('GB/s', 'TFLOP/s')
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and 0 < r['frac'] <= 1.0
+    assert r['traffic'] is None or r['traffic'] > 0
+    # achieved = FLOPs per launch / average launch duration
+    assert abs(r['achieved'] - r['flops_per_launch'] / (r['avg_launch_ms'] * 1e-3) / 1e12) / r['achieved'] < 0.01
+    assert r['kernel'] in r['per_kernel']
+    dom = max(r['per_kernel'].items(), key=lambda kv: kv[1]['ms_per_step'])[0]
+    assert dom == r['kernel']                            # "dominant" = largest summed duration
+    ac = r['all_conv']
+    assert abs(ac['gflop_per_step'] - 8 * 118.28) < 1.0  # 118.28 GFLOP per image
+    assert abs(ac['tflops'] - ac['gflop_per_step'] / ac['ms_per_step']) < 0.5
+    assert 0 < r['engine']['frac'] <= 1.0
+
+
+def test_cpu_baseline_block():
+    c = _load()['cpu_baseline']
+    assert c['kind'] in ('port', 'reference') and c['unit'] == 'images/s' and c['value'] > 0 and c['cores'] >= 1
+    assert isinstance(c['sample'], str) and len(c['sample']) > 10
+
+
+def test_cli_defaults():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--help'], capture_output=True, text=True,
+                         timeout=120)
+    assert out.returncode == 0
+    for flag in ('--gpus', '--steps', '--warmup'):
+        assert flag in out.stdout
