@@ -1,0 +1,144 @@
+"""Static race check of the two-stream execution plan (engine.Plan) — no GPU needed.
+
+The plan is a flat op list with fork / join markers ('record' / 'wait' of named events) and two buffer pools.  Two HIP
+streams only order their work through those events, so every pair of ops on DIFFERENT streams that touch the same
+device buffer (at least one writing) must be ordered by a record -> wait chain, including the recycled arena buffers and
+the hand-placed pool transfers (the projection shortcut computed on the side stream and consumed on the main one).
+The check replays the op list with vector clocks and reports unordered conflicting pairs; it also checks the invariants
+that make consecutive iterations safe: the side stream's first op waits on an event of the main stream, and the main
+stream has joined ALL side-stream work when the plan ends.
+"""
+import pytest
+import torch
+
+from yolact_amd import _lib as L
+
+
+def _make_net(config):
+    import yolact_amd
+    yolact_amd.set_cfg(config)
+    from yolact_amd.yolact import Yolact
+    return Yolact()
+
+
+def _buffers(plan):
+    """(base, bytes, label) of every allocation the ops may touch."""
+    out = []
+    for label, ar in (('arenaA', plan.arena), ('arenaB', getattr(plan, 'arena_b', None))):
+        if ar is not None:
+            out += [(b.data_ptr(), b.numel() * 4, '%s[%d]' % (label, i)) for i, b in enumerate(ar.all)]
+    for label in ('loc', 'conf', 'coef'):
+        t = getattr(plan, label)
+        out.append((t.data_ptr(), t.numel() * 4, label))
+    return out
+
+
+def _owner(bufs, ptr):
+    """(label, sub): arena buffers are used whole (sub None); the persistent head tensors loc / conf / coef are written
+    level by level — [B, P, k] rows starting at the level's prior offset — so a write is keyed by that offset and only
+    conflicts with the same level or with a reader of the whole tensor (Detect)."""
+    if not ptr:
+        return None                                   # the per-call proto output: fresh memory every run
+    hits = [(lab, base) for base, size, lab in bufs if base <= ptr < base + max(size, 1)]
+    assert len(hits) == 1, (ptr, hits)
+    lab, base = hits[0]
+    return (lab, ptr - base) if lab in ('loc', 'conf', 'coef') else (lab, None)
+
+
+def _conflict(a, b):
+    return a[0] == b[0] and (a[1] is None or b[1] is None or a[1] == b[1])
+
+
+def _accesses(plan, op, bufs):
+    """(reads, writes) as buffer labels."""
+    fn, args, name, where = op
+    lib = plan.lib
+    if fn == 'input':
+        return set(), {_owner(bufs, plan.in_args[1])}
+    if fn == 'detect':
+        return {('loc', None), ('conf', None), ('coef', None)}, set()
+    if fn is lib.ymi_dcn_v2_forward_f32:
+        dd = args.contents
+        d, extra = dd.conv, [dd.offmask]
+    elif fn is lib.ymi_conv2d_nhwc_f32:
+        d, extra = args.contents, []
+    else:                                             # layout / pool / resize calls: (src, dst, ...)
+        assert isinstance(args, tuple), name
+        return {_owner(bufs, args[0])}, {_owner(bufs, args[1])}
+    reads = {_owner(bufs, d.x)} | {_owner(bufs, e) for e in extra}
+    if d.res_mode != L.RES_NONE:
+        reads.add(_owner(bufs, d.res))
+    writes = {_owner(bufs, d.seg[i].ptr) for i in range(d.nseg)}
+    return reads - {None}, writes - {None}
+
+
+def check_schedule(plan):
+    bufs = _buffers(plan)
+    pos = {'A': 0, 'B': 0}                             # ops issued so far per stream
+    know = {'A': 0, 'B': 0}                            # ops of the OTHER stream known complete before the next op starts
+    events, trace, problems = {}, [], []
+    b_synced = False                                   # has B waited on an event of A yet?
+    last_b_burst_ok = True
+    for op in plan.ops:
+        fn, args, name, where = op
+        other = 'B' if where == 'A' else 'A'
+        if fn == 'record':
+            events[args] = (where, pos[where])
+            continue
+        if fn == 'wait':
+            src, p = events[args]                      # KeyError = wait before record: a bug in itself
+            if src == other:
+                know[where] = max(know[where], p)
+                if where == 'B':
+                    b_synced = True
+            continue
+        if where == 'B' and pos['B'] == 0 and not b_synced:
+            # iteration n+1's side-stream work must start behind a point of the main stream that itself follows the
+            # join of iteration n (the main stream's program order provides the rest)
+            last_b_burst_ok = False
+            problems.append('the first side-stream op (%s) does not wait on the main stream' % name)
+        pos[where] += 1
+        r, w = _accesses(plan, op, bufs)
+        trace.append((where, pos[where], know[where], name, r, w))
+    for i, (s1, i1, k1, n1, r1, w1) in enumerate(trace):
+        for (s2, i2, k2, n2, r2, w2) in trace[i + 1:]:
+            if s1 == s2:
+                continue
+            shared = [x for x in w1 for y in (r2 | w2) if _conflict(x, y)] + [x for x in w2 for y in r1 if _conflict(x, y)]
+            if shared and not (k2 >= i1 or k1 >= i2):
+                problems.append('%s (%s#%d) and %s (%s#%d) both touch %s without an event between them'
+                                % (n1, s1, i1, n2, s2, i2, sorted(set(x[0] for x in shared))))
+    if know['A'] != pos['B']:
+        problems.append('plan ends with %d of %d side-stream ops joined' % (know['A'], pos['B']))
+    return problems, pos, last_b_burst_ok
+
+
+@pytest.mark.parametrize('config,size', [('yolact_resnet50_config', 550), ('yolact_base_config', 550),
+                                         ('yolact_darknet53_config', 550), ('yolact_im700_config', 700),
+                                         ('yolact_plus_resnet50_config', 550)])
+def test_two_stream_plan_is_race_free(config, size):
+    from yolact_amd.engine import Plan
+    net = _make_net(config)
+    plan = Plan(net, 2, size, size, torch.device('cpu'), dry_two_streams=True)
+    problems, pos, _ = check_schedule(plan)
+    assert not problems, problems[:5]
+    assert pos['B'] > 8 and pos['A'] > 40               # both streams carry work (P4..P7 + Detect vs the rest)
+    if 'resnet' in config or 'base' in config or 'im700' in config:
+        assert any(n.endswith('.down') and w == 'B' for _, _, n, w in plan.ops), 'projection shortcuts on the side stream'
+
+
+def test_checker_catches_a_missing_wait():
+    """Remove the wait that orders conv3 behind the side-stream shortcut: the checker must flag that pair."""
+    from yolact_amd.engine import Plan
+    plan = Plan(_make_net('yolact_resnet50_config'), 1, 550, 550, torch.device('cpu'), dry_two_streams=True)
+    idx = [i for i, op in enumerate(plan.ops) if op[0] == 'wait' and op[1] == 'layer1.0.down']
+    assert len(idx) == 1
+    del plan.ops[idx[0]]
+    problems, _, _ = check_schedule(plan)
+    assert any('layer1.0.down' in p and 'layer1.0.conv3' in p for p in problems), problems[:3]
+
+
+def test_single_stream_plan_has_no_markers():
+    from yolact_amd.engine import Plan
+    plan = Plan(_make_net('yolact_resnet50_config'), 1, 550, 550, torch.device('cpu'))
+    assert all(op[0] not in ('record', 'wait') and op[3] == 'A' for op in plan.ops)

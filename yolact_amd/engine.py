@@ -144,7 +144,10 @@ def out_size(n, k, s, p):
 
 
 class Plan:
-    def __init__(self, net, B, H, W, device):
+    def __init__(self, net, B, H, W, device, dry_two_streams=False):
+        """`dry_two_streams`: emit the two-stream op list (fork / join markers, per-stream arenas) without creating HIP
+        streams or events — for static checks of the schedule on a machine without a GPU (tests/test_plan_schedule.py);
+        such a plan cannot be run."""
         self.net, self.B, self.H, self.W, self.device = net, B, H, W, device
         self.ops = []          # (callable, args...) executed in order
         self.conv_meta = []    # (name, desc) for profiling / roofline accounting
@@ -154,8 +157,8 @@ class Plan:
         # Two HIP streams: A = the caller's current stream (backbone, P3 branch, protonet), B = a side stream for the
         # small P4..P7 FPN/head convs and Detect, which are latency-bound and leave most CUs idle when run alone
         # (profiles/r01_layers_v4.txt: 0.7 ms of < 60 TF/s layers + 0.35 ms of Detect per batch-8 step).
-        self.two_streams = device.type == 'cuda' and os.environ.get('YOLACT_AMD_STREAMS', '2') != '1'
-        self.stream_b = torch.cuda.Stream(device=device) if self.two_streams else None
+        self.two_streams = (device.type == 'cuda' and os.environ.get('YOLACT_AMD_STREAMS', '2') != '1') or dry_two_streams
+        self.stream_b = torch.cuda.Stream(device=device) if self.two_streams and device.type == 'cuda' else None
         self.overlap = True      # runtime switch: False runs the same op list on ONE stream (serialised kernels), which
                                  # is what per-kernel timing (bench.py's roofline pass) needs
         self.events = {}
@@ -281,7 +284,7 @@ class Plan:
 
     def record(self, ev):
         if self.two_streams:
-            self.events[ev] = torch.cuda.Event()
+            self.events[ev] = torch.cuda.Event() if self.device.type == 'cuda' else None
             self.ops.append(('record', ev, ev, self._cur))
 
     def wait(self, ev):
