@@ -68,6 +68,7 @@ def build_net(meta, device=DEV):
     from yolact_amd.yolact import Yolact
     net = Yolact()
     net.load_state_dict_compat(case_state_dict(meta))
+    net.detect.use_fast_nms = True          # what eval.py:871 does (the class default is the reference's False)
     return net.to(device)
 
 

@@ -103,3 +103,47 @@ def match_detections(got, ref, score_tol=1e-4, box_tol=1e-4, coef_tol=1e-4):
                 problems.append('tied group [%d,%d) differs' % (i, j))
         i = j
     return problems
+
+
+def assert_margin_match(prior_idx, out, raw, dets, cfg, delta=1e-3, value_tol=1e-4):
+    """End-to-end detection parity, margin-aware (SURVEY 7 hard part 3(ii), oracle/margins.py).
+
+    `out`: the product's list of {'detection': ..}; `prior_idx`: Detect.last_prior_idx (prior index per returned
+    detection); `raw` / `dets`: the oracle's head tensors and detections.  For every image
+      * every (prior, class) decision of the reference whose margin exceeds `delta` is reproduced exactly
+        (sure <= device output <= possible),
+      * detections present on both sides agree in score / box / coefficients to `value_tol`,
+      * the device scores are sorted descending.
+    Returns a per-image summary (sure / possible / common counts) for the test log."""
+    from oracle import margins as MG
+    summary = []
+    for b in range(len(out)):
+        m = MG.detect_margins(raw['conf'][b], raw['loc'][b], raw['priors'], cfg.nms_conf_thresh, cfg.nms_thresh,
+                              cfg.nms_top_k, cfg.max_num_detections, delta=delta, delta_iou=delta)
+        MG.check_against_oracle(m, dets[b])
+        g = out[b]['detection']
+        if g is None:
+            assert not m['sure'], 'image %d: device returned nothing, %d sure detections expected' % (b, len(m['sure']))
+            summary.append((b, 0, len(m['possible']), 0))
+            continue
+        gp, gc = prior_idx[b].cpu().tolist(), g['class'].cpu().tolist()
+        problems = MG.margin_match(gp, gc, m)
+        assert not problems, 'image %d: %s\n%s' % (b, problems, MG.summarize(m))
+        sc = g['score'].float().cpu()
+        assert bool((sc[:-1] >= sc[1:]).all()), 'scores must be sorted descending'
+        r = dets[b]
+        ncommon = 0
+        if r is not None:
+            ridx = {pc: i for i, pc in enumerate(zip(r['prior'].tolist(), r['class'].tolist()))}
+            pairs = [(i, ridx[pc]) for i, pc in enumerate(zip(gp, gc)) if pc in ridx]
+            ncommon = len(pairs)
+            if pairs:
+                gi = torch.tensor([i for i, _ in pairs]); ri = torch.tensor([j for _, j in pairs])
+                assert (sc[gi] - r['score'][ri]).abs().max().item() <= value_tol
+                bscale = max(1.0, r['box'].abs().max().item())
+                assert (g['box'].float().cpu()[gi] - r['box'][ri]).abs().max().item() <= value_tol * bscale
+                assert (g['mask'].float().cpu()[gi] - r['mask'][ri]).abs().max().item() <= value_tol
+            if len(m['possible']) == len(m['sure']):          # nothing undecidable: the outputs must be the same set
+                assert ncommon == r['score'].shape[0] == len(gp)
+        summary.append((b, len(m['sure']), len(m['possible']), ncommon))
+    return summary

@@ -1,0 +1,142 @@
+"""Oracle parity of the plans that are actually TIMED: the BASELINE configurations at their batch sizes, with the default
+(shipped-table) plan, plus one run with F(4x4,3x3) Winograd forced onto every eligible layer.
+
+Every golden fixture runs at batch 1-2; which layers go Winograd, and with which tile, depends on the batch (the tune
+table is keyed by layer shape incl. B), so parity at batch 1 says nothing about the batch-8 plan bench.py times.  Here the
+CPU oracle (oracle/yolact_oracle.py: torch-CPU restatement pinned to the executed reference, tests/test_oracle_golden.py)
+runs on the GPU box's host cores at the bench shapes and is compared with `net.forward_raw` and `net(x)`:
+
+  heads   |loc|, |coef| <= 1e-4 absolute; conf logits and prototypes <= 1e-4 * max|ref| (north star: "masks/scores within
+          1e-4 fp32"); softmax scores <= 1e-4 absolute
+  Detect  margin-aware matching (oracle/margins.py): every reference decision whose margin exceeds 1e-3 is reproduced
+          exactly, common detections agree to 1e-4; undecidable ones are listed
+  masks   postprocess() of two images: binary masks differ from the oracle's only where its soft value is within 1e-4 of 0.5
+"""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import CONFIGS, assert_margin_match  # noqa: E402
+from yolact_amd.utils.synth import synth_images, synth_state_dict  # noqa: E402
+
+DEV = 'cuda:0'
+
+# (id, config, batch, size, weight seed, conf gain, image seed)
+CASES = [
+    ('configs1_r50_b8', 'yolact_resnet50_config', 8, 550, 0, 0.04, 1234),     # == bench.py's default workload, same tensors
+    ('configs2_r101_b16', 'yolact_base_config', 16, 550, 3, 0.04, 2234),
+    ('configs4_im700_b8', 'yolact_im700_config', 8, 700, 5, 0.04, 3234),       # per-GPU share of configs[4]
+    ('configs3_plus_r50_b8', 'yolact_plus_resnet50_config', 8, 550, 6, 0.04, 4234),
+    ('darknet53_b8', 'yolact_darknet53_config', 8, 550, 4, 0.04, 5234),        # named in north_star
+]
+
+
+def _build(config, seed, gain):
+    import yolact_amd
+    yolact_amd.set_cfg(config)
+    from yolact_amd.yolact import Yolact
+    net = Yolact()
+    sd = synth_state_dict([(k, tuple(v.shape)) for k, v in net.state_dict().items()], seed=seed, conf_gain=gain)
+    net.load_state_dict_compat(sd)
+    net.detect.use_fast_nms = True
+    return net.to(DEV), sd
+
+
+def _compare(net, sd, config, B, size, img_seed, tag):
+    from oracle import yolact_oracle as O
+    from yolact_amd.layers.output_utils import postprocess
+    cfg = CONFIGS[config].copy()
+    x = synth_images(B, size, size, seed=img_seed)
+    with torch.no_grad():
+        raw = O.forward_raw(x, sd, cfg)
+        dets = O.detect(raw, cfg)
+    xd = x.to(DEV)
+    got = net.forward_raw(xd)
+    torch.cuda.synchronize()
+    plan = net.plan_for(xd)
+    errs = {}
+    for k, absolute in (('loc', True), ('mask', True), ('conf_logits', False), ('proto', False)):
+        g, r = got[k].cpu(), raw[k]
+        assert g.shape == r.shape, (k, g.shape, r.shape)
+        err = (g - r).abs().max().item()
+        scale = 1.0 if absolute else max(1.0, r.abs().max().item())
+        errs[k] = err / scale
+        assert err <= 1e-4 * scale, '%s %s: max err %g (scale %g)' % (tag, k, err, scale)
+    conf_err = (torch.softmax(got['conf_logits'], -1).cpu() - raw['conf']).abs().max().item()
+    assert conf_err <= 1e-4, conf_err
+    assert torch.equal(got['priors'].cpu(), raw['priors'])
+    out = net(xd)
+    assert len(out) == B
+    summary = assert_margin_match(net.detect.last_prior_idx, out, raw, dets, cfg, delta=1e-3)
+    n_w2 = sum(1 for op in plan.ops if isinstance(op[2], str) and op[2].endswith('[wino]') and op[1].contents.m == 2)
+    n_w4 = sum(1 for op in plan.ops if isinstance(op[2], str) and op[2].endswith('[wino]') and op[1].contents.m == 4)
+    print('%s: plan F(2x2) x%d, F(4x4) x%d, tune misses %d; head errors / scale %s; softmax err %.2e; per image '
+          '(sure, possible, common) %s' % (tag, n_w2, n_w4, plan.tune_misses, {k: '%.2e' % v for k, v in errs.items()},
+                                           conf_err, [(s, p, c) for _, s, p, c in summary]))
+    for b in (0, B - 1):
+        if dets[b] is None:
+            continue
+        # stage the ORACLE's detections through the device postprocess: identical inputs, so the masks may differ only
+        # at pixels whose soft value sits within 1e-4 of the threshold
+        d = {k: dets[b][k].to(DEV).clone() for k in ('box', 'mask', 'class', 'score', 'proto')}
+        classes, scores, boxes, masks = postprocess([{'detection': d, 'net': net}], size, size)
+        rc, rs, rb, rm, soft = O.postprocess(dets[b], size, size, cfg, sd, return_soft=True)
+        assert torch.equal(classes.cpu(), rc) and torch.equal(boxes.cpu(), rb)
+        bad = masks.cpu() != rm
+        assert bad.float().mean().item() < 1e-4
+        if bad.any():
+            assert (soft[bad] - 0.5).abs().max().item() < 1e-4
+    return plan, n_w2, n_w4
+
+
+@pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
+def test_timed_plan_matches_oracle_at_batch(case):
+    tag, config, B, size, seed, gain, img_seed = case
+    net, sd = _build(config, seed, gain)
+    _compare(net, sd, config, B, size, img_seed, tag)
+
+
+def test_forced_f4x4_plan_matches_oracle_at_batch8():
+    """YOLACT_AMD_WINOGRAD=4 + YOLACT_AMD_WINOGRAD_FORCE=1: every eligible 3x3 / stride-1 layer runs F(4x4,3x3) whether or
+    not it is the fastest choice, so the whole-network error of the least accurate variant is what gets checked."""
+    old = {k: os.environ.get(k) for k in ('YOLACT_AMD_WINOGRAD', 'YOLACT_AMD_WINOGRAD_FORCE')}
+    os.environ['YOLACT_AMD_WINOGRAD'], os.environ['YOLACT_AMD_WINOGRAD_FORCE'] = '4', '1'
+    try:
+        tag, config, B, size, seed, gain, img_seed = CASES[0]
+        net, sd = _build(config, seed, gain)
+        plan, n_w2, n_w4 = _compare(net, sd, config, B, size, img_seed, 'forced F(4x4) ' + tag)
+        assert n_w2 == 0 and n_w4 >= 25, (n_w2, n_w4)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_plan_is_deterministic_across_processes():
+    """The default plan comes from the shipped tune table, so two fresh processes produce identical bits (the round-1
+    plan timed its tiles per process: K-split tiles change the summation order, i.e. the bits)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, hashlib, torch; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')\n"
+        "from test_gpu_batch_parity import _build\n"
+        "from yolact_amd.utils.synth import synth_images\n"
+        "net, sd = _build('yolact_resnet50_config', 0, 0.04)\n"
+        "x = synth_images(8, 550, 550, seed=1234).to('cuda:0')\n"
+        "r = net.forward_raw(x); torch.cuda.synchronize()\n"
+        "h = hashlib.sha256()\n"
+        "[h.update(r[k].cpu().numpy().tobytes()) for k in ('loc', 'conf_logits', 'mask', 'proto')]\n"
+        "print('DIGEST', h.hexdigest(), net.plan_for(x).tune_misses)\n" % (root, root))
+    outs = []
+    for _ in range(2):
+        p = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append([l for l in p.stdout.splitlines() if l.startswith('DIGEST')][-1].split())
+    assert outs[0][1] == outs[1][1], 'two processes produced different head tensors'
+    assert outs[0][2] == '0' and outs[1][2] == '0', 'BASELINE configs[1] must be fully covered by the shipped tune table'

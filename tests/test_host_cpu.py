@@ -85,10 +85,18 @@ def test_struct_sizes_match_header():
 def test_product_path_rejects_cpu_tensors():
     """No CPU fallback: CPU inputs raise instead of silently computing somewhere else."""
     net = _make_net('yolact_resnet50_config')
-    with pytest.raises(RuntimeError, match='GPU'):
-        net(torch.zeros(1, 3, 550, 550))
     from yolact_amd.layers.detection import Detect
     d = Detect(81, 0, 200, 0.05, 0.5)
+    assert d.use_fast_nms is False and d.use_cross_class_nms is False       # the reference's defaults (detection.py:29-30)
+    with pytest.raises(NotImplementedError, match='use_fast_nms'):          # traditional NMS: loud, not silently Fast NMS
+        d({'loc': torch.zeros(1, 8, 4), 'conf': torch.zeros(1, 8, 81), 'mask': torch.zeros(1, 8, 32),
+           'priors': torch.zeros(8, 4)}, None)
+    with pytest.raises(NotImplementedError, match='use_fast_nms'):
+        net(torch.zeros(1, 3, 550, 550))
+    d.use_fast_nms = True                                                    # eval.py:871
+    net.detect.use_fast_nms = True
+    with pytest.raises(RuntimeError, match='GPU'):
+        net(torch.zeros(1, 3, 550, 550))
     with pytest.raises(RuntimeError, match='GPU'):
         d({'loc': torch.zeros(1, 8, 4), 'conf': torch.zeros(1, 8, 81), 'mask': torch.zeros(1, 8, 32),
            'priors': torch.zeros(8, 4)}, None)

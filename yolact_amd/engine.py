@@ -24,6 +24,45 @@ def _ceil(a, b):
     return (a + b - 1) // b * b
 
 
+# ---- shipped tile / algorithm table ------------------------------------------------------------------------------
+TUNE_GEN = 2          # bump whenever tile ids or kernel variants change meaning: older tables are ignored
+TUNE_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tune')
+_table_cache = {}
+
+
+def _read_table_file(path):
+    try:
+        with open(path) as f:
+            doc = json.load(f)
+    except (OSError, ValueError):
+        return {}
+    if not isinstance(doc, dict) or doc.get('gen') != TUNE_GEN or doc.get('abi') != L.ABI_VERSION:
+        return {}
+    return dict(doc.get('entries', {}))
+
+
+def _write_table_file(path, entries, device=None, note=None):
+    doc = {'gen': TUNE_GEN, 'abi': L.ABI_VERSION,
+           'device': torch.cuda.get_device_name(device) if device is not None and device.type == 'cuda' else None,
+           'note': note or 'tile id per conv shape (B,H,W,Cin,Cout,kh,kw,stride,pad,res_mode,nseg,Kpad); wino(...) -> '
+                           '[m, gemm tile, direct ms, winograd ms, F(2x2) ms, F(4x4) ms]',
+           'entries': {k: entries[k] for k in sorted(entries)}}
+    tmp = path + '.tmp%d' % os.getpid()
+    with open(tmp, 'w') as f:
+        json.dump(doc, f, indent=0, separators=(',', ':'))
+    os.replace(tmp, path)
+
+
+def load_tune_table(device):
+    """Entries of the shipped table for this device's architecture ({} when there is none)."""
+    arch = 'gfx950'
+    if device.type == 'cuda':
+        arch = getattr(torch.cuda.get_device_properties(device), 'gcnArchName', 'gfx950').split(':')[0]
+    if arch not in _table_cache:
+        _table_cache[arch] = _read_table_file(os.path.join(TUNE_DIR, arch + '.json'))
+    return dict(_table_cache[arch])
+
+
 class Packed:
     """A convolution's filters in the engine layout [CoutPad][Kpad] (k = (ky*kw+kx)*Cin + c) + folded epilogue."""
 
@@ -167,10 +206,18 @@ class Plan:
         wsel = os.environ.get('YOLACT_AMD_WINOGRAD', '1')
         self.use_winograd = device.type == 'cuda' and wsel != '0'
         self.wino_variants = (2,) if wsel == '2' else (4,) if wsel == '4' else (2, 4)
+        # YOLACT_AMD_WINOGRAD_FORCE=1: take the Winograd path on every eligible layer even where the direct kernel
+        # measured faster (parity tests of the least accurate variant; never the default)
+        self.wino_force = os.environ.get('YOLACT_AMD_WINOGRAD_FORCE', '0') == '1'
         self.down_on_side_stream = os.environ.get('YOLACT_AMD_DOWN_STREAM', 'B') == 'B'      # measured +1 %
         self.wino_alt, self._wino_packed, self._wino_ws = {}, {}, {}
+        self._done_event = None
+        self._priors_timed = False
+        self.param_stamp = None
+        self.tune_misses = 0
         self._build()
         self._bind_wino_workspaces()
+        self.sections = [None if op[0] in ('record', 'wait', 'detect') else self.section_of(op[2]) for op in self.ops]
 
     # ---- op emitters ---------------------------------------------------------------------------
     def _arena(self):
@@ -533,22 +580,58 @@ class Plan:
         return outs
 
     # ---- execution -------------------------------------------------------------------------------
-    def run(self, x: torch.Tensor, detect=None):
+    @staticmethod
+    def section_of(name):
+        """The reference's timer section an op belongs to (yolact.py:570 'backbone', :574 'fpn', :581 'proto',
+        :607 'pred_heads'); 'Detect' (detection.py:63) is timed by Detect.finish."""
+        if name.startswith('fpn.'):
+            return 'fpn'
+        if name.startswith('proto.'):
+            return 'proto'
+        if name.startswith('head'):
+            return 'pred_heads'
+        return 'backbone'
+
+    def mark_done(self):
+        """Record, on the caller's current stream, that everything reading this plan's persistent buffers has been
+        enqueued; the next run() — possibly on another stream — waits for it."""
+        if self.device.type == 'cuda' and not torch.cuda.is_current_stream_capturing():
+            if self._done_event is None:
+                self._done_event = torch.cuda.Event()
+            self._done_event.record(torch.cuda.current_stream(self.device))
+
+    def run(self, x: torch.Tensor, detect=None, timer=None):
         """x [B,3,H,W] fp32 contiguous on the plan's device. Returns (proto, detect_result): the fresh proto tensor
         and whatever `detect(stream_ptr)` returned (None without a callback).  loc/conf/coef are the plan's persistent
         head buffers.  `detect` is invoked at the point of the op list where every head has been written; its
         kernels must be launched on the stream it is handed (the side stream in two-stream mode) while its output
-        tensors are allocated by the caller's ambient stream — they are only consumed after the final join."""
+        tensors are allocated by the caller's ambient stream — they are only consumed after the final join.
+        `timer`: the reference's utils.timer module (or None): the op ranges are bracketed with its section names.
+        The arena, the head buffers and the Winograd workspaces are shared by every run of this plan: callers serialise
+        run() on the host (Yolact._run_lock) and consecutive runs are ordered on the device by an event, so two user
+        streams cannot overlap on the same buffers."""
         lib = self.lib
         cur = torch.cuda.current_stream(self.device)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if self._done_event is not None and not capturing:
+            cur.wait_event(self._done_event)
         sa = C.c_void_p(cur.cuda_stream)
         two = self.two_streams and self.overlap
         sb = C.c_void_p(self.stream_b.cuda_stream) if two else sa
         proto = torch.empty(self.proto_shape, dtype=torch.float32, device=self.device)
         self.proto_patch.seg[0].ptr = proto.data_ptr()
         det = None
-        for fn, args, name, where in self.ops:
+        sec = None
+        for (fn, args, name, where), nsec in zip(self.ops, self.sections):
             s = sb if where == 'B' else sa
+            if timer is not None and nsec is not None and nsec != sec:
+                if sec is not None:
+                    timer.stop(sec)
+                timer.start(nsec)
+                if nsec == 'pred_heads' and not self._priors_timed:
+                    with timer.env('makepriors'):       # yolact.py:219: priors are host constants of the plan, built once
+                        self._priors_timed = True
+                sec = nsec
             if fn == 'input':
                 a = self.in_args
                 rc = lib.ymi_nchw_to_nhwc4_f32(x.data_ptr(), a[1], a[2], a[3], a[4], a[5], s)
@@ -570,31 +653,66 @@ class Plan:
                 rc = fn(args, s)
             if rc != 0:
                 L.check(rc, name)
+        if timer is not None and sec is not None:
+            timer.stop(sec)
+        self.mark_done()
         return proto, det
 
-    def autotune(self, x: torch.Tensor, reps: int = 3):
-        """Measure, don't guess: time every tile configuration of every distinct conv shape on the device (HIP
-        events on the launch stream) and keep the fastest.  The unsplit tile shapes accumulate K in the same
-        order (bit-identical results); the K-split tiles (_lib.KSPLIT_TILES) sum 2 or 4 partial chains in a fixed
-        order — deterministic for a given plan, ~1e-7 relative away from the unsplit order.  Set
-        YOLACT_AMD_TUNE_CACHE to a file to pin the choices across processes (bit-reproducible runs)."""
+    # ---- tile / algorithm selection ------------------------------------------------------------------
+    def tune(self, x: torch.Tensor, reps: int = 3):
+        """Pick the tile of every conv launch and direct-vs-Winograd per 3x3 layer.
+
+        Deterministic by default: the choices come from the SHIPPED table `yolact_amd/tune/gfx950.json` (measured on
+        MI355X by tools/make_tune_table.py, keyed by layer shape), so two processes on two boxes run the same kernels
+        in the same summation order and produce the same bits.  A shape the table does not know is measured on the
+        device (HIP events on the launch stream, `self.tune_misses` counts them); such a plan is only reproducible
+        within its process unless YOLACT_AMD_TUNE_CACHE names a file to persist the new entries in.
+
+        YOLACT_AMD_AUTOTUNE: '1' (default) table + measure on miss | '0' no tuning at all (library heuristic tiles,
+        direct kernels only) | 'table' table only, a miss falls back to the heuristic | 'force' ignore the tables and
+        measure everything (what tools/make_tune_table.py uses)."""
+        mode = os.environ.get('YOLACT_AMD_AUTOTUNE', '1')
+        self.tune_table, self.wino_table, self.tune_misses = [], [], 0
+        if mode == '0':
+            return []
         cache_path = os.environ.get('YOLACT_AMD_TUNE_CACHE')
         disk = {}
-        if cache_path and os.path.exists(cache_path):
-            with open(cache_path) as f:
-                disk = json.load(f)
+        if mode != 'force':
+            disk.update(load_tune_table(self.device))
+            if cache_path and os.path.exists(cache_path):
+                disk.update(_read_table_file(cache_path))
+        n0 = len(disk)
         self.run(x)                      # realistic values in every buffer
         s = L.stream_ptr()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        cache, table = {}, []
+        measure = mode != 'table'
+        self._tune_direct(e0, e1, s, reps, disk, measure)
+        self._tune_winograd(e0, e1, s, reps, disk, measure)
+        torch.cuda.synchronize(self.device)
+        if cache_path and (len(disk) != n0 or mode == 'force'):
+            _write_table_file(cache_path, disk, self.device)
+        self.tune_entries = disk
+        return self.tune_table
+
+    autotune = tune      # round-1 name
+
+    def _tune_direct(self, e0, e1, s, reps, disk, measure):
+        cache = {}
         for fn, dptr, name, _where in self.ops:
             if fn is not self.lib.ymi_conv2d_nhwc_f32:
                 continue
             d = dptr.contents
             key = (d.B, d.H, d.W, d.Cin, d.Cout, d.kh, d.kw, d.stride, d.pad, d.res_mode, d.nseg, d.Kpad)
             if key not in cache and str(key) in disk:
-                cache[key] = int(disk[str(key)])     # tuned in an earlier process (e.g. before a rocprofv3 run)
+                d.tile = int(disk[str(key)])
+                if fn(dptr, s) == 0:                      # a stale / foreign entry must not make every forward raise
+                    cache[key] = d.tile
             if key not in cache:
+                self.tune_misses += 1
+                if not measure:
+                    cache[key] = L.TILE_AUTO
+                    d.tile = L.TILE_AUTO
+                    continue
                 if d.Cin % 32 != 0:          # stem loader: basic tiles only
                     cands = [L.TILE_128x64, L.TILE_64x64] if d.Cout <= 64 else list(L.BASIC_TILES)
                 elif d.Cout <= 32:
@@ -630,66 +748,70 @@ class Plan:
                         best, best_ms = t, times[L.TILE_NAMES[t]]
                 assert best is not None, name
                 cache[key] = best
-                table.append((name, L.TILE_NAMES[best], times))
+                disk[str(key)] = best
+                self.tune_table.append((name, L.TILE_NAMES[best], times))
             d.tile = cache[key]
-        self._autotune_winograd(e0, e1, s, reps, disk, cache_path)
-        self.tune_table = table
-        if cache_path and table:
-            disk.update({str(k): v for k, v in cache.items()})
-            with open(cache_path, 'w') as f:
-                json.dump(disk, f)
-        return table
 
-    def _autotune_winograd(self, e0, e1, s, reps, disk, cache_path):
+    def _tune_winograd(self, e0, e1, s, reps, disk, measure):
         """Per eligible layer: best GEMM tile of the Winograd path, then Winograd vs the (already tuned) direct kernel.
         The winner replaces the op in the list."""
         lib = self.lib
         wtiles = [L.TILE_64x64, L.TILE_64x128, L.TILE_128x64, L.TILE_128x128_W8, L.TILE_64x128_S3, L.TILE_32x64_K2]
         memo = {}
-        self.wino_table = []
         for idx, alts in sorted(self.wino_alt.items()):
             fn, dptr, name, where = self.ops[idx]
             if fn is not lib.ymi_conv2d_nhwc_f32:
                 continue
             w0 = alts[0]
             key = 'wino' + str((w0.B, w0.H, w0.W, w0.C, w0.Cout, w0.act, w0.nseg, tuple(a.m for a in alts)))
-            if key in disk:
-                memo[key] = tuple(disk[key])
+            if key not in memo and key in disk:
+                ent = tuple(disk[key])
+                ok = True
+                if ent[1]:                                 # validate the stored (m, tile) with one launch
+                    wd = [a for a in alts if a.m == ent[0]]
+                    if wd:
+                        wd[0].tile = int(ent[1])
+                        ok = lib.ymi_conv3x3_winograd_f32(C.byref(wd[0]), s) == 0
+                    else:
+                        ok = False
+                if ok:
+                    memo[key] = ent
             if key not in memo:
-                def timed(f, arg):
-                    f(arg, s)
-                    best = 1e30
-                    for _ in range(2):
-                        e0.record()
-                        for _ in range(reps):
-                            f(arg, s)
-                        e1.record()
-                        e1.synchronize()
-                        best = min(best, e0.elapsed_time(e1) / reps)
-                    return best
-                t_direct = timed(fn, dptr)
-                best_m, best_t, best_ms, per_m = 0, 0, 1e30, {}
-                for wd in alts:
-                    for t in wtiles:
-                        wd.tile = t
-                        if lib.ymi_conv3x3_winograd_f32(C.byref(wd), s) != 0:
-                            continue
-                        ms = timed(lib.ymi_conv3x3_winograd_f32, C.pointer(wd))
-                        per_m[wd.m] = min(ms, per_m.get(wd.m, 1e30))
-                        if ms < best_ms:
-                            best_m, best_t, best_ms = wd.m, t, ms
-                memo[key] = (best_m, best_t, round(t_direct, 4), round(best_ms, 4),
-                             round(per_m.get(2, 0.0), 4), round(per_m.get(4, 0.0), 4))
-                disk[key] = list(memo[key])
+                self.tune_misses += 1
+                if not measure:
+                    memo[key] = (0, 0, 0.0, 0.0, 0.0, 0.0)
+                else:
+                    def timed(f, arg):
+                        f(arg, s)
+                        best = 1e30
+                        for _ in range(2):
+                            e0.record()
+                            for _ in range(reps):
+                                f(arg, s)
+                            e1.record()
+                            e1.synchronize()
+                            best = min(best, e0.elapsed_time(e1) / reps)
+                        return best
+                    t_direct = timed(fn, dptr)
+                    best_m, best_t, best_ms, per_m = 0, 0, 1e30, {}
+                    for wd in alts:
+                        for t in wtiles:
+                            wd.tile = t
+                            if lib.ymi_conv3x3_winograd_f32(C.byref(wd), s) != 0:
+                                continue
+                            ms = timed(lib.ymi_conv3x3_winograd_f32, C.pointer(wd))
+                            per_m[wd.m] = min(ms, per_m.get(wd.m, 1e30))
+                            if ms < best_ms:
+                                best_m, best_t, best_ms = wd.m, t, ms
+                    memo[key] = (best_m, best_t, round(t_direct, 4), round(best_ms, 4),
+                                 round(per_m.get(2, 0.0), 4), round(per_m.get(4, 0.0), 4))
+                    disk[key] = list(memo[key])
             best_m, best_t, t_direct, t_wino, t_f2, t_f4 = memo[key]
             self.wino_table.append((name, 'F%d/%s' % (best_m, L.TILE_NAMES.get(best_t, '-')), t_direct, t_wino, t_f2, t_f4))
-            if best_t and t_wino < 0.97 * t_direct:
+            if best_t and (self.wino_force or t_wino < 0.97 * t_direct):
                 wd = [a for a in alts if a.m == best_m][0]
-                wd.tile = best_t
+                wd.tile = int(best_t)
                 self.ops[idx] = (lib.ymi_conv3x3_winograd_f32, C.pointer(wd), name + '[wino]', where)
-        if cache_path and self.wino_table:
-            with open(cache_path, 'w') as f:
-                json.dump(disk, f)
 
     def conv_flops(self):
         return sum(self.lib.ymi_conv_flops(C.byref(d)) for _, d in self.conv_meta)

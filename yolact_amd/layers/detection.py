@@ -10,6 +10,7 @@ from __future__ import annotations
 import ctypes as C
 import sys
 import contextlib
+import threading
 
 import torch
 
@@ -32,29 +33,37 @@ class Detect(object):
             raise ValueError('nms_threshold must be non negative.')   # detection.py:25-26
         self.conf_thresh = conf_thresh
         self.use_cross_class_nms = False
-        self.use_fast_nms = True   # the reference defaults to False and eval.py:871 turns it on; see __call__
+        self.use_fast_nms = False  # detection.py:30: the reference's default; eval.py:871 sets it from --fast_nms (True)
         self._ws = {}
+        self._ws_lock = threading.Lock()
+        self.last_prior_idx = None   # per image: prior index of every returned detection (diagnostics / parity tests;
+                                     # NOT part of the reference's return structure, so it is kept off the dicts)
 
     def _workspace(self, B, P, C, D, cap, dev, slot=0):
+        """Scratch tensors of the three Detect kernels, one set per (shape, device, slot).  They live as long as this
+        Detect object: raw addresses of a set may be baked into a captured hipGraph (YOLACT_AMD_GRAPH=1), so nothing
+        is ever evicted behind a graph's back (a set is ~B*P*85*4 bytes, 52 MB at batch 8)."""
         key = (B, P, C, D, cap, dev, slot)
         ws = self._ws.get(key)
         if ws is None:
-            nfg = C - 1
-            ws = dict(
-                scores_t=torch.empty(B, nfg, P, device=dev), keep=torch.empty(B, P, dtype=torch.int32, device=dev),
-                num_keep=torch.zeros(B, dtype=torch.int32, device=dev), maxsc=torch.empty(B, P, device=dev),
-                argmax=torch.empty(B, P, dtype=torch.int32, device=dev),
-                cand_score=torch.empty(B, nfg * self.top_k, device=dev),
-                cand_prior=torch.empty(B, nfg * self.top_k, dtype=torch.int32, device=dev))
-            if len(self._ws) > 4:
-                self._ws.clear()
-            self._ws[key] = ws
+            with self._ws_lock:
+                ws = self._ws.get(key)
+                if ws is None:
+                    nfg = C - 1
+                    ws = dict(
+                        scores_t=torch.empty(B, nfg, P, device=dev), keep=torch.empty(B, P, dtype=torch.int32, device=dev),
+                        num_keep=torch.zeros(B, dtype=torch.int32, device=dev), maxsc=torch.empty(B, P, device=dev),
+                        argmax=torch.empty(B, P, dtype=torch.int32, device=dev),
+                        cand_score=torch.empty(B, nfg * self.top_k, device=dev),
+                        cand_prior=torch.empty(B, nfg * self.top_k, dtype=torch.int32, device=dev))
+                    self._ws[key] = ws
         return ws
 
     def run_device(self, loc, conf, mask, priors, conf_is_logits, stream=None, slot=0):
         """Launch the Detect kernels; returns fixed-capacity device tensors (no host sync).  `stream`: raw
         hipStream_t (ctypes void*) to launch on — the execution plan passes its side stream — default: torch's
         current stream.  Output tensors are always allocated under the ambient stream."""
+        self._require_fast_nms()
         for name, t in (('loc', loc), ('conf', conf), ('mask', mask), ('priors', priors)):
             L.require_cuda(t, name)
         cfg = active_cfg()
@@ -64,6 +73,18 @@ class Detect(object):
         max_det = int(cfg.max_num_detections)
         cap = self.top_k if self.use_cross_class_nms else max_det
         ws = self._workspace(B, P, Ccls, D, cap, dev, slot)
+        return self._launch(loc, conf, mask, priors, conf_is_logits, stream, ws, B, P, Ccls, D, dev, max_det, cap)
+
+    def _require_fast_nms(self):
+        if not self.use_fast_nms:
+            # detection.py:101-106: the reference would run traditional_nms (per-class greedy NMS in Cython on the
+            # CPU, utils/cython_nms.pyx) here.  That path is outside the hot path (non-default in eval.py,
+            # a CPU round trip per class); raising keeps the semantics honest instead of silently running Fast NMS.
+            raise NotImplementedError(
+                'Detect.use_fast_nms is False (the reference default): traditional Cython/CPU NMS is not part of the '
+                'MI355X hot path.  Set net.detect.use_fast_nms = True, as eval.py:871 does for its default --fast_nms.')
+
+    def _launch(self, loc, conf, mask, priors, conf_is_logits, stream, ws, B, P, Ccls, D, dev, max_det, cap):
         out = dict(count=torch.empty(B, dtype=torch.int32, device=dev), box=torch.empty(B, cap, 4, device=dev),
                    score=torch.empty(B, cap, device=dev), cls=torch.empty(B, cap, dtype=torch.int64, device=dev),
                    coef=torch.empty(B, cap, D, device=dev), prior=torch.empty(B, cap, dtype=torch.int32, device=dev))
@@ -88,9 +109,6 @@ class Detect(object):
     def __call__(self, predictions, net):
         """predictions: 'loc' [B,P,4], 'conf' [B,P,C] post-softmax (reference contract) or 'conf_logits' (fused
         softmax), 'mask' [B,P,D], 'priors' [P,4], optional 'proto' [B,ph,pw,D]."""
-        if not self.use_fast_nms:
-            raise NotImplementedError('traditional (Cython, CPU) NMS is outside the hot path; eval.py runs with '
-                                      '--fast_nms=True by default (SURVEY §2)')
         if 'conf_logits' in predictions and 'conf' not in predictions:
             conf, is_logits = predictions['conf_logits'], True
         else:
@@ -103,15 +121,17 @@ class Detect(object):
         """Fixed-capacity device outputs -> the reference's list of per-image dicts (one host read of the counts)."""
         with _timer_env('Detect'):
             counts = o['count'].tolist()          # the one host sync per batch
-            out = []
+            out, pri = [], []
             for b, n in enumerate(counts):
                 if n == 0:
                     out.append({'detection': None, 'net': net})
+                    pri.append(None)
                     continue
                 det = {'box': o['box'][b, :n], 'mask': o['coef'][b, :n], 'class': o['cls'][b, :n],
                        'score': o['score'][b, :n]}
                 if proto is not None:
                     det['proto'] = proto[b]
-                det['_prior'] = o['prior'][b, :n]
+                pri.append(o['prior'][b, :n])
                 out.append({'detection': det, 'net': net})
+            self.last_prior_idx = pri
         return out

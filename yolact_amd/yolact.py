@@ -10,7 +10,6 @@ libyolact_amd.so and replays it on the current HIP stream.  CPU tensors are reje
 """
 from __future__ import annotations
 
-import contextlib
 import os
 import sys
 import threading
@@ -25,19 +24,10 @@ from .engine import Plan
 from .layers.detection import Detect
 
 
-def _timer_env(name):
-    """Use the reference's utils.timer sections (yolact.py:570-607) when eval.py has it loaded."""
-    t = sys.modules.get('utils.timer')
-    if t is not None and hasattr(t, 'env'):
-        return t.env(name)
-    return contextlib.nullcontext()
-
-
 class Yolact(nn.Module):
     def __init__(self):
         super().__init__()
         cfg = active_cfg()
-        self.cfg = cfg
         if not (is_lincomb(cfg) and cfg.eval_mask_branch):
             raise NotImplementedError('only mask_type.lincomb configs are on the hot path (SURVEY §8)')
         for flag in ('use_prediction_module', 'use_yolo_regressors', 'use_mask_scoring', 'use_instance_coeff',
@@ -94,7 +84,18 @@ class Yolact(nn.Module):
                              nms_thresh=cfg.nms_thresh)
         self._plans = {}
         self._plan_lock = threading.Lock()
+        self._run_lock = threading.Lock()
+        self._ptensors = None
+        # any route that rewrites parameters wholesale (nn.Module.load_state_dict included) drops the packed / BN-folded
+        # copies the plans hold; in-place edits are caught by the version stamps checked in plan_for()
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_plans())
         self.eval()
+
+    @property
+    def cfg(self):
+        """The config the forward pass reads — at CALL time, like the reference's global `cfg` (yolact.py:566-674): the
+        reference's own `data.config.cfg` when that module is loaded (eval.py), else yolact_amd.config.cfg."""
+        return active_cfg()
 
     # ---- weights ---------------------------------------------------------------------------------------
     def save_weights(self, path):
@@ -119,11 +120,20 @@ class Yolact(nn.Module):
     def invalidate_plans(self):
         with self._plan_lock:
             self._plans.clear()
+            self._ptensors = None
+
+    def _param_stamp(self):
+        """Sum of the autograd version counters of every parameter / buffer: changes on any in-place edit."""
+        pt = self._ptensors
+        if pt is None:
+            pt = self._ptensors = [t for t in list(self.parameters()) + list(self.buffers())]
+        return sum(t._version for t in pt)
 
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)   # .cuda()/.to(): packed filters must be rebuilt on the new device
         if hasattr(self, '_plans'):
             self._plans.clear()
+            self._ptensors = None
         return r
 
     def init_weights(self, backbone_path):
@@ -139,6 +149,11 @@ class Yolact(nn.Module):
     def plan_for(self, x, slot=0) -> Plan:
         key = (tuple(x.shape), x.device, slot)
         p = self._plans.get(key)
+        stamp = self._param_stamp()
+        if p is not None and p.param_stamp != stamp:
+            # a parameter was edited in place after the plan packed it (BN fold, Winograd filters): rebuild everything
+            self.invalidate_plans()
+            p, stamp = None, self._param_stamp()
         if p is None:
             with self._plan_lock:   # one-time setup is not thread-safe in the reference either (eval.py:793-796)
                 p = self._plans.get(key)
@@ -146,26 +161,29 @@ class Yolact(nn.Module):
                     B, _, H, W = x.shape
                     with torch.no_grad():
                         p = Plan(self, B, H, W, x.device)
-                        if x.is_cuda and os.environ.get('YOLACT_AMD_AUTOTUNE', '1') != '0':
-                            p.autotune(x)
+                        p.param_stamp = stamp
+                        if x.is_cuda:
+                            p.tune(x)
                     self._plans[key] = p
         return p
 
     def forward(self, x):
         """x: float32 [B,3,H,W], normalised RGB (resnet_transform, data/config.py:181-186)."""
+        self.detect._require_fast_nms()      # traditional NMS (the reference's Detect default) is not on the hot path: raise
         L.require_cuda(x, 'input batch')
         if x.dim() != 4 or x.shape[1] != 3:
             raise ValueError('expected [B,3,H,W], got %s' % (tuple(x.shape),))
         if next(self.parameters()).device != x.device:
             raise RuntimeError('model and input live on different devices')
-        cfg = self.cfg
+        cfg = self.cfg                    # read at call time, like the reference (yolact.py:566-568)
         cfg._tmp_img_h, cfg._tmp_img_w = int(x.shape[2]), int(x.shape[3])
         x = x.detach().to(torch.float32).contiguous()
         with torch.cuda.device(x.device):
             plan = self.plan_for(x)
-            with _timer_env('backbone'):
+            # the op list carries the reference's timer sections (backbone / fpn / proto / pred_heads, yolact.py:570-607)
+            with self._run_lock:
                 proto, dev_out = plan.run(x, detect=lambda s: self.detect.run_device(
-                    plan.loc, plan.conf, plan.coef, plan.priors, True, stream=s))
+                    plan.loc, plan.conf, plan.coef, plan.priors, True, stream=s), timer=sys.modules.get('utils.timer'))
             return self.detect.finish(dev_out, proto, self)
 
     def maskiou_forward(self, masks_lo):
@@ -206,8 +224,9 @@ class Yolact(nn.Module):
         plan = self.plan_for(x, slot)
         if os.environ.get('YOLACT_AMD_GRAPH', '0') == '1':
             return self._forward_device_graph(plan, x, slot)
-        proto, out = plan.run(x, detect=lambda s: self.detect.run_device(
-            plan.loc, plan.conf, plan.coef, plan.priors, True, stream=s, slot=slot))
+        with self._run_lock:    # a plan's arena / head buffers are shared state: one forward at a time per model
+            proto, out = plan.run(x, detect=lambda s: self.detect.run_device(
+                plan.loc, plan.conf, plan.coef, plan.priors, True, stream=s, slot=slot))
         out['proto'] = proto
         return out
 
@@ -252,6 +271,9 @@ class Yolact(nn.Module):
         x = x.detach().to(torch.float32).contiguous()
         with torch.cuda.device(x.device):
             plan = self.plan_for(x)
-            proto, _ = plan.run(x)
-            return {'loc': plan.loc.clone(), 'conf_logits': plan.conf.clone(), 'mask': plan.coef.clone(),
-                    'priors': plan.priors, 'proto': proto}
+            with self._run_lock:
+                proto, _ = plan.run(x)
+                out = {'loc': plan.loc.clone(), 'conf_logits': plan.conf.clone(), 'mask': plan.coef.clone(),
+                       'priors': plan.priors, 'proto': proto}
+                plan.mark_done()      # the clones read the plan's persistent head buffers
+            return out
