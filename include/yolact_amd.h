@@ -169,6 +169,14 @@ int ymi_lincomb_crop_f32(const float *proto, const float *coef, const float *box
 /* out[n,y,x] = bilinear(masks_lo[n], (h,w))[y,x] > thresh ? 1 : 0 (float32) ; thresh<0 -> no binarise */
 int ymi_mask_upsample_f32(const float *masks_lo, float *out, int N, int ph, int pw, int h, int w,
                           float thresh, void *stream);
+/* The same two steps for a whole fixed-capacity batch in ONE launch each (the per-image Python loop of eval.py:149 /
+ * output_utils.py:35 collapsed): proto [B,ph,pw,D], coef [B,cap,D], box [B,cap,4], masks_lo [B,cap,ph,pw], out
+ * [B,cap,h,w]; count [B] int32 ON THE DEVICE = live detections per image (null: all cap); rows past count[b] are
+ * left untouched. */
+int ymi_lincomb_crop_batch_f32(const float *proto, const float *coef, const float *box, const int32_t *count,
+                               float *masks_lo, int B, int cap, int ph, int pw, int D, int crop, void *stream);
+int ymi_mask_upsample_batch_f32(const float *masks_lo, const int32_t *count, float *out, int B, int cap, int ph, int pw,
+                                int h, int w, float thresh, void *stream);
 /* boxes [N,4] relative -> int64 absolute pixels via sanitize_coordinates(cast=False) then truncation */
 int ymi_boxes_to_pixels(const float *box, int64_t *out, int N, int w, int h, void *stream);
 

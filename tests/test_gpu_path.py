@@ -354,3 +354,39 @@ def test_hipgraph_replay_equals_eager():
                 for b, nb in enumerate(n):              # rows past count are unspecified scratch
                     assert torch.equal(e[k][b, :nb], g[k][b, :nb]), (k, b)
     assert not torch.equal(g1['proto'], g2['proto'])
+
+
+def test_postprocess_batch_equals_per_image_and_flat_kernel():
+    """One-launch batched postprocess == the per-image reference-API postprocess bit for bit, on the device outputs of a
+    real forward; and the row-band upsample kernel == the flat round-1 kernel bit for bit (odd sizes, unaligned bands)."""
+    import ctypes as C
+    from gpu_utils import build_net
+    from helpers import case_images
+    from yolact_amd import _lib as L
+    from yolact_amd.layers.output_utils import postprocess, postprocess_batch
+    meta, _ = load_golden('r50_dense')
+    net = build_net(meta)
+    x = case_images(meta).to(DEV)
+    dev_out = net.forward_device(x)
+    preds = net.detect.finish(dev_out, dev_out['proto'], net)
+    for (w, h) in ((550, 550), (131, 97)):
+        bat = postprocess_batch(dev_out, w, h)
+        counts = bat['count'].tolist()
+        for b in range(meta['B']):
+            classes, scores, boxes, masks = postprocess(preds, w, h, batch_idx=b)
+            n = counts[b]
+            assert n == classes.shape[0] and n > 0
+            assert torch.equal(bat['masks'][b, :n], masks) and torch.equal(bat['boxes'][b, :n], boxes)
+            assert torch.equal(bat['classes'][b, :n], classes) and torch.equal(bat['scores'][b, :n], scores)
+    # band kernel vs flat kernel on soft (thresh < 0) and hard outputs, sizes that make every band unaligned
+    lo = torch.rand(7, 138, 138, device=DEV)
+    for (h, w) in ((97, 131), (550, 550), (33, 1), (5, 1023)):
+        for thr in (-1.0, 0.5):
+            a = torch.full((7, h, w), float('nan'), device=DEV)
+            L.check(L.lib().ymi_mask_upsample_f32(lo.data_ptr(), a.data_ptr(), 7, 138, 138, h, w, C.c_float(thr), L.stream_ptr()))
+            ref = torch.nn.functional.interpolate(lo[None], (h, w), mode='bilinear', align_corners=False)[0]
+            if thr < 0:
+                assert (a - ref).abs().max().item() < 1e-5
+            else:
+                bad = a != (ref > 0.5).float()
+                assert bad.float().mean().item() < 1e-4 and not torch.isnan(a).any()

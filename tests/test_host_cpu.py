@@ -169,6 +169,18 @@ def _gloo_worker(rank, world, port, q):
         assert allrec is None
     lo, hi = parallel.shard_range(13, rank, world)
     assert (lo, hi) == ((0, 7) if rank == 0 else (7, 13))
+    # uneven shards (13 images over 2 ranks = 7 + 6): every rank pads to `per` rows, dst trims to the global batch
+    per = 7
+    mine = torch.arange((hi - lo) * rec.shape[1], dtype=torch.float32).view(hi - lo, rec.shape[1]) + 1000 * rank
+    allr = parallel.gather_records(mine, dst=0, rows_per_rank=per, n_items=13)
+    if rank == 0:
+        assert allr.shape == (13, rec.shape[1]) and torch.equal(allr[:7], mine) and float(allr[7, 0]) == 1000.0
+    # mismatched sizes without rows_per_rank: an error on every rank, not undefined behaviour inside the collective
+    try:
+        parallel.gather_records(mine, dst=0)
+        raise SystemExit('size mismatch not detected')
+    except RuntimeError as e:
+        assert 'different numbers of records' in str(e)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -84,6 +84,8 @@ SYMBOLS = [
     ('ymi_detect_f32', C.c_int, [C.POINTER(DetectDesc), _P]),
     ('ymi_lincomb_crop_f32', C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     ('ymi_mask_upsample_f32', C.c_int, [_P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    ('ymi_lincomb_crop_batch_f32', C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    ('ymi_mask_upsample_batch_f32', C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P]),
     ('ymi_boxes_to_pixels', C.c_int, [_P, _P, _I, _I, _I, _P]),
     ('ymi_dcn_v2_forward_f32', C.c_int, [C.POINTER(DcnDesc), _P]),
     ('ymi_composite_masks_u8', C.c_int, [_P, _P, _P, _I, _I, _I, _F, _P, _P]),

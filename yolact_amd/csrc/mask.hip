@@ -2,6 +2,7 @@
 // then bilinear upsample to the image size + binarise, and box sanitising.
 // Reference: layers/output_utils.py:69-99, layers/box_utils.py:327-373 (sanitize_coordinates, crop).
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/yolact_amd.h"
 
 namespace {
@@ -11,14 +12,25 @@ namespace {
 // 32 lanes of a half-wave hold 32 consecutive pixels of ONE detection -> 128-byte coalesced stores into
 // the [N, ph*pw] output.  K = D (32): lane-half h holds k = 16h..16h+15 (64 contiguous bytes of the
 // pixel's / detection's row) and step s pairs (s, 16+s) — same free-K-order trick as the conv engine.
+// Batched form: blockIdx.y = image b of a fixed-capacity batch (proto [B,npix,D], coef / box / out rows b*cap ..); the
+// number of live detections of image b is read from `count[b]` on the device (no host round trip), `N` when count is null.
 template <int D>
 __global__ __launch_bounds__(256) void lincomb_crop_k(const float *__restrict__ proto, const float *__restrict__ coef,
                                                       const float *__restrict__ box, float *__restrict__ out, int ph,
-                                                      int pw, int N, int crop) {
+                                                      int pw, int N, int crop, const int *__restrict__ count, int cap) {
   static_assert(D == 32, "mask_dim 32");
   extern __shared__ float cb[];  // [Npad][4] crop bounds x1,x2,y1,y2
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int npix = ph * pw;
+  {
+    const int b = blockIdx.y;
+    if (count) { N = count[b]; N = N > cap ? cap : N; }
+    if (N <= 0) return;
+    proto += (size_t)b * npix * D;
+    coef += (size_t)b * cap * D;
+    box += (size_t)b * cap * 4;
+    out += (size_t)b * cap * npix;
+  }
   const int ntiles = (N + 31) / 32;
   for (int n = t; n < ntiles * 32; n += 256) {
     float x1 = 0.f, x2 = (float)pw, y1 = 0.f, y2 = (float)ph;
@@ -130,6 +142,59 @@ __global__ __launch_bounds__(256) void mask_upsample_k(const float *__restrict__
   }
 }
 
+// Row-band form of the same upsample (the default): one block = R consecutive output rows of one mask.
+//   phase 1  thread = output column(s); the horizontally interpolated values of the two source rows y0 / y1 stay in
+//            registers and are refreshed only when the (block-uniform) source row changes — about every h/ph output rows —
+//            so a pixel costs ~1/4 of a gather instead of four, plus two lerps, one compare and one LDS store;
+//   phase 2  the band (R*w contiguous floats of the flat [N,h,w] output) leaves LDS as aligned 16-byte stores.
+// The flat kernel above did four dependent gathers and two integer divisions per pixel and reached 1.2 TB/s of the
+// 968 MB mask write of a batch (profiles/r01); this one is bound by the HBM write.
+// Arithmetic is identical to mask_upsample_k (same fp32 coordinate math, same lerp association) — bit-equal outputs.
+// blockIdx.y = mask index n = b*cap + i; masks past count[b] are skipped (their rows are unspecified, like every
+// fixed-capacity output of the path).
+template <int R>
+__global__ __launch_bounds__(256) void mask_upsample_band_k(const float *__restrict__ lo, float *__restrict__ out, int ph,
+                                                            int pw, int h, int w, float sh, float sw, float thresh,
+                                                            const int *__restrict__ count, int cap) {
+  extern __shared__ __attribute__((aligned(16))) float band[];      // [3 + R*w], shifted so that LDS float4 j <-> global float4 j
+  const int n = blockIdx.y;
+  if (count) {
+    const int b = n / cap, i = n - b * cap;
+    if (i >= count[b]) return;
+  }
+  const int y_begin = blockIdx.x * R;
+  const int rows = (h - y_begin) < R ? (h - y_begin) : R;
+  const long g0 = ((long)n * h + y_begin) * w;       // first flat element of the band
+  const int shift = (int)(g0 & 3);                   // LDS index e holds flat element g0 - shift + e
+  const float *img = lo + (size_t)n * ph * pw;
+  for (int x = threadIdx.x; x < w; x += 256) {
+    int x0, x1; float lx;
+    up_coord(x, sw, pw, x0, x1, lx);
+    int cy0 = -1, cy1 = -1;
+    float v00 = 0.f, v01 = 0.f, v10 = 0.f, v11 = 0.f;
+    for (int r = 0; r < rows; ++r) {
+      int y0, y1; float ly;
+      up_coord(y_begin + r, sh, ph, y0, y1, ly);
+      if (y0 != cy0) { cy0 = y0; v00 = img[y0 * pw + x0]; v01 = img[y0 * pw + x1]; }
+      if (y1 != cy1) { cy1 = y1; v10 = img[y1 * pw + x0]; v11 = img[y1 * pw + x1]; }
+      const float v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+      band[shift + r * w + x] = thresh < 0.f ? v : (v > thresh ? 1.f : 0.f);
+    }
+  }
+  __syncthreads();
+  const int end = shift + rows * w;
+  float *dst = out + (g0 - shift);                   // 16-byte aligned (out is, and g0 - shift is a multiple of 4)
+  const int j0 = (shift + 3) >> 2, j1 = end >> 2;    // float4 chunks [j0, j1) are fully inside the band
+  if (j1 > j0) {
+    for (int e = shift + threadIdx.x; e < 4 * j0; e += 256) dst[e] = band[e];
+    for (int j = j0 + threadIdx.x; j < j1; j += 256)
+      *reinterpret_cast<f32x4 *>(dst + 4 * j) = *reinterpret_cast<const f32x4 *>(band + 4 * j);
+    for (int e = 4 * j1 + threadIdx.x; e < end; e += 256) dst[e] = band[e];
+  } else {
+    for (int e = shift + threadIdx.x; e < end; e += 256) dst[e] = band[e];
+  }
+}
+
 // boxes -> absolute int64 pixels: sanitize_coordinates(x1, x2, w, padding=0, cast=False) then .long()
 __global__ void boxes_to_pixels_k(const float *__restrict__ box, long long *__restrict__ out, int N, int w, int h) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -157,14 +222,57 @@ int ymi_lincomb_crop_f32(const float *proto, const float *coef, const float *box
   const int grid = (npix + 127) / 128;
   const size_t lds = (size_t)((N + 31) / 32) * 32 * 4 * sizeof(float);
   hipLaunchKernelGGL(lincomb_crop_k<32>, dim3(grid), dim3(256), lds, (hipStream_t)stream, proto, coef, box, masks_lo,
-                     ph, pw, N, crop);
+                     ph, pw, N, crop, (const int *)nullptr, N);
   return ymi_launch_status();
+}
+
+int ymi_lincomb_crop_batch_f32(const float *proto, const float *coef, const float *box, const int32_t *count,
+                               float *masks_lo, int B, int cap, int ph, int pw, int D, int crop, void *stream) {
+  if (!proto || !coef || !box || !masks_lo) return YMI_ENULL;
+  if (D != 32) return YMI_ESHAPE;
+  if (B <= 0 || B > 65535 || ph <= 0 || pw <= 0 || cap <= 0 || cap > 1024) return YMI_EARG;
+  const int npix = ph * pw;
+  const size_t lds = (size_t)((cap + 31) / 32) * 32 * 4 * sizeof(float);
+  hipLaunchKernelGGL(lincomb_crop_k<32>, dim3((npix + 127) / 128, B), dim3(256), lds, (hipStream_t)stream, proto, coef, box,
+                     masks_lo, ph, pw, cap, crop, (const int *)count, cap);
+  return ymi_launch_status();
+}
+
+namespace {
+constexpr int UP_ROWS = 8;
+// banded kernel when a band fits the LDS budget and the grid's y dimension; flat kernel otherwise
+int launch_upsample(const float *masks_lo, float *out, const int32_t *count, int nmask, int cap, int ph, int pw, int h, int w,
+                    float thresh, hipStream_t s) {
+  if (((size_t)UP_ROWS * w + 4) * sizeof(float) <= 64 * 1024 && nmask <= 65535 && ((uintptr_t)out & 15) == 0) {
+    hipLaunchKernelGGL(mask_upsample_band_k<UP_ROWS>, dim3((h + UP_ROWS - 1) / UP_ROWS, nmask), dim3(256),
+                       ((size_t)UP_ROWS * w + 4) * sizeof(float), s, masks_lo, out, ph, pw, h, w, (float)ph / (float)h,
+                       (float)pw / (float)w, thresh, (const int *)count, cap);
+    return ymi_launch_status();
+  }
+  if (count) return YMI_ESHAPE;
+  const long total = (long)nmask * h * w, total4 = (total + 3) / 4;
+  long g = (total4 + 255) / 256;
+  const long capg = 256L * 16;
+  hipLaunchKernelGGL(mask_upsample_k, dim3((int)(g > capg ? capg : g)), dim3(256), 0, s, masks_lo, out, ph, pw, h, w,
+                     (float)ph / (float)h, (float)pw / (float)w, thresh, total4, total);
+  return ymi_launch_status();
+}
+}  // namespace
+
+int ymi_mask_upsample_batch_f32(const float *masks_lo, const int32_t *count, float *out, int B, int cap, int ph, int pw,
+                                int h, int w, float thresh, void *stream) {
+  if (!masks_lo || !out) return YMI_ENULL;
+  if (B <= 0 || cap <= 0 || ph <= 0 || pw <= 0 || h <= 0 || w <= 0 || (long)B * cap > 65535) return YMI_EARG;
+  return launch_upsample(masks_lo, out, count, B * cap, cap, ph, pw, h, w, thresh, (hipStream_t)stream);
 }
 
 int ymi_mask_upsample_f32(const float *masks_lo, float *out, int N, int ph, int pw, int h, int w, float thresh,
                           void *stream) {
   if (!masks_lo || !out) return YMI_ENULL;
   if (N <= 0 || ph <= 0 || pw <= 0 || h <= 0 || w <= 0) return YMI_EARG;
+  static const bool flat = getenv("YOLACT_AMD_UPSAMPLE_FLAT") != nullptr;   // A/B switch for the measurement log
+  if (!flat)
+    return launch_upsample(masks_lo, out, nullptr, N, N, ph, pw, h, w, thresh, (hipStream_t)stream);
   const long total = (long)N * h * w, total4 = (total + 3) / 4;
   long g = (total4 + 255) / 256;
   const long cap = 256L * 16;

@@ -68,5 +68,64 @@ def postprocess(det_output, w, h, batch_idx=0, interpolation_mode='bilinear', vi
     return classes, scores, boxes_px, masks
 
 
+def postprocess_batch(dev_out, w, h, crop_masks=True):
+    """postprocess() for a whole batch with NO per-image Python loop and no host synchronisation: the fixed-capacity
+    device outputs of `Yolact.forward_device` (count [B], box [B,cap,4], score, cls, coef [B,cap,D], proto [B,ph,pw,D])
+    go through ONE lincomb+sigmoid+crop launch and ONE upsample+threshold launch (output_utils.py:69-99 per image in the
+    reference).  Returns fixed-capacity tensors: classes [B,cap] i64, scores [B,cap], boxes [B,cap,4] i64 pixels,
+    masks [B,cap,h,w] f32 {0,1}, count [B] i32; rows >= count[b] are unspecified.  `masks[b, :count[b]]` equals what
+    postprocess(preds, w, h, batch_idx=b) returns bit for bit (same kernels)."""
+    cfg = active_cfg()
+    if not (is_lincomb(cfg) and cfg.eval_mask_branch) or act_name(cfg.mask_proto_mask_activation) != 'sigmoid':
+        raise NotImplementedError('only mask_type.lincomb with sigmoid masks is on the hot path')
+    if getattr(cfg, 'use_maskiou', False):
+        raise NotImplementedError('YOLACT++ mask re-scoring runs per image: use postprocess()')
+    proto, coef, box, count = dev_out['proto'], dev_out['coef'], dev_out['box'], dev_out['count']
+    L.require_cuda(proto, "dev_out['proto']")
+    B, ph, pw, D = proto.shape
+    cap = coef.shape[1]
+    dev = proto.device
+    lib = L.lib()
+    with torch.cuda.device(dev):
+        s = L.stream_ptr()
+        masks_lo = torch.empty(B, cap, ph, pw, device=dev)
+        L.check(lib.ymi_lincomb_crop_batch_f32(proto.data_ptr(), coef.data_ptr(), box.data_ptr(), count.data_ptr(),
+                                               masks_lo.data_ptr(), B, cap, ph, pw, D, 1 if crop_masks else 0, s),
+                'ymi_lincomb_crop_batch_f32')
+        masks = torch.empty(B, cap, h, w, device=dev)
+        L.check(lib.ymi_mask_upsample_batch_f32(masks_lo.data_ptr(), count.data_ptr(), masks.data_ptr(), B, cap, ph, pw, h,
+                                                w, C.c_float(0.5), s), 'ymi_mask_upsample_batch_f32')
+        boxes_px = torch.empty(B, cap, 4, dtype=torch.int64, device=dev)
+        L.check(lib.ymi_boxes_to_pixels(box.data_ptr(), boxes_px.data_ptr(), B * cap, w, h, s), 'ymi_boxes_to_pixels')
+    return {'classes': dev_out['cls'], 'scores': dev_out['score'], 'boxes': boxes_px, 'masks': masks, 'count': count}
+
+
+MEANS = (103.94, 116.78, 123.68)     # data/config.py:28-29, BGR order
+STD = (57.38, 57.12, 58.40)
+
+
 def undo_image_transformation(img, w, h):
-    raise NotImplementedError('display helper (output_utils.py:128-144, needs cv2) — out of scope for the hot path')
+    """output_utils.py:128-144 (display helper of eval.py's prep_display when the frame was not kept): transformed
+    [3,H,W] tensor -> float RGB ndarray [h,w,3] in 0..1.  Host-side numpy like the reference; the final resize is
+    cv2.resize when OpenCV is installed, otherwise the same half-pixel bilinear mapping through torch."""
+    import numpy as np
+    cfg = active_cfg()
+    img_numpy = img.permute(1, 2, 0).cpu().numpy()
+    img_numpy = img_numpy[:, :, (2, 1, 0)]                      # to BGR
+    tr = cfg.backbone.transform
+    name = tr if isinstance(tr, str) else ('resnet' if tr.normalize else 'vgg' if tr.subtract_means else 'other')
+    if name == 'resnet':
+        img_numpy = (img_numpy * np.array(STD) + np.array(MEANS)) / 255.0
+    elif name == 'vgg':
+        img_numpy = (img_numpy / 255.0 + np.array(MEANS) / 255.0).astype(np.float32)
+    img_numpy = img_numpy[:, :, (2, 1, 0)]                      # to RGB
+    img_numpy = np.clip(img_numpy, 0, 1)
+    try:
+        import cv2
+        if hasattr(cv2, 'resize'):
+            return cv2.resize(img_numpy, (w, h))
+    except ImportError:
+        pass
+    t = torch.from_numpy(np.ascontiguousarray(img_numpy)).permute(2, 0, 1).unsqueeze(0)
+    t = torch.nn.functional.interpolate(t, (h, w), mode='bilinear', align_corners=False)
+    return t.squeeze(0).permute(1, 2, 0).contiguous().numpy()

@@ -46,14 +46,48 @@ def unpack_records(rec: torch.Tensor, D: int) -> List[Optional[Dict[str, torch.T
     return out
 
 
-def gather_records(rec: torch.Tensor, dst: int = 0) -> Optional[torch.Tensor]:
-    """The single collective of the path. Returns [world*B, ...] on dst, None elsewhere. No-op at world size 1."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+def pad_records(rec: torch.Tensor, rows: int) -> torch.Tensor:
+    """Pad a rank's [b, L] records to `rows` rows with count-0 records (an uneven last shard, e.g. 13 images over 4
+    ranks = 4,4,4,1): every rank must contribute the same number of bytes to the gather."""
+    if rec.shape[0] == rows:
+        return rec
+    if rec.shape[0] > rows:
+        raise ValueError('shard has %d records, expected at most %d' % (rec.shape[0], rows))
+    pad = torch.zeros(rows - rec.shape[0], rec.shape[1], dtype=rec.dtype, device=rec.device)
+    return torch.cat([rec, pad], 0)
+
+
+def gather_records(rec: torch.Tensor, dst: int = 0, rows_per_rank: Optional[int] = None, n_items: Optional[int] = None,
+                   force_collective: bool = False) -> Optional[torch.Tensor]:
+    """The single collective of the path: ONE dist.gather (RCCL over xGMI under the `nccl` backend) of the fixed-size
+    records to rank `dst`.  Returns [n, L] on dst (n = world * rows, trimmed to `n_items` when given), None elsewhere.
+
+    rows_per_rank: records every rank contributes (= ceil(global batch / world), the `per` of shard_range); a shorter
+    (last) shard is padded with count-0 records, which the trim removes.  Default: this rank's own row count, i.e. all
+    shards equal — checked, because a size mismatch inside an RCCL gather is undefined behaviour, not an error.
+    Without an initialised process group the records are returned as they are.  At world size 1 the gather is skipped
+    unless `force_collective` (or YOLACT_AMD_FORCE_GATHER=1): then the real collective runs with one rank, which is how
+    the single-GPU box exercises the RCCL code path."""
+    import os
+    if not (dist.is_available() and dist.is_initialized()):
         return rec
     world = dist.get_world_size()
+    force = force_collective or os.environ.get('YOLACT_AMD_FORCE_GATHER', '0') == '1'
+    if world == 1 and not force:
+        return rec
+    rows = int(rows_per_rank) if rows_per_rank is not None else int(rec.shape[0])
+    if rows_per_rank is None and world > 1:
+        # cheap consistency check (one tiny all_reduce of the row count) instead of undefined behaviour on mismatch
+        t = torch.tensor([rows, -rows], device=rec.device, dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if int(t[0]) != -int(t[1]):
+            raise RuntimeError('gather_records: ranks hold different numbers of records (%d..%d); pass rows_per_rank'
+                               % (-int(t[1]), int(t[0])))
+    rec = pad_records(rec.contiguous(), rows)
     if dist.get_rank() == dst:
         bufs = [torch.empty_like(rec) for _ in range(world)]
         dist.gather(rec, bufs, dst=dst)
-        return torch.cat(bufs, 0)
+        out = torch.cat(bufs, 0)
+        return out if n_items is None else out[:n_items]
     dist.gather(rec, None, dst=dst)
     return None
