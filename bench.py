@@ -11,6 +11,15 @@ then the single RCCL gather of detection records to rank 0 and the host read of 
 (what `Yolact.forward` must do to return the reference's dynamically-sized outputs).
 `--with-postprocess` adds postprocess() to 550x550 for every image (the reference's FPS definition).
 
+Launching: `python bench.py --gpus N` starts its N ranks ITSELF (re-exec under torch.distributed.run on 127.0.0.1) when it
+is not already running under a launcher; it refuses to run when the box has fewer than N GPUs or WORLD_SIZE disagrees
+with --gpus.  Every run — N = 1 included — initialises the `nccl` (= RCCL) process group and sends the detection records
+through the real `dist.gather`; the JSON carries `rccl_ranks` and `gathered_records` (= global batch) as the proof.
+`secondary` (N = 1): the same batch with postprocess() to 550x550 in the step, and the reference's own published-FPS
+definition (eval.py:264-281 prep_benchmark: batch 1, postprocess, top-k `.cpu().numpy()` copies, sync).
+Other BASELINE configs: `--config yolact_im700_config --batch 8` (configs[4], per-GPU share; size 700 is implied),
+`--config yolact_base_config --batch 16` (configs[2]), `--config yolact_plus_resnet50_config` (configs[3]).
+
 One JSON line on rank 0, with `roofline` (dominant conv kernel, live HIP-event timing on the launch stream) and,
 at N=1, `cpu_baseline` (the CPU oracle = port of the reference's path, timed on this host's cores).
 
@@ -47,6 +56,7 @@ def build_model(device, size, config=CONFIG):
     shapes = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
     sd = synth_state_dict(shapes, seed=0, conf_gain=0.04)      # ~70 % of priors over threshold
     net.load_state_dict_compat(sd)
+    net.detect.use_fast_nms = True                              # eval.py:871 (default --fast_nms); the class default is False
     return net.to(device), sd
 
 
@@ -132,24 +142,26 @@ def traffic_from_profiles(kernel):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md; tools/gpu_session_traffic.sh writes
     profiles/r01_traffic.json).  null when no PMC record exists for that kernel."""
-    path = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        rec = json.load(f).get(kernel)
-    return rec['bytes_per_launch'] if rec else None
+    for fn in ('r02_traffic.json', 'r01_traffic.json'):
+        path = os.path.join(ROOT, 'profiles', fn)
+        if os.path.exists(path):
+            with open(path) as f:
+                rec = json.load(f).get(kernel)
+            if rec:
+                return rec['bytes_per_launch']
+    return None
 
 
-def cpu_baseline(sd, size, budget_s=20.0):
+def cpu_baseline(sd, size, batch=8, budget_s=20.0):
     """The CPU oracle (port of the reference's forward + Detect) on this host's cores, bounded sample."""
     import yolact_amd
     from oracle import yolact_oracle as O
     from yolact_amd.utils.synth import synth_images
     cfg = yolact_amd.CONFIGS[CONFIG].copy()
     threads = torch.get_num_threads()
-    x = synth_images(2, size, size, seed=4321)
+    x = synth_images(batch, size, size, seed=1234)           # the very batch the GPU path is timed on
     with torch.no_grad():
-        O.detect(O.forward_raw(x, sd, cfg), cfg)            # warm-up
+        O.detect(O.forward_raw(x[:2], sd, cfg), cfg)         # warm-up (thread pool, oneDNN primitive cache)
         t0 = time.perf_counter()
         n = 0
         while True:
@@ -159,8 +171,77 @@ def cpu_baseline(sd, size, budget_s=20.0):
             if dt > budget_s or n >= 64:
                 break
     return {'value': round(n / dt, 3), 'unit': 'images/s', 'cores': threads, 'kind': 'port',
-            'sample': '%d images (batches of 2, %dx%d) forward+Detect through oracle/yolact_oracle.py, %.1f s, '
-                      'torch %s CPU fp32, os.cpu_count()=%s' % (n, size, size, dt, torch.__version__, os.cpu_count())}
+            'sample': '%d images (batches of %d = the timed workload, %dx%d) forward+Detect through '
+                      'oracle/yolact_oracle.py (the reference checkout does not exist on the GPU box, so this is the '
+                      'port, not eval.py itself), %.1f s, torch %s CPU fp32, os.cpu_count()=%s'
+                      % (n, batch, size, size, dt, torch.__version__, os.cpu_count())}
+
+
+def secondary_lines(net, x, size, steps=10):
+    """The reference's FPS definitions next to the headline (SURVEY 8(d) "Secondary"): (a) the same batch
+    with postprocess() to size x size inside the step (one lincomb + one upsample launch for the whole batch), (b) batch 1
+    end to end exactly like eval.py:264-281 prep_benchmark — forward, Detect, postprocess, the top-k (5) `.cpu().numpy()`
+    copies, synchronize — which is what the reference's published Titan Xp numbers measure."""
+    from yolact_amd.layers.output_utils import postprocess, postprocess_batch
+    out = {}
+
+    def timed(fn, n):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    B = x.shape[0]
+
+    def step_post():
+        o = net.forward_device(x)
+        r = postprocess_batch(o, size, size)
+        r['count'].tolist()
+
+    def step_fwd():
+        net.forward_device(x)['count'].tolist()
+    t_post = timed(step_post, steps)
+    t_fwd = timed(step_fwd, steps)
+    mask_bytes = float(net.forward_device(x)['count'].sum().item()) * size * size * 4
+    out['batch_with_postprocess'] = {
+        'value': round(B / t_post, 2), 'unit': 'images/s', 'ms_per_step': round(t_post * 1e3, 3),
+        'postprocess_ms_per_step': round((t_post - t_fwd) * 1e3, 3),
+        'mask_write_GBps': round(mask_bytes / max(t_post - t_fwd, 1e-9) / 1e9, 1),
+        'what': 'batch %d forward + Detect + postprocess to %dx%d (float32 {0,1} masks for every detection, %.0f MB '
+                'written per step) + host read of the counts' % (B, size, size, mask_bytes / 1e6)}
+    x1 = x[:1].contiguous()
+
+    def step_ref_fps():
+        preds = net(x1)
+        t = postprocess(preds, size, size, crop_masks=True, score_threshold=0)
+        classes, scores, boxes, masks = [v[:5] for v in t]
+        scores.cpu().numpy(); classes.cpu().numpy(); boxes.cpu().numpy(); masks.cpu().numpy()
+        torch.cuda.synchronize()
+    t1 = timed(step_ref_fps, 4 * steps)
+    out['reference_fps_definition_batch1'] = {
+        'value': round(1.0 / t1, 2), 'unit': 'images/s (FPS)', 'ms_per_image': round(t1 * 1e3, 3),
+        'what': 'eval.py:264-281 prep_benchmark: batch 1 net(x) + postprocess to %dx%d + top-5 .cpu().numpy() copies + '
+                'sync (the definition behind the reference README FPS column)' % (size, size)}
+    return out
+
+
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks ourselves (one process per GPU, RCCL rendezvous on
+    127.0.0.1) and exit with their status."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -169,98 +250,129 @@ def main():
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=8, help='images per GPU')
-    ap.add_argument('--size', type=int, default=550)
+    ap.add_argument('--size', type=int, default=0, help='input size (default: the config\'s max_size: 550, or 700 for im700)')
     ap.add_argument('--config', default=CONFIG, help='other BASELINE configs (parity-test cases; the metric is quoted on '
                     'the default yolact_resnet50_config)')
     ap.add_argument('--with-postprocess', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true')
     ap.add_argument('--layers', action='store_true', help='also print the per-layer conv table to stderr')
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
 
+    launched = 'WORLD_SIZE' in os.environ and 'RANK' in os.environ
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+        raise SystemExit('bench.py: --gpus %d requested but this box has %d visible GPU(s); refusing to report a '
+                         '%d-GPU number measured on fewer devices' % (args.gpus, n_dev, args.gpus))
+    if not launched and args.gpus > 1:
+        relaunch_under_torchrun(args)
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    if args.gpus != world and world > 1:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    if args.gpus != world:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))   # RCCL over xGMI
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    torch.cuda.set_device(dev)
+    rccl_error = None
+    if launched:
+        dist.init_process_group('nccl', device_id=dev)                                 # RCCL over xGMI
+    else:
+        # single process: still bring RCCL up (world 1) so the gather the path performs is the real collective
+        import socket
+        s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+        try:
+            dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1, device_id=dev)
+        except Exception as e:      # an RCCL-less box must still produce the single-GPU line; the JSON says so
+            rccl_error = '%s: %s' % (type(e).__name__, e)
 
+    import yolact_amd
     from yolact_amd import parallel
-    from yolact_amd.layers.output_utils import postprocess
+    from yolact_amd.layers.output_utils import postprocess_batch
     from yolact_amd.utils.synth import synth_images
+    size = args.size or int(yolact_amd.CONFIGS[args.config].max_size)
     with torch.no_grad():
-        net, sd = build_model(dev, args.size, args.config)
-        x = synth_images(args.batch, args.size, args.size, seed=1234 + rank).to(dev)   # resident in HBM
+        net, sd = build_model(dev, size, args.config)
+        x = synth_images(args.batch, size, size, seed=1234 + rank).to(dev)   # resident in HBM
+        have_pg = dist.is_initialized()
+        got = {'n': 0}
 
         def step():
             out = net.forward_device(x)
-            rec = parallel.gather_records(parallel.pack_records(out), dst=0)
+            rec = parallel.gather_records(parallel.pack_records(out), dst=0, force_collective=have_pg)
             if rec is not None:
                 counts = rec[:, 0].tolist()                         # host read of the per-image counts (rank 0)
+                got['n'] = len(counts)
             if args.with_postprocess:
-                n_local = out['count'].tolist()
-                for b, n in enumerate(n_local):
-                    if n:
-                        det = {'box': out['box'][b, :n], 'mask': out['coef'][b, :n], 'class': out['cls'][b, :n],
-                               'score': out['score'][b, :n], 'proto': out['proto'][b]}
-                        postprocess([{'detection': det, 'net': net}], args.size, args.size)
+                postprocess_batch(out, size, size)
             return rec
 
         for _ in range(args.warmup):
             step()
-        if world > 1:
+        if have_pg:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
-        if world > 1:
+        if have_pg:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if have_pg:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
 
         result = None
         if rank == 0:
+            if got['n'] != args.batch * world:
+                raise SystemExit('bench.py: rank 0 gathered %d records, expected %d' % (got['n'], args.batch * world))
+            plan = net.plan_for(x)
             rf, layers = roofline(net, x)
             imgs = args.batch * world * args.steps
+            is_headline = args.config == CONFIG and size == 550 and args.batch == 8
             result = {
-                'metric': 'images/sec (550x550, batch 8 per GPU), YOLACT ResNet50-FPN forward + Detect (Fast NMS)',
+                'metric': 'images/sec (%dx%d, batch %d per GPU), YOLACT %s forward + Detect (Fast NMS)'
+                          % (size, size, args.batch, args.config.replace('_config', '')),
                 'value': round(imgs / dt, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
                 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
                 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                 'config': {'workload': '%s%s, %dx%d, batch %d per GPU, random-init '
                                        'weights (no checkpoint offline), inputs resident in HBM'
-                                       % ('configs[1]: ' if args.config == CONFIG else '', args.config, args.size, args.size,
-                                          args.batch),
+                                       % ('configs[1]: ' if is_headline else '', args.config, size, size, args.batch),
                            'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
-                           'postprocess_in_step': bool(args.with_postprocess)},
+                           'postprocess_in_step': bool(args.with_postprocess),
+                           'plan': {'source': 'shipped tune table yolact_amd/tune/gfx950.json' if plan.tune_misses == 0
+                                    else 'tune table + %d shapes measured in this process' % plan.tune_misses,
+                                    'tune_misses': plan.tune_misses}},
+                'rccl_ranks': dist.get_world_size() if have_pg else 0,
+                'gathered_records': got['n'],
+                'collective': ('dist.gather over the nccl (RCCL) backend, %d rank(s)' % dist.get_world_size()) if have_pg
+                              else 'none (RCCL init failed: %s)' % rccl_error,
                 'roofline': rf,
             }
             result['roofline']['all_conv']['sustained_tflops_in_timed_region'] = round(
                 rf['all_conv']['gflop_per_step'] / (dt / args.steps * 1e3), 2)
             if args.layers:
-                for name, best, times in getattr(net.plan_for(x), 'tune_table', []):
+                for name, best, times in getattr(plan, 'tune_table', []):
                     print('tune %-20s -> %-8s %s' % (name, best, times), file=sys.stderr)
-                for name, best, t_dir, t_win, t_f2, t_f4 in getattr(net.plan_for(x), 'wino_table', []):
+                for name, best, t_dir, t_win, t_f2, t_f4 in getattr(plan, 'wino_table', []):
                     print('wino %-20s -> %-14s direct %.4f ms  F(2x2) %.4f  F(4x4) %.4f%s' % (
                         name, best, t_dir, t_f2, t_f4, '' if t_win < 0.97 * t_dir else '   (kept direct)'), file=sys.stderr)
                 for k, (ms, fl, kern) in layers.items():
                     print('%-22s %8.3f ms %8.2f GFLOP %7.1f TF/s  %s' % (k, ms, fl / 1e9, fl / ms / 1e9, kern),
                           file=sys.stderr)
+            if world == 1 and not args.no_secondary and not getattr(yolact_amd.CONFIGS[args.config], 'use_maskiou', False):
+                result['secondary'] = secondary_lines(net, x, size)
         if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == CONFIG:
-            result['cpu_baseline'] = cpu_baseline(sd, args.size)
+            result['cpu_baseline'] = cpu_baseline(sd, size, args.batch)
         if rank == 0:
             print(json.dumps(result))
-    if world > 1:
+    if have_pg:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -56,3 +56,18 @@ def test_cli_defaults():
     assert out.returncode == 0
     for flag in ('--gpus', '--steps', '--warmup'):
         assert flag in out.stdout
+
+
+def test_refuses_more_gpus_than_the_box_has():
+    """`python bench.py --gpus N` must never print an N-GPU line measured on fewer devices (round-1 verdict, Weak 4):
+    this container has no GPU, so any N is refused with a non-zero exit and a message that says why."""
+    for n in ('1', '2', '8'):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', n], capture_output=True, text=True,
+                             timeout=300)
+        assert out.returncode != 0
+        assert 'visible GPU' in (out.stderr + out.stdout) and '--gpus %s' % n in (out.stderr + out.stdout)
+        assert '"value"' not in out.stdout
+    env = dict(os.environ, WORLD_SIZE='4', RANK='0')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '0'], capture_output=True, text=True,
+                         timeout=300, env=env)
+    assert out.returncode != 0

@@ -1,0 +1,50 @@
+"""The multi-GPU exchange step on real RCCL: a one-GPU box still runs the `nccl` backend with world size 1 (SURVEY 8(e):
+"World-size-1 RCCL (degenerate gather) still exercises the code path").  pack -> dist.gather -> unpack must reproduce what
+Detect.finish returns for the same device outputs."""
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda:0'
+
+
+def test_world1_nccl_gather_roundtrip_equals_detect_finish():
+    import torch.distributed as dist
+    from gpu_utils import build_net
+    from helpers import case_images, load_golden
+    from yolact_amd import parallel
+    meta, _ = load_golden('r50_dense')
+    net = build_net(meta)
+    x = case_images(meta).to(DEV)
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    assert not dist.is_initialized()
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1,
+                            device_id=torch.device(DEV))
+    try:
+        assert dist.get_backend() == 'nccl' and dist.get_world_size() == 1
+        dev_out = net.forward_device(x)
+        rec = parallel.pack_records(dev_out)
+        same = parallel.gather_records(rec, dst=0)                         # world 1, not forced: passthrough
+        assert same is rec
+        got = parallel.gather_records(rec, dst=0, force_collective=True)   # the real collective, one rank
+        torch.cuda.synchronize()
+        assert got is not rec and got.shape == rec.shape and torch.equal(got, rec)
+        # uneven-shard form: pad to 4 rows per rank, trim to the 2 real images
+        got4 = parallel.gather_records(rec, dst=0, rows_per_rank=4, n_items=meta['B'], force_collective=True)
+        assert torch.equal(got4, rec)
+        dets = parallel.unpack_records(got, dev_out['coef'].shape[2])
+        ref = net.detect.finish(dev_out, dev_out['proto'], net)
+        assert len(dets) == len(ref) == meta['B']
+        for d, r in zip(dets, ref):
+            r = r['detection']
+            assert (d is None) == (r is None)
+            if d is not None:
+                for k in ('box', 'score', 'class', 'mask'):
+                    assert torch.equal(d[k], r[k]), k
+                assert d['class'].dtype == torch.int64
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()

@@ -28,6 +28,7 @@
 // activation, scatter to up to 3 output segments with independent strides.
 #include "common.h"
 #include <stdlib.h>
+#include <mutex>
 #include "../../include/yolact_amd.h"
 
 namespace {
@@ -647,6 +648,8 @@ ProfRec g_prof[PROF_MAX];
 unsigned long long *g_trace = nullptr;
 long g_trace_cap = 0;
 int g_prof_n = 0, g_prof_alloc = 0, g_prof_on = 0;
+std::mutex g_prof_mu;   // the opt-in profiling records are process-global: threaded callers (eval.py's evalvideo pool) may
+                        // launch concurrently, so slot allocation is serialised; with profiling off nothing is locked
 
 // The workgroup dispatcher does not balance a grid that fits in one residency round: it packs up to `occupancy`
 // blocks on a CU while others hold fewer (a 616-block layer ran as if its busiest CU held 4+ blocks, not 3).  When
@@ -761,6 +764,19 @@ int validate(const ymi_conv_desc *d, int loader) {
   if (d->nseg < 1 || d->nseg > 3) return YMI_EARG;
   for (int s = 0; s < d->nseg; ++s) if (!d->seg[s].ptr) return YMI_ENULL;
   if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0 || d->Ho <= 0 || d->Wo <= 0) return YMI_EARG;
+  if (d->stride <= 0 || d->kh <= 0 || d->kw <= 0 || d->pad < 0 || d->Cin <= 0) return YMI_EARG;   // (a C caller must get
+                                                                                 // an error code, never a SIGFPE)
+  // output segments: ascending, non-overlapping channel ranges inside [0, Cout]; a row must hold the segment
+  for (int s = 0; s < d->nseg; ++s) {
+    const ymi_conv_seg &g = d->seg[s];
+    if (g.n0 < 0 || g.n1 <= g.n0 || g.n0 >= d->Cout) return YMI_EARG;
+    if (s > 0 && g.n0 < d->seg[s - 1].n1) return YMI_EARG;
+    const int width = (g.n1 < d->Cout ? g.n1 : d->Cout) - g.n0;
+    if (g.row_stride < width || g.batch_stride < 0) return YMI_ESHAPE;
+  }
+  if (d->res_mode != YMI_RES_NONE && d->res_mode != YMI_RES_ADD && d->res_mode != YMI_RES_BILINEAR) return YMI_EARG;
+  if (d->res_mode != YMI_RES_NONE && d->res_ld < d->Cout) return YMI_ESHAPE;
+  if (d->res_mode == YMI_RES_BILINEAR && (d->res_H <= 0 || d->res_W <= 0)) return YMI_EARG;
   if (d->ldx % 4 != 0 || d->Kpad % 32 != 0 || d->Kpad < d->kh * d->kw * d->Cin) return YMI_ESHAPE;
   if (loader == 1) { if (d->Cin != 4) return YMI_ESHAPE; }
   else if (d->Cin % 32 != 0) return YMI_ESHAPE;
@@ -810,11 +826,15 @@ int run_conv(const ymi_conv_desc *d, int loader, const float *offmask, int ldo, 
     tile = YMI_TILE_64x64;
   }
   ProfRec *pr = nullptr;
-  if (g_prof_on && g_prof_n < PROF_MAX) {
-    pr = &g_prof[g_prof_n];
-    if (g_prof_n >= g_prof_alloc) { hipEventCreate(&pr->e0); hipEventCreate(&pr->e1); g_prof_alloc = g_prof_n + 1; }
-    pr->flops = prof_flops >= 0 ? prof_flops : ymi_conv_flops(d); pr->tile = tile; pr->kind = prof_kind >= 0 ? prof_kind : loader;
-    hipEventRecord(pr->e0, s);
+  std::unique_lock<std::mutex> prof_lock(g_prof_mu, std::defer_lock);
+  if (g_prof_on) {
+    prof_lock.lock();            // held across the launch so e0 / launch / e1 of one record stay together on the stream
+    if (g_prof_n < PROF_MAX) {
+      pr = &g_prof[g_prof_n];
+      if (g_prof_n >= g_prof_alloc) { hipEventCreate(&pr->e0); hipEventCreate(&pr->e1); g_prof_alloc = g_prof_n + 1; }
+      pr->flops = prof_flops >= 0 ? prof_flops : ymi_conv_flops(d); pr->tile = tile; pr->kind = prof_kind >= 0 ? prof_kind : loader;
+      hipEventRecord(pr->e0, s);
+    }
   }
   switch (tile) {
 #define X(id, wm, wn, wk, tm, tn, ns, all) case id: rc = launch_cfg<wm, wn, wk, tm, tn, ns, all>(kp, loader, s, groups); break;
@@ -831,7 +851,9 @@ int run_conv(const ymi_conv_desc *d, int loader, const float *offmask, int ldo, 
 // internal (not part of the C ABI): profiling brackets for composite ops (csrc/winograd.hip): a record that spans
 // several launches.  Returns the record index or -1 when profiling is off.
 int ymi_internal_prof_begin(double flops, int tile, int kind, hipStream_t s) {
-  if (!g_prof_on || g_prof_n >= PROF_MAX) return -1;
+  if (!g_prof_on) return -1;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (g_prof_n >= PROF_MAX) return -1;
   ProfRec *pr = &g_prof[g_prof_n];
   if (g_prof_n >= g_prof_alloc) { hipEventCreate(&pr->e0); hipEventCreate(&pr->e1); g_prof_alloc = g_prof_n + 1; }
   pr->flops = flops; pr->tile = tile; pr->kind = kind;
@@ -876,7 +898,7 @@ int ymi_debug_set_trace(void *buf, long cap_blocks) {
 
 int ymi_prof_enable(int on) { g_prof_on = on; return YMI_OK; }
 int ymi_prof_count(void) { return g_prof_n; }
-int ymi_prof_reset(void) { g_prof_n = 0; return YMI_OK; }
+int ymi_prof_reset(void) { std::lock_guard<std::mutex> lk(g_prof_mu); g_prof_n = 0; return YMI_OK; }
 int ymi_prof_read(int i, float *ms, double *flops, int32_t *tile, int32_t *kind) {
   if (i < 0 || i >= g_prof_n) return YMI_EARG;
   hipError_t e = hipEventSynchronize(g_prof[i].e1);
