@@ -71,7 +71,12 @@ enum { YMI_TILE_AUTO = 0, YMI_TILE_128x128 = 1, YMI_TILE_128x64 = 2, YMI_TILE_64
        YMI_TILE_64x64_S3 = 9, YMI_TILE_64x64_S4 = 10, YMI_TILE_64x128_S3 = 11, YMI_TILE_128x64_S3 = 12,
        YMI_TILE_32x32_K4_S4 = 13, YMI_TILE_64x32_K2_S3 = 14, YMI_TILE_32x64_K2_S3 = 15,
        /* _W8 = 512-thread blocks (8 waves): half the global->LDS traffic per FLOP of the 4-wave tile of equal wave tile */
-       YMI_TILE_128x128_W8 = 16, YMI_TILE_256x128_W8 = 17, YMI_TILE_128x256_W8 = 18 };
+       YMI_TILE_128x128_W8 = 16, YMI_TILE_256x128_W8 = 17, YMI_TILE_128x256_W8 = 18,
+       /* tile | YMI_TILE_X3: the same block tile computed as "bf16x3" — every fp32 operand split exactly into three bf16
+        * pieces (24 mantissa bits), 6 of the 9 piece products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the
+        * dropped terms are <= 3 * 2^-24 |a b| (one fp32 rounding of the product).  Cin % 32 == 0 layers; available for
+        * tiles 1, 2, 3, 5, 6, 7, 8, 9, 11, 12, 16. */
+       YMI_TILE_X3 = 32 };
 
 int ymi_abi_version(void);
 const char *ymi_strerror(int code);

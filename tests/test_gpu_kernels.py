@@ -296,3 +296,25 @@ def test_winograd_head_segments_and_tanh(m):
 def test_winograd_rejects_unsupported():
     d = L.WinoDesc()
     assert L.lib().ymi_conv3x3_winograd_f32(C.byref(d), L.stream_ptr()) != 0
+
+
+@pytest.mark.parametrize('base', [3, 5, 1, 8, 16])
+def test_conv_bf16x3_is_fp32_class(base):
+    """tile | TILE_X3: every operand split exactly into three bf16 pieces, 6 piece products on the bf16 matrix pipe.  The error
+    against an fp64 reference must be of the exact-fp32 kernel's own class (both ~1e-7 of sum|a b|), over a K = 2304
+    reduction with operands of mixed magnitude (incl. values far below / above the bf16-friendly range)."""
+    from gpu_utils import run_conv
+    g = _g(90 + base)
+    B, Cin, H, W, Cout, k = 2, 256, 13, 11, 192, 3
+    x = torch.randn(B, Cin, H, W, generator=g) * torch.exp(torch.randn(B, Cin, 1, 1, generator=g) * 2.0)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    x[0, 0, 0, 0], x[0, 1, 2, 3], w[0, 0, 0, 0], w[5, 7, 1, 1] = 1e-30, 3.0e4, -2.5e-22, 40.0
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    mag = F.conv2d(x.double().abs(), w.double().abs(), None, 1, 1)
+    y32 = run_conv(x, w, None, None, 1, 1, tile=base).double()
+    yx3 = run_conv(x, w, None, None, 1, 1, tile=base | L.TILE_X3).double()
+    e32 = ((y32 - ref).abs() / mag).max().item()
+    ex3 = ((yx3 - ref).abs() / mag).max().item()
+    print('tile %s: fp32 MFMA err %.2e, bf16x3 err %.2e (of sum|ab|)' % (L.TILE_NAMES[base], e32, ex3))
+    assert e32 < 5e-7 and ex3 < 5e-7
+    assert ex3 < 4 * e32 + 1e-7

@@ -65,7 +65,7 @@ __device__ __forceinline__ f32x16 mma6(const Split3 &a, const Split3 &b, f32x16 
 // A, B: [rows][32] fp32 in global (row-major, k contiguous).  planes: [3][rows][32] bf16 bit patterns (u16).
 // LDS fp32 image: [row][32], 16-byte slots XOR-swizzled by (row>>1)&7 (the engine's layout).
 // LDS plane image: [3][row][32 bf16] = 64-byte rows, 16-byte slots XOR-swizzled by (row>>2)&3.
-template <int MODE, int TM, int TN>
+template <int MODE, int TM, int TN, int ORDER>
 __global__ __launch_bounds__(256) void probe_k(const float *__restrict__ A, const float *__restrict__ B,
                                                const unsigned short *__restrict__ Ap, const unsigned short *__restrict__ Bp,
                                                float *__restrict__ Cout, int iters, int write_c) {
@@ -159,10 +159,23 @@ __global__ __launch_bounds__(256) void probe_k(const float *__restrict__ A, cons
                           *reinterpret_cast<const f32x4 *>(p + 4 * ((4 * s + 2 * hh + 1) ^ fsw)));
           }
         }
+        if (ORDER == 0) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+          for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = mma6(a[i], b[j], acc[i][j]);
+            for (int j = 0; j < TN; ++j) acc[i][j] = mma6(a[i], b[j], acc[i][j]);
+        } else {        // product-major: consecutive MFMAs on different accumulators
+#pragma unroll
+          for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j) {
+                const bf16x8 fa_ = pr == 0 ? a[i].h : pr == 1 ? a[i].l : pr == 2 ? a[i].m : pr == 3 ? a[i].h : pr == 4 ? a[i].m : a[i].h;
+                const bf16x8 fb_ = pr == 0 ? b[j].l : pr == 1 ? b[j].h : pr == 2 ? b[j].m : pr == 3 ? b[j].m : pr == 4 ? b[j].h : b[j].h;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_, fb_, acc[i][j], 0, 0, 0);
+              }
+        }
       }
     }
   }
@@ -203,15 +216,16 @@ static void make_planes(const std::vector<float> &X, int rows, std::vector<unsig
   }
 }
 
-template <int MODE, int TM, int TN>
+template <int MODE, int TM, int TN, int ORDER = 0>
 void run(const char *name, int cus, bool first) {
   constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
   std::vector<float> A(BM * BK), B(BN * BK);
   srand(7);
-  for (auto &v : A) v = (float)rand() / RAND_MAX * 2.f - 1.f;
-  for (auto &v : B) v = ((float)rand() / RAND_MAX * 2.f - 1.f) * 0.05f;
+  const bool zeros = getenv("SPLIT_PROBE_ZEROS") != nullptr;   // zero operands: same instruction stream at the un-throttled clock
+  for (auto &v : A) v = zeros ? 0.f : (float)rand() / RAND_MAX * 2.f - 1.f;
+  for (auto &v : B) v = zeros ? 0.f : ((float)rand() / RAND_MAX * 2.f - 1.f) * 0.05f;
   // a few tiny / large magnitudes to exercise the exponent range of the pieces
-  A[3] = 1e-20f; A[40] = 3.0e4f; B[5] = -2.5e-12f; B[77] = 17.f;
+  if (!zeros) { A[3] = 1e-20f; A[40] = 3.0e4f; B[5] = -2.5e-12f; B[77] = 17.f; }
   std::vector<unsigned short> Ap, Bp;
   make_planes(A, BM, Ap); make_planes(B, BN, Bp);
   float *dA, *dB, *dC; unsigned short *dAp, *dBp;
@@ -221,7 +235,7 @@ void run(const char *name, int cus, bool first) {
   CK(hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(dAp, Ap.data(), Ap.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dBp, Bp.data(), Bp.size() * 2, hipMemcpyHostToDevice));
   // numerics: one K chunk, compare with fp64
-  hipLaunchKernelGGL((probe_k<MODE, TM, TN>), dim3(1), dim3(256), 0, 0, dA, dB, dAp, dBp, dC, 1, 1);
+  hipLaunchKernelGGL((probe_k<MODE, TM, TN, ORDER>), dim3(1), dim3(256), 0, 0, dA, dB, dAp, dBp, dC, 1, 1);
   CK(hipDeviceSynchronize());
   std::vector<float> C(BM * BN);
   CK(hipMemcpy(C.data(), dC, C.size() * 4, hipMemcpyDeviceToHost));
@@ -238,10 +252,10 @@ void run(const char *name, int cus, bool first) {
   const int iters = 4000;
   for (int bpc = 1; bpc <= 3; ++bpc) {
     const int blocks = cus * bpc;
-    hipLaunchKernelGGL((probe_k<MODE, TM, TN>), dim3(blocks), dim3(256), 0, 0, dA, dB, dAp, dBp, dC, 200, 0);
+    hipLaunchKernelGGL((probe_k<MODE, TM, TN, ORDER>), dim3(blocks), dim3(256), 0, 0, dA, dB, dAp, dBp, dC, 200, 0);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL((probe_k<MODE, TM, TN>), dim3(blocks), dim3(256), 0, 0, dA, dB, dAp, dBp, dC, iters, 0);
+    hipLaunchKernelGGL((probe_k<MODE, TM, TN, ORDER>), dim3(blocks), dim3(256), 0, 0, dA, dB, dAp, dBp, dC, iters, 0);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double fl = 2.0 * BM * BN * BK * (double)iters * blocks;     // fp32-equivalent FLOPs
@@ -263,6 +277,9 @@ int main() {
   run<2, 1, 2>("bf16x3_Bplanes_64x128", cus, false);
   run<3, 2, 2>("bf16x3_ABplanes_128x128", cus, false);
   run<3, 1, 2>("bf16x3_ABplanes_64x128", cus, false);
+  run<1, 2, 2, 1>("bf16x3_fly_128x128_prodmajor", cus, false);
+  run<1, 1, 2, 1>("bf16x3_fly_64x128_prodmajor", cus, false);
+  run<3, 2, 2, 1>("bf16x3_ABplanes_128x128_prodmajor", cus, false);
   printf("}\n");
   return 0;
 }

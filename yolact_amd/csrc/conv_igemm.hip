@@ -37,6 +37,41 @@ constexpr int BK = 32;
 constexpr unsigned OOB = 0x80000000u;  // buffer offset >= num_records (< 2^31, validated) -> the load returns zeros
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// ---- PREC = 1: fp32-class products on the bf16 matrix pipe ("bf16x3") -------------------------------------------------
+// x = h + m + l exactly, three bf16 pieces taken by TRUNCATION (8 + 8 + 8 = 24 significant bits; bf16 has the fp32
+// exponent range, so no scaling and no overflow / underflow cases beyond fp32's own).  a*b = sum of 9 piece products, each
+// EXACT in the fp32 accumulate of v_mfma_f32_32x32x16_bf16 (8 x 8 bits); the three smallest (m*l, l*m, l*l <= 3 * 2^-24 |ab|)
+// are dropped, which is the size of ONE fp32 rounding of the product — the error class of the exact-fp32 MFMA itself
+// (tools/split_probe.hip measures both against fp64).  6 bf16 MFMAs at 16x the fp32-MFMA rate = 0.375x the matrix-pipe
+// time; the split costs 4 VALU + 1.5 v_perm per element on the separate VALU pipe.
+struct Split3 { bf16x8 h, m, l; };
+
+__device__ __forceinline__ Split3 split8(const f32x4 x0, const f32x4 x1) {
+  const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+  unsigned r1[8], r2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float h = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x[e]) & 0xFFFF0000u);
+    const float r = x[e] - h;                                   // exact: the low 16 mantissa bits
+    r1[e] = __builtin_bit_cast(unsigned, r);
+    const float m = __builtin_bit_cast(float, r1[e] & 0xFFFF0000u);
+    r2[e] = __builtin_bit_cast(unsigned, r - m);               // exact, <= 8 significant bits: already a bf16 value
+  }
+  u32x4 ph, pm, pl;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {                                 // {odd[31:16], even[31:16]}
+    ph[q] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, x[2 * q + 1]), __builtin_bit_cast(unsigned, x[2 * q]), 0x07060302u);
+    pm[q] = __builtin_amdgcn_perm(r1[2 * q + 1], r1[2 * q], 0x07060302u);
+    pl[q] = __builtin_amdgcn_perm(r2[2 * q + 1], r2[2 * q], 0x07060302u);
+  }
+  Split3 s;
+  s.h = __builtin_bit_cast(bf16x8, ph); s.m = __builtin_bit_cast(bf16x8, pm); s.l = __builtin_bit_cast(bf16x8, pl);
+  return s;
+}
+
 
 struct KParams {
   ymi_conv_desc d;
@@ -171,19 +206,22 @@ __device__ __forceinline__ void epilogue_general(const KParams &p, const float *
 //         what the layers whose grid gives each CU only 1-3 blocks need.
 // blocks per CU the LDS footprint allows (= waves per SIMD for 256-thread blocks): the register budget handed to the
 // compiler, so that the epilogue's prefetch registers never cost a resident block
-template <int WM, int WN, int WK, int TM, int TN, int NSTAGE, int LOADER>
+template <int WM, int WN, int WK, int TM, int TN, int NSTAGE, int LOADER, int PREC>
 constexpr int conv_occupancy() {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int ns = (LOADER == 2) ? 2 : NSTAGE;
   constexpr int stage_b = ns * (BM + BN) * BK * WK * 4, epi_b = WK * BM * (BN + 4) * 4;
   constexpr int lds_b = stage_b > epi_b ? stage_b : epi_b;
   constexpr int occ = (160 * 1024) / lds_b;
-  constexpr int cap = (LOADER == 2) ? 3 : 5;     // the DCN gather keeps per-tap geometry in registers: no spills
+  // the DCN gather keeps per-tap geometry in registers; the bf16x3 path holds 12 registers of split pieces per 32-row
+  // fragment on top of the raw fp32 fragment: budget registers (= blocks per CU) so that neither spills
+  constexpr int cap = (LOADER == 2) ? 3
+                      : (PREC == 1 ? (WM * WN * WK == 8 ? 1 : (TM * TN >= 4 ? 2 : (TM * TN == 2 ? 3 : 4))) : 5);
   return occ > cap ? cap : (occ < 1 ? 1 : occ);
 }
 
-template <int WM, int WN, int WK, int TM, int TN, int NSTAGE, int LOADER>
-__global__ __launch_bounds__(64 * WM * WN * WK, (conv_occupancy<WM, WN, WK, TM, TN, NSTAGE, LOADER>() * (WM * WN * WK) / 4))
+template <int WM, int WN, int WK, int TM, int TN, int NSTAGE, int LOADER, int PREC>
+__global__ __launch_bounds__(64 * WM * WN * WK, (conv_occupancy<WM, WN, WK, TM, TN, NSTAGE, LOADER, PREC>() * (WM * WN * WK) / 4))
 void conv_igemm_f32(const KParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // host pass: empty body.  hipcc (ROCm 7.2) silently drops the host launch stub of a
                                       // templated kernel whose body uses the buffer-resource LDS-DMA builtins.
@@ -201,6 +239,7 @@ void conv_igemm_f32(const KParams p) {
   static_assert(DMA_PER_STEP * (NS - 2) <= 63, "vmcnt is a 6-bit counter");
   static_assert(WM * WN * WK == 4 || WM * WN * WK == 8, "4 or 8 waves per block");
   static_assert(LOADER != 2 || WK == 1, "DCN gather runs without the K split");
+  static_assert(PREC == 0 || LOADER == 0 || LOADER == 3, "the bf16x3 path exists for the LDS-DMA loaders only");
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
   const ymi_conv_desc &d = p.d;
@@ -486,6 +525,76 @@ void conv_igemm_f32(const KParams p) {
       }
     }
   };
+  // ---- PREC == 1: the same chunk as 2 steps of 16 k; lane half h of step s holds k = 16 s + 8 h .. + 7 = logical 16-byte
+  // slots 4s + 2h and 4s + 2h + 1 of its row (A and B agree on the K order, which is all a dot product needs).
+  // Raw fp32 fragments of step s + 1 are requested right after step s has been split, so their LDS latency and the
+  // splitting VALU work of the next step overlap this step's 6 * TM * TN bf16 MFMAs (VALU and matrix pipes are separate).
+  f32x4 rwa[PREC == 1 ? TM : 1][2], rwb[PREC == 1 ? TN : 1][2];
+  int fo2[2][2];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) fo2[s2][q] = frag_row + 4 * ((4 * s2 + 2 * hh_ + q) ^ fsw);
+  auto load_raw = [&](int buf, int s2) {
+    const float *As = lds + buf * STAGE + wk * SUB + (wm * TM * 32) * BK;
+    const float *Bs = lds + buf * STAGE + wk * SUB + BM * BK + (wn * TN * 32) * BK;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      rwa[i][0] = *reinterpret_cast<const f32x4 *>(As + i * 32 * BK + fo2[s2][0]);
+      rwa[i][1] = *reinterpret_cast<const f32x4 *>(As + i * 32 * BK + fo2[s2][1]);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      rwb[j][0] = *reinterpret_cast<const f32x4 *>(Bs + j * 32 * BK + fo2[s2][0]);
+      rwb[j][1] = *reinterpret_cast<const f32x4 *>(Bs + j * 32 * BK + fo2[s2][1]);
+    }
+  };
+  auto compute_x3 = [&](int buf, bool stage_next, int nst, int nbuf) {
+    constexpr int NPOS = 12 * TM * TN;         // hook positions: behind every MFMA
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      Split3 xa[TM], xb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) xa[i] = split8(rwa[i][0], rwa[i][1]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) xb[j] = split8(rwb[j][0], rwb[j][1]);
+      if (s2 == 0) load_raw(buf, 1);
+      // product-major order: consecutive MFMAs hit different accumulators (no back-to-back dependent issue); per
+      // accumulator the small cross terms still come first and the dominant h*h product last
+#pragma unroll
+      for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const bf16x8 fa_ = pr == 0 ? xa[i].h : pr == 1 ? xa[i].l : pr == 2 ? xa[i].m : pr == 3 ? xa[i].h : pr == 4 ? xa[i].m : xa[i].h;
+            const bf16x8 fb_ = pr == 0 ? xb[j].l : pr == 1 ? xb[j].h : pr == 2 ? xb[j].m : pr == 3 ? xb[j].m : pr == 4 ? xb[j].h : xb[j].h;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_, fb_, acc[i][j], 0, 0, 0);
+            const int pos = ((s2 * 6 + pr) * TM + i) * TN + j;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+              if ((NPOS * q) / NP == pos) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (stage_next) issue_piece(nst, nbuf, q);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+          }
+    }
+  };
+  // precision-independent entry points of the main loop
+  auto prefetch_frags = [&](int buf) {
+    if constexpr (PREC == 1) {
+      load_raw(buf, 0);
+    } else {
+      load_frag(buf, 0, 0);
+      load_frag(buf, 1, 1);
+    }
+  };
+  auto compute_chunk = [&](int buf, bool stage_next, int nst, int nbuf) {
+    if constexpr (PREC == 1) compute_x3(buf, stage_next, nst, nbuf);
+    else compute(buf, stage_next, nst, nbuf);
+  };
   // a wave without a chunk of its own in a ragged K-split step still stages its share
   auto stage_only = [&](int nst, int nbuf) {
 #pragma unroll
@@ -507,10 +616,7 @@ void conv_igemm_f32(const KParams p) {
       const int cur = st & 1;
       const bool more = (st + 1) < nsteps;
       const bool mine = (WK == 1) || (st * WK + wk < p.nk);   // wave-uniform: does this wave's chunk exist?
-      if (mine) {
-        load_frag(cur, 0, 0);
-        load_frag(cur, 1, 1);
-      }
+      if (mine) prefetch_frags(cur);
       __builtin_amdgcn_sched_barrier(0);
       const bool stage = more && !(p.abl & 1);
       if (LOADER == 2) {
@@ -518,7 +624,7 @@ void conv_igemm_f32(const KParams p) {
         __builtin_amdgcn_sched_barrier(0);
         compute(cur, false, 0, 0);
       } else if (mine) {
-        compute(cur, stage, st + 1, cur ^ 1);
+        compute_chunk(cur, stage, st + 1, cur ^ 1);
       } else if (stage) {
         stage_only(st + 1, cur ^ 1);
       }
@@ -543,13 +649,10 @@ void conv_igemm_f32(const KParams p) {
     int cur = 0, nxt = NS - 1;   // stage of step st, stage to refill (= stage of step st + NS - 1)
     for (int st = 0; st < nsteps; ++st) {
       const bool mine = (WK == 1) || (st * WK + wk < p.nk);
-      if (mine) {
-        load_frag(cur, 0, 0);
-        load_frag(cur, 1, 1);
-      }
+      if (mine) prefetch_frags(cur);
       __builtin_amdgcn_sched_barrier(0);
       const bool stage = st + NS - 1 < nsteps && !(p.abl & 1);
-      if (mine) compute(cur, stage, st + NS - 1, nxt);
+      if (mine) compute_chunk(cur, stage, st + NS - 1, nxt);
       else if (stage) stage_only(st + NS - 1, nxt);
       if (st + 1 < nsteps) {
         const int rem = nsteps - 2 - st;                        // steps issued beyond st+1
@@ -657,7 +760,7 @@ std::mutex g_prof_mu;   // the opt-in profiling records are process-global: thre
 // the block's LDS allocation with unused dynamic LDS, so no CU can take more than its share.
 constexpr int LDS_PER_CU = 160 * 1024, NUM_CU = 256;
 
-template <int WM, int WN, int WK, int TM, int TN, int NS, bool ALL_LOADERS>
+template <int WM, int WN, int WK, int TM, int TN, int NS, bool ALL_LOADERS, int PREC>
 int launch_cfg(const KParams &kp, int loader, hipStream_t s, int groups) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int ns_eff_bytes = NS * (BM + BN) * BK * WK * 4, epi_bytes = WK * BM * (BN + 4) * 4;
@@ -669,7 +772,11 @@ int launch_cfg(const KParams &kp, int loader, hipStream_t s, int groups) {
   if (p.trace && (grid > g_trace_cap || groups > 1)) p.trace = nullptr;
   int dyn = 0;
   {
-    const int occ = LDS_PER_CU / static_lds;               // LDS-limited residency (VGPRs allow >= this for every tile)
+    int occ = LDS_PER_CU / static_lds;                     // LDS-limited residency (VGPRs allow >= this for every fp32 tile)
+    if (PREC == 1) {
+      constexpr int occ_regs = conv_occupancy<WM, WN, WK, TM, TN, NS, 0, PREC>();
+      occ = occ < occ_regs ? occ : occ_regs;
+    }
     const int k = (grid * groups + NUM_CU - 1) / NUM_CU;    // blocks per CU if perfectly spread
     if (k < occ && !(p.abl & 8)) {
       const int want = LDS_PER_CU / (k + 1) + 1024;         // > 160K/(k+1)  =>  at most k blocks fit
@@ -677,42 +784,54 @@ int launch_cfg(const KParams &kp, int loader, hipStream_t s, int groups) {
     }
   }
   if (loader == 0 && groups > 1) {
-    hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, NS, 3>), dim3(grid, groups), dim3(64 * WM * WN * WK), dyn, s, p);
+    hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, NS, 3, PREC>), dim3(grid, groups), dim3(64 * WM * WN * WK), dyn, s, p);
   } else if (loader == 0) {
-    hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, NS, 0>), dim3(grid, groups), dim3(64 * WM * WN * WK), dyn, s, p);
-  } else if constexpr (ALL_LOADERS) {   // stem (Cin = 4) and DCN gather loaders exist for the basic tiles only
-    if (loader == 1) hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, NS, 1>), dim3(grid, groups), dim3(64 * WM * WN * WK), dyn, s, p);
-    else hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, NS, 2>), dim3(grid, groups), dim3(64 * WM * WN * WK), dyn, s, p);
+    hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, NS, 0, PREC>), dim3(grid, groups), dim3(64 * WM * WN * WK), dyn, s, p);
+  } else if constexpr (ALL_LOADERS && PREC == 0) {   // stem (Cin = 4) and DCN gather loaders: basic fp32 tiles only
+    if (loader == 1) hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, NS, 1, 0>), dim3(grid, groups), dim3(64 * WM * WN * WK), dyn, s, p);
+    else hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, NS, 2, 0>), dim3(grid, groups), dim3(64 * WM * WN * WK), dyn, s, p);
   } else {
     return YMI_EARG;
   }
   return ymi_launch_status();
 }
 
-// tile id -> (WM, WN, WK, TM, TN, NSTAGE, all loaders?)
-#define YMI_TILE_TABLE(X)                                   \
-  X(YMI_TILE_128x128, 2, 2, 1, 2, 2, 2, true)               \
-  X(YMI_TILE_128x64, 2, 2, 1, 2, 1, 2, true)                \
-  X(YMI_TILE_64x64, 2, 2, 1, 1, 1, 2, true)                 \
-  X(YMI_TILE_128x32, 4, 1, 1, 1, 1, 2, true)                \
-  X(YMI_TILE_64x128, 2, 2, 1, 1, 2, 2, true)                \
-  X(YMI_TILE_32x32_K4, 1, 1, 4, 1, 1, 2, false)             \
-  X(YMI_TILE_64x32_K2, 2, 1, 2, 1, 1, 2, false)             \
-  X(YMI_TILE_32x64_K2, 1, 2, 2, 1, 1, 2, false)             \
-  X(YMI_TILE_64x64_S3, 2, 2, 1, 1, 1, 3, false)             \
-  X(YMI_TILE_64x64_S4, 2, 2, 1, 1, 1, 4, false)             \
-  X(YMI_TILE_64x128_S3, 2, 2, 1, 1, 2, 3, false)            \
-  X(YMI_TILE_128x64_S3, 2, 2, 1, 2, 1, 3, false)            \
-  X(YMI_TILE_32x32_K4_S4, 1, 1, 4, 1, 1, 4, false)          \
-  X(YMI_TILE_64x32_K2_S3, 2, 1, 2, 1, 1, 3, false)          \
-  X(YMI_TILE_32x64_K2_S3, 1, 2, 2, 1, 1, 3, false)          \
-  X(YMI_TILE_128x128_W8, 4, 2, 1, 1, 2, 2, false)           \
-  X(YMI_TILE_256x128_W8, 4, 2, 1, 2, 2, 2, false)           \
-  X(YMI_TILE_128x256_W8, 4, 2, 1, 1, 4, 2, false)
+// tile id -> (WM, WN, WK, TM, TN, NSTAGE, all loaders?, PREC).  ids | YMI_TILE_X3 (32): the same block tile computed as
+// bf16x3 (fp32-class products on the bf16 matrix pipe, see split8()).
+#define YMI_TILE_TABLE(X)                                      \
+  X(YMI_TILE_128x128, 2, 2, 1, 2, 2, 2, true, 0)               \
+  X(YMI_TILE_128x64, 2, 2, 1, 2, 1, 2, true, 0)                \
+  X(YMI_TILE_64x64, 2, 2, 1, 1, 1, 2, true, 0)                 \
+  X(YMI_TILE_128x32, 4, 1, 1, 1, 1, 2, true, 0)                \
+  X(YMI_TILE_64x128, 2, 2, 1, 1, 2, 2, true, 0)                \
+  X(YMI_TILE_32x32_K4, 1, 1, 4, 1, 1, 2, false, 0)             \
+  X(YMI_TILE_64x32_K2, 2, 1, 2, 1, 1, 2, false, 0)             \
+  X(YMI_TILE_32x64_K2, 1, 2, 2, 1, 1, 2, false, 0)             \
+  X(YMI_TILE_64x64_S3, 2, 2, 1, 1, 1, 3, false, 0)             \
+  X(YMI_TILE_64x64_S4, 2, 2, 1, 1, 1, 4, false, 0)             \
+  X(YMI_TILE_64x128_S3, 2, 2, 1, 1, 2, 3, false, 0)            \
+  X(YMI_TILE_128x64_S3, 2, 2, 1, 2, 1, 3, false, 0)            \
+  X(YMI_TILE_32x32_K4_S4, 1, 1, 4, 1, 1, 4, false, 0)          \
+  X(YMI_TILE_64x32_K2_S3, 2, 1, 2, 1, 1, 3, false, 0)          \
+  X(YMI_TILE_32x64_K2_S3, 1, 2, 2, 1, 1, 3, false, 0)          \
+  X(YMI_TILE_128x128_W8, 4, 2, 1, 1, 2, 2, false, 0)           \
+  X(YMI_TILE_256x128_W8, 4, 2, 1, 2, 2, 2, false, 0)           \
+  X(YMI_TILE_128x256_W8, 4, 2, 1, 1, 4, 2, false, 0)           \
+  X(YMI_TILE_X3 | YMI_TILE_128x128, 2, 2, 1, 2, 2, 2, false, 1)     \
+  X(YMI_TILE_X3 | YMI_TILE_128x64, 2, 2, 1, 2, 1, 2, false, 1)      \
+  X(YMI_TILE_X3 | YMI_TILE_64x64, 2, 2, 1, 1, 1, 2, false, 1)       \
+  X(YMI_TILE_X3 | YMI_TILE_64x128, 2, 2, 1, 1, 2, 2, false, 1)      \
+  X(YMI_TILE_X3 | YMI_TILE_32x32_K4, 1, 1, 4, 1, 1, 2, false, 1)    \
+  X(YMI_TILE_X3 | YMI_TILE_64x32_K2, 2, 1, 2, 1, 1, 2, false, 1)    \
+  X(YMI_TILE_X3 | YMI_TILE_32x64_K2, 1, 2, 2, 1, 1, 2, false, 1)    \
+  X(YMI_TILE_X3 | YMI_TILE_64x64_S3, 2, 2, 1, 1, 1, 3, false, 1)    \
+  X(YMI_TILE_X3 | YMI_TILE_64x128_S3, 2, 2, 1, 1, 2, 3, false, 1)   \
+  X(YMI_TILE_X3 | YMI_TILE_128x64_S3, 2, 2, 1, 2, 1, 3, false, 1)   \
+  X(YMI_TILE_X3 | YMI_TILE_128x128_W8, 4, 2, 1, 1, 2, 2, false, 1)
 
 int tile_dims(int tile, int &bm, int &bn) {
   switch (tile) {
-#define X(id, wm, wn, wk, tm, tn, ns, all) case id: bm = wm * tm * 32; bn = wn * tn * 32; return 0;
+#define X(id, wm, wn, wk, tm, tn, ns, all, prec) case id: bm = wm * tm * 32; bn = wn * tn * 32; return 0;
     YMI_TILE_TABLE(X)
 #undef X
   }
@@ -721,7 +840,7 @@ int tile_dims(int tile, int &bm, int &bn) {
 
 bool tile_all_loaders(int tile) {
   switch (tile) {
-#define X(id, wm, wn, wk, tm, tn, ns, all) case id: return all;
+#define X(id, wm, wn, wk, tm, tn, ns, all, prec) case id: return all;
     YMI_TILE_TABLE(X)
 #undef X
   }
@@ -837,7 +956,7 @@ int run_conv(const ymi_conv_desc *d, int loader, const float *offmask, int ldo, 
     }
   }
   switch (tile) {
-#define X(id, wm, wn, wk, tm, tn, ns, all) case id: rc = launch_cfg<wm, wn, wk, tm, tn, ns, all>(kp, loader, s, groups); break;
+#define X(id, wm, wn, wk, tm, tn, ns, all, prec) case id: rc = launch_cfg<wm, wn, wk, tm, tn, ns, all, prec>(kp, loader, s, groups); break;
     YMI_TILE_TABLE(X)
 #undef X
     default: return YMI_EARG;

@@ -25,6 +25,7 @@ def _ceil(a, b):
 
 
 # ---- shipped tile / algorithm table ------------------------------------------------------------------------------
+SPLIT_DEFAULT = '0'   # default of YOLACT_AMD_SPLIT (see Plan.__init__)
 TUNE_GEN = 2          # bump whenever tile ids or kernel variants change meaning: older tables are ignored
 TUNE_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tune')
 _table_cache = {}
@@ -209,6 +210,10 @@ class Plan:
         # YOLACT_AMD_WINOGRAD_FORCE=1: take the Winograd path on every eligible layer even where the direct kernel
         # measured faster (parity tests of the least accurate variant; never the default)
         self.wino_force = os.environ.get('YOLACT_AMD_WINOGRAD_FORCE', '0') == '1'
+        # YOLACT_AMD_SPLIT=1: the bf16x3 variants of the GEMM tiles (fp32-class products on the bf16 matrix pipe, 6 bf16
+        # MFMAs per product at 16x the fp32-MFMA rate, csrc/conv_igemm.hip split8) join the candidates of every Cin % 32
+        # == 0 layer and of the Winograd GEMMs; the measurement decides per shape
+        self.split = os.environ.get('YOLACT_AMD_SPLIT', SPLIT_DEFAULT) == '1'
         self.down_on_side_stream = os.environ.get('YOLACT_AMD_DOWN_STREAM', 'B') == 'B'      # measured +1 %
         self.wino_alt, self._wino_packed, self._wino_ws = {}, {}, {}
         self._done_event = None
@@ -703,8 +708,9 @@ class Plan:
                 continue
             d = dptr.contents
             key = (d.B, d.H, d.W, d.Cin, d.Cout, d.kh, d.kw, d.stride, d.pad, d.res_mode, d.nseg, d.Kpad)
-            if key not in cache and str(key) in disk:
-                d.tile = int(disk[str(key)])
+            skey = str(key) + ('|x3' if self.split else '')
+            if key not in cache and skey in disk:
+                d.tile = int(disk[skey])
                 if fn(dptr, s) == 0:                      # a stale / foreign entry must not make every forward raise
                     cache[key] = d.tile
             if key not in cache:
@@ -723,9 +729,11 @@ class Plan:
                              L.TILE_32x32_K4, L.TILE_32x32_K4_S4, L.TILE_64x32_K2, L.TILE_64x32_K2_S3,
                              L.TILE_32x64_K2, L.TILE_32x64_K2_S3]
                 else:
-                    cands = [t for t in sorted(L.TILE_NAMES) if t != L.TILE_128x32]
+                    cands = [t for t in sorted(L.TILE_NAMES) if t != L.TILE_128x32 and not (t & L.TILE_X3)]
                     if d.Cout < 256:
                         cands = [t for t in cands if t != L.TILE_128x256_W8]
+                if self.split and d.Cin % 32 == 0:
+                    cands = cands + [t | L.TILE_X3 for t in cands if t in L.X3_BASE_TILES]
                 best, best_ms, times = None, 1e30, {}
                 ok_cands = []
                 for t in cands:                       # warm every candidate once (code fetch, clocks); skip the
@@ -748,7 +756,7 @@ class Plan:
                         best, best_ms = t, times[L.TILE_NAMES[t]]
                 assert best is not None, name
                 cache[key] = best
-                disk[str(key)] = best
+                disk[skey] = best
                 self.tune_table.append((name, L.TILE_NAMES[best], times))
             d.tile = cache[key]
 
@@ -757,13 +765,16 @@ class Plan:
         The winner replaces the op in the list."""
         lib = self.lib
         wtiles = [L.TILE_64x64, L.TILE_64x128, L.TILE_128x64, L.TILE_128x128_W8, L.TILE_64x128_S3, L.TILE_32x64_K2]
+        if self.split:
+            wtiles = wtiles + [t | L.TILE_X3 for t in wtiles]
         memo = {}
         for idx, alts in sorted(self.wino_alt.items()):
             fn, dptr, name, where = self.ops[idx]
             if fn is not lib.ymi_conv2d_nhwc_f32:
                 continue
             w0 = alts[0]
-            key = 'wino' + str((w0.B, w0.H, w0.W, w0.C, w0.Cout, w0.act, w0.nseg, tuple(a.m for a in alts)))
+            key = 'wino' + str((w0.B, w0.H, w0.W, w0.C, w0.Cout, w0.act, w0.nseg, tuple(a.m for a in alts))) + (
+                '|x3' if self.split else '')
             if key not in memo and key in disk:
                 ent = tuple(disk[key])
                 ok = True
