@@ -529,7 +529,7 @@ void conv_igemm_f32(const KParams p) {
   // slots 4s + 2h and 4s + 2h + 1 of its row (A and B agree on the K order, which is all a dot product needs).
   // Raw fp32 fragments of step s + 1 are requested right after step s has been split, so their LDS latency and the
   // splitting VALU work of the next step overlap this step's 6 * TM * TN bf16 MFMAs (VALU and matrix pipes are separate).
-  f32x4 rwa[PREC == 1 ? TM : 1][2], rwb[PREC == 1 ? TN : 1][2];
+  f32x4 rwa[TM][2], rwb[TN][2];       // (dead, hence register-free, when PREC == 0)
   int fo2[2][2];
 #pragma unroll
   for (int s2 = 0; s2 < 2; ++s2)
