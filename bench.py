@@ -38,12 +38,28 @@ import os
 import sys
 import time
 
+# The plan overlaps two HIP streams.  ROCm maps streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues in creation
+# order; once RCCL has created its own streams, the plan's side stream lands on the SAME hardware queue as the main one
+# and the overlap is gone (measured: forward 6.69 ms instead of 6.25, profiles/r02_overlap_probe.txt).  Must be set before
+# the HIP runtime initialises.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz (spec)
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (spec; 2470-2495 measured)
+X3_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6   # bf16x3 tiles: 6 bf16 MFMA products per fp32-class product -> 416.7 TFLOP/s of
+                                             # fp32-equivalent work is what the matrix pipe can deliver in that mode
+
+
+def kernel_peak(name):
+    """Matrix-pipe peak, in fp32(-equivalent) TFLOP/s, of a conv_igemm_f32 instantiation: the exact-fp32 MFMA tiles are
+    bounded by the fp32 MFMA peak, the `...x3` tiles (fp32-class products as 6 bf16 MFMAs) by bf16 peak / 6."""
+    tile = name.split('<', 1)[1].split(',', 1)[0] if '<' in name else ''
+    return X3_PEAK_TFLOPS if tile.endswith('x3') else FP32_MFMA_PEAK_TFLOPS
 CONFIG = 'yolact_resnet50_config'
 
 
@@ -109,13 +125,23 @@ def roofline(net, x, reps=3):
     dom = max(by_kernel.items(), key=lambda kv: kv[1][0])
     name, (dms, dfl, dn) = dom
     ach = dfl / (dms * 1e-3) / 1e12
-    detail = {k: {'ms_per_step': v[0] / reps, 'tflops': v[1] / (v[0] * 1e-3) / 1e12, 'launches_per_step': v[2] // reps}
+    detail = {k: {'ms_per_step': v[0] / reps, 'tflops': v[1] / (v[0] * 1e-3) / 1e12, 'launches_per_step': v[2] // reps,
+                  'peak': round(kernel_peak(k), 1), 'frac': round(v[1] / (v[0] * 1e-3) / 1e12 / kernel_peak(k), 4)}
               for k, v in by_kernel.items()}
+    peak = kernel_peak(name)
+    # matrix-pipe utilisation of the whole engine: time the pipe would need at each launch's own peak / time taken
+    eng_ms = sum(v[0] for v in by_kernel.values())
+    eng_ideal_ms = sum(v[1] / (kernel_peak(k) * 1e12) * 1e3 for k, v in by_kernel.items())
+    x3_ms = sum(v[0] for k, v in by_kernel.items() if kernel_peak(k) != FP32_MFMA_PEAK_TFLOPS)
     wino2 = sum(1 for v in layers.values() if v[2].startswith('winograd F(2x2'))
     wino4 = sum(1 for v in layers.values() if v[2].startswith('winograd F(4x4'))
     return {
-        'bound': 'mfma', 'kernel': name, 'achieved': round(ach, 2), 'peak': FP32_MFMA_PEAK_TFLOPS,
-        'unit': 'TFLOP/s', 'frac': round(ach / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic_from_profiles(name),
+        'bound': 'mfma', 'kernel': name, 'achieved': round(ach, 2), 'peak': round(peak, 1),
+        'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': traffic_from_profiles(name),
+        'peak_basis': ('fp32 MFMA (v_mfma_f32_32x32x2_f32), 157.3 TFLOP/s' if peak == FP32_MFMA_PEAK_TFLOPS else
+                       'bf16x3 tile: every fp32 operand split exactly into 3 bf16 pieces, 6 piece products per fp32-class '
+                       'product on v_mfma_f32_32x32x16_bf16 with fp32 accumulate -> peak = 2500 / 6 = 416.7 TFLOP/s of '
+                       'fp32-equivalent work (executed bf16 FLOPs = 6 x achieved)'),
         'measured': 'HIP events on the launch stream, %d serialised passes right after the timed region' % reps,
         'flops_basis': 'FLOPs the launch executes on the matrix cores (for a direct conv launch = the algorithmic conv '
                        'FLOPs; for the Winograd GEMM launch = 16 (F(2x2,3x3)) or 36 (F(4x4,3x3)) GEMMs [T x C] x [C x Cout], '
@@ -129,11 +155,13 @@ def roofline(net, x, reps=3):
                               'F(2x2,3x3) (2.25x fewer multiplications) and %d F(4x4,3x3) (4x fewer), so this figure '
                               'can exceed what the matrix cores execute' % (len(layers), wino2, wino4)},
         'engine': {'kernel': 'conv_igemm_f32<*> (every instantiation: direct loaders + grouped Winograd GEMM)',
-                   'ms_per_step': round(sum(v[0] for v in by_kernel.values()) / reps, 3),
-                   'executed_tflops': round(sum(v[1] for v in by_kernel.values()) / (sum(v[0] for v in by_kernel.values()) * 1e-3) / 1e12, 2),
-                   'frac': round(sum(v[1] for v in by_kernel.values()) / (sum(v[0] for v in by_kernel.values()) * 1e-3) / 1e12
-                                 / FP32_MFMA_PEAK_TFLOPS, 4),
-                   'basis': 'FLOPs executed on the matrix cores by all GEMM launches of a step / their summed durations'},
+                   'ms_per_step': round(eng_ms / reps, 3),
+                   'executed_tflops': round(sum(v[1] for v in by_kernel.values()) / (eng_ms * 1e-3) / 1e12, 2),
+                   'frac': round(eng_ideal_ms / eng_ms, 4),
+                   'x3_share_of_time': round(x3_ms / eng_ms, 3),
+                   'basis': 'fp32(-equivalent) FLOPs executed by all GEMM launches of a step / their summed durations; frac '
+                            '= matrix-pipe time at each launch\'s own peak (157.3 exact-fp32 tiles, 416.7 bf16x3 tiles) / '
+                            'time taken'},
         'per_kernel': detail,
     }, layers
 
@@ -355,6 +383,10 @@ def main():
                               else 'none (RCCL init failed: %s)' % rccl_error,
                 'roofline': rf,
             }
+            if rf['engine']['x3_share_of_time'] > 0:
+                result['dtype'] = ('f32 (fp32 in / fp32 accumulate; %.0f %% of the GEMM time on bf16x3 tiles = every fp32 product as 6 '
+                                   'exact bf16 piece products on the bf16 matrix pipe, error class of one fp32 rounding; the rest '
+                                   'on exact-fp32 MFMA)' % (100 * rf['engine']['x3_share_of_time']))
             result['roofline']['all_conv']['sustained_tflops_in_timed_region'] = round(
                 rf['all_conv']['gflop_per_step'] / (dt / args.steps * 1e3), 2)
             if args.layers:

@@ -72,10 +72,13 @@ enum { YMI_TILE_AUTO = 0, YMI_TILE_128x128 = 1, YMI_TILE_128x64 = 2, YMI_TILE_64
        YMI_TILE_32x32_K4_S4 = 13, YMI_TILE_64x32_K2_S3 = 14, YMI_TILE_32x64_K2_S3 = 15,
        /* _W8 = 512-thread blocks (8 waves): half the global->LDS traffic per FLOP of the 4-wave tile of equal wave tile */
        YMI_TILE_128x128_W8 = 16, YMI_TILE_256x128_W8 = 17, YMI_TILE_128x256_W8 = 18,
+       /* one block per CU, deep LDS-DMA pipeline (96 - 144 KB of stages): the regime the bf16x3 variants need, whose K
+        * step is too short to hide a DMA round trip behind one or two co-resident blocks */
+       YMI_TILE_128x128_S3 = 19, YMI_TILE_128x128_W8_S3 = 20, YMI_TILE_256x128_W8_S3 = 21, YMI_TILE_128x128_W8_S4 = 22,
        /* tile | YMI_TILE_X3: the same block tile computed as "bf16x3" — every fp32 operand split exactly into three bf16
         * pieces (24 mantissa bits), 6 of the 9 piece products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the
         * dropped terms are <= 3 * 2^-24 |a b| (one fp32 rounding of the product).  Cin % 32 == 0 layers; available for
-        * tiles 1, 2, 3, 5, 6, 7, 8, 9, 11, 12, 16. */
+        * tiles 1, 2, 3, 5, 6, 7, 8, 9, 11, 12, 16, 17, 19 - 22. */
        YMI_TILE_X3 = 32 };
 
 int ymi_abi_version(void);

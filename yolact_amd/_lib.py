@@ -19,10 +19,12 @@ TILE_32x32_K4, TILE_64x32_K2, TILE_32x64_K2 = 6, 7, 8
 TILE_64x64_S3, TILE_64x64_S4, TILE_64x128_S3, TILE_128x64_S3, TILE_32x32_K4_S4, TILE_64x32_K2_S3, TILE_32x64_K2_S3 = range(9, 16)
 TILE_NAMES = {1: '128x128', 2: '128x64', 3: '64x64', 4: '128x32', 5: '64x128', 6: '32x32k4', 7: '64x32k2', 8: '32x64k2',
               9: '64x64s3', 10: '64x64s4', 11: '64x128s3', 12: '128x64s3', 13: '32x32k4s4', 14: '64x32k2s3', 15: '32x64k2s3',
-              16: '128x128w8', 17: '256x128w8', 18: '128x256w8'}
+              16: '128x128w8', 17: '256x128w8', 18: '128x256w8', 19: '128x128s3', 20: '128x128w8s3', 21: '256x128w8s3',
+              22: '128x128w8s4'}
 TILE_128x128_W8, TILE_256x128_W8, TILE_128x256_W8 = 16, 17, 18
+TILE_128x128_S3, TILE_128x128_W8_S3, TILE_256x128_W8_S3, TILE_128x128_W8_S4 = 19, 20, 21, 22
 TILE_X3 = 32                        # tile | TILE_X3: bf16x3 split-precision variant of the same block tile (include/yolact_amd.h)
-X3_BASE_TILES = (1, 2, 3, 5, 6, 7, 8, 9, 11, 12, 16)
+X3_BASE_TILES = (1, 2, 3, 5, 6, 7, 8, 9, 11, 12, 16, 17, 19, 20, 21, 22)
 for _t in X3_BASE_TILES:
     TILE_NAMES[_t | TILE_X3] = TILE_NAMES[_t] + 'x3'
 BASIC_TILES = (1, 2, 3, 4, 5)      # available for every loader (stem, DCN)

@@ -817,6 +817,10 @@ int launch_cfg(const KParams &kp, int loader, hipStream_t s, int groups) {
   X(YMI_TILE_128x128_W8, 4, 2, 1, 1, 2, 2, false, 0)           \
   X(YMI_TILE_256x128_W8, 4, 2, 1, 2, 2, 2, false, 0)           \
   X(YMI_TILE_128x256_W8, 4, 2, 1, 1, 4, 2, false, 0)           \
+  X(YMI_TILE_128x128_S3, 2, 2, 1, 2, 2, 3, false, 0)           \
+  X(YMI_TILE_128x128_W8_S3, 4, 2, 1, 1, 2, 3, false, 0)        \
+  X(YMI_TILE_256x128_W8_S3, 4, 2, 1, 2, 2, 3, false, 0)        \
+  X(YMI_TILE_128x128_W8_S4, 4, 2, 1, 1, 2, 4, false, 0)        \
   X(YMI_TILE_X3 | YMI_TILE_128x128, 2, 2, 1, 2, 2, 2, false, 1)     \
   X(YMI_TILE_X3 | YMI_TILE_128x64, 2, 2, 1, 2, 1, 2, false, 1)      \
   X(YMI_TILE_X3 | YMI_TILE_64x64, 2, 2, 1, 1, 1, 2, false, 1)       \
@@ -827,7 +831,12 @@ int launch_cfg(const KParams &kp, int loader, hipStream_t s, int groups) {
   X(YMI_TILE_X3 | YMI_TILE_64x64_S3, 2, 2, 1, 1, 1, 3, false, 1)    \
   X(YMI_TILE_X3 | YMI_TILE_64x128_S3, 2, 2, 1, 1, 2, 3, false, 1)   \
   X(YMI_TILE_X3 | YMI_TILE_128x64_S3, 2, 2, 1, 2, 1, 3, false, 1)   \
-  X(YMI_TILE_X3 | YMI_TILE_128x128_W8, 4, 2, 1, 1, 2, 2, false, 1)
+  X(YMI_TILE_X3 | YMI_TILE_128x128_W8, 4, 2, 1, 1, 2, 2, false, 1)  \
+  X(YMI_TILE_X3 | YMI_TILE_256x128_W8, 4, 2, 1, 2, 2, 2, false, 1)  \
+  X(YMI_TILE_X3 | YMI_TILE_128x128_S3, 2, 2, 1, 2, 2, 3, false, 1)  \
+  X(YMI_TILE_X3 | YMI_TILE_128x128_W8_S3, 4, 2, 1, 1, 2, 3, false, 1) \
+  X(YMI_TILE_X3 | YMI_TILE_256x128_W8_S3, 4, 2, 1, 2, 2, 3, false, 1) \
+  X(YMI_TILE_X3 | YMI_TILE_128x128_W8_S4, 4, 2, 1, 1, 2, 4, false, 1)
 
 int tile_dims(int tile, int &bm, int &bn) {
   switch (tile) {

@@ -764,7 +764,8 @@ class Plan:
         """Per eligible layer: best GEMM tile of the Winograd path, then Winograd vs the (already tuned) direct kernel.
         The winner replaces the op in the list."""
         lib = self.lib
-        wtiles = [L.TILE_64x64, L.TILE_64x128, L.TILE_128x64, L.TILE_128x128_W8, L.TILE_64x128_S3, L.TILE_32x64_K2]
+        wtiles = [L.TILE_64x64, L.TILE_64x128, L.TILE_128x64, L.TILE_128x128_W8, L.TILE_64x128_S3, L.TILE_32x64_K2,
+                  L.TILE_128x128, L.TILE_128x128_S3, L.TILE_128x128_W8_S3, L.TILE_256x128_W8, L.TILE_256x128_W8_S3]
         if self.split:
             wtiles = wtiles + [t | L.TILE_X3 for t in wtiles]
         memo = {}
