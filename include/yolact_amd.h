@@ -16,7 +16,7 @@
 extern "C" {
 #endif
 
-#define YMI_ABI_VERSION 1
+#define YMI_ABI_VERSION 2
 
 /* activation codes (epilogue) */
 enum { YMI_ACT_NONE = 0, YMI_ACT_RELU = 1, YMI_ACT_LEAKY01 = 2, YMI_ACT_TANH = 3, YMI_ACT_SIGMOID = 4 };
@@ -61,6 +61,10 @@ typedef struct {
   int32_t cin_alg;      /* real (un-padded) input channels for FLOP accounting; 0 = Cin */
   int32_t _pad0;
   ymi_conv_seg seg[3];
+  const void *w_x3;     /* optional, for tile | YMI_TILE_X3: the SAME filters pre-split into three bf16 planes
+                         * [3][CoutPad][Kpad] (uint16 bit patterns; plane 0 = top 8 significant bits by truncation, 1 = next 8,
+                         * 2 = last 8; plane0 + plane1 + plane2 == w exactly).  With it the kernel splits only the activations
+                         * on the fly (a third of the VALU work); NULL: both operands are split on the fly. */
 } ymi_conv_desc;
 
 /* block tile BMxBN; _Kn = the block's 4 waves also split K n ways (partial sums reduced in LDS in a fixed order:
@@ -114,6 +118,7 @@ typedef struct {
   int32_t m;            /* output tile edge: 0 or 2 = F(2x2,3x3) (16 GEMMs), 4 = F(4x4,3x3) (36 GEMMs) */
   int32_t _pad0;
   ymi_conv_seg seg[3];
+  const void *u_x3;     /* optional, for tile | YMI_TILE_X3: u pre-split into bf16 planes [G][3][CoutPad][C] (see ymi_conv_desc.w_x3) */
 } ymi_wino_desc;
 int ymi_conv3x3_winograd_f32(const ymi_wino_desc *d, void *stream);
 

@@ -20,8 +20,9 @@ def nchw(x_nhwc):
 
 
 def run_conv(x, weight, bias=None, bn=None, stride=1, pad=0, act=L.ACT_NONE, res=None, res_mode=L.RES_NONE,
-             res_after_act=0, tile=L.TILE_AUTO, cin_pad=None, dcn_offmask=None):
-    """x: CPU NCHW tensor. Returns CPU NCHW output of the HIP conv."""
+             res_after_act=0, tile=L.TILE_AUTO, cin_pad=None, dcn_offmask=None, planes=True):
+    """x: CPU NCHW tensor. Returns CPU NCHW output of the HIP conv.  `planes`: for bf16x3 tiles also hand the kernel the
+    pre-split filter planes (ymi_conv_desc.w_x3); False = both operands are split on the fly."""
     pk = Packed(weight, bias, bn, stride, pad, cin_pad, DEV)
     xn = nhwc(x)
     if cin_pad and cin_pad != xn.shape[-1]:
@@ -44,6 +45,8 @@ def run_conv(x, weight, bias=None, bn=None, stride=1, pad=0, act=L.ACT_NONE, res
         d.res, d.res_ld, d.res_H, d.res_W = rd.data_ptr(), rd.shape[3], rd.shape[1], rd.shape[2]
     d.nseg, d.tile = 1, tile
     d.seg[0] = L.ConvSeg(0, pk.Cout, act, pk.Cout, Ho * Wo * pk.Cout, y.data_ptr())
+    if (tile & L.TILE_X3) and planes and pk.Cin % 32 == 0:
+        d.w_x3 = pk.w3().data_ptr()
     s = L.stream_ptr()
     if dcn_offmask is not None:
         om = nhwc(dcn_offmask).to(DEV)
@@ -90,6 +93,8 @@ def run_wino(x, weight, bias=None, bn=None, act=L.ACT_NONE, tile=L.TILE_AUTO, m=
     d.scale = pk.scale.data_ptr() if pk.scale is not None else None
     d.bias = pk.bias.data_ptr() if pk.bias is not None else None
     d.B, d.H, d.W, d.C, d.Cout, d.act, d.tile, d.m = B, H, W, Cc, Cout, act, tile, m
+    if tile & L.TILE_X3:
+        d.u_x3 = wp.u3().data_ptr()
     L.check(L.lib().ymi_conv3x3_winograd_f32(C.byref(d), L.stream_ptr()), 'winograd')
     torch.cuda.synchronize()
     return nchw(y.cpu())

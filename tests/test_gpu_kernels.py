@@ -37,6 +37,8 @@ def test_conv_plain(shape, tile):
     ref = F.conv2d(x, w, b, s, p)
     assert y.shape == ref.shape
     assert rel_err(y, ref) < 2e-5
+    if tile & L.TILE_X3:                     # the same tile with both operands split on the fly (no filter planes)
+        assert rel_err(run_conv(x, w, b, None, s, p, tile=tile, planes=False), ref) < 2e-5
 
 
 def test_conv_asymmetric_filter_detects_transposes():
@@ -222,7 +224,9 @@ def test_dcn_known_answers():
 
 
 @pytest.mark.parametrize('shape', [(2, 64, 9, 11, 96), (1, 32, 69, 69, 64), (3, 128, 6, 5, 132), (1, 256, 18, 18, 256)])
-@pytest.mark.parametrize('tile', [L.TILE_AUTO, L.TILE_64x64, L.TILE_64x128, L.TILE_128x128_W8, L.TILE_32x64_K2])
+@pytest.mark.parametrize('tile', [L.TILE_AUTO, L.TILE_64x64, L.TILE_64x128, L.TILE_128x128_W8, L.TILE_32x64_K2,
+                                  L.TILE_64x64 | L.TILE_X3, L.TILE_128x128 | L.TILE_X3, L.TILE_64x128 | L.TILE_X3,
+                                  L.TILE_128x128_S3 | L.TILE_X3, L.TILE_256x128_W8 | L.TILE_X3])
 @pytest.mark.parametrize('m', [2, 4])
 def test_winograd_matches_direct(shape, tile, m):
     """Winograd F(2x2,3x3) / F(4x4,3x3) paths (csrc/winograd.hip) vs torch's conv and vs the direct implicit-GEMM kernel:
@@ -312,9 +316,11 @@ def test_conv_bf16x3_is_fp32_class(base):
     ref = F.conv2d(x.double(), w.double(), None, 1, 1)
     mag = F.conv2d(x.double().abs(), w.double().abs(), None, 1, 1)
     y32 = run_conv(x, w, None, None, 1, 1, tile=base).double()
-    yx3 = run_conv(x, w, None, None, 1, 1, tile=base | L.TILE_X3).double()
     e32 = ((y32 - ref).abs() / mag).max().item()
-    ex3 = ((yx3 - ref).abs() / mag).max().item()
-    print('tile %s: fp32 MFMA err %.2e, bf16x3 err %.2e (of sum|ab|)' % (L.TILE_NAMES[base], e32, ex3))
-    assert e32 < 1e-5 and ex3 < 1e-5          # K = 2304 products of mixed magnitude: both are fp32-rounding class
-    assert ex3 < 2 * e32 + 1e-7               # measured: the split path is the MORE accurate one (2.0e-6 vs 4.0e-6, 64x64 tile)
+    for planes in (True, False):
+        yx3 = run_conv(x, w, None, None, 1, 1, tile=base | L.TILE_X3, planes=planes).double()
+        ex3 = ((yx3 - ref).abs() / mag).max().item()
+        print('tile %s: fp32 MFMA err %.2e, bf16x3 (%s) err %.2e (of sum|ab|)' % (
+            L.TILE_NAMES[base], e32, 'filter planes' if planes else 'both split on the fly', ex3))
+        assert e32 < 1e-5 and ex3 < 1e-5      # K = 2304 products of mixed magnitude: both are fp32-rounding class
+        assert ex3 < 2 * e32 + 1e-7           # measured: the split path is the MORE accurate one (2.0e-6 vs 4.0e-6, 64x64 tile)

@@ -66,6 +66,8 @@ def main():
             d.res, d.res_ld, d.res_mode = res.data_ptr(), Cout, L.RES_ADD
         d.nseg = 1
         d.seg[0] = L.ConvSeg(0, Cout, L.ACT_RELU, Cout, Ho * Wo * Cout, y.data_ptr())
+        if os.environ.get('PROBE_PLANES', '1') == '1':
+            d.w_x3 = pk.w3().data_ptr()          # bf16x3 tiles: pre-split filter planes (PROBE_PLANES=0: split both on the fly)
         fl = lib.ymi_conv_flops(C.byref(d))
         s = L.stream_ptr()
         for t in tiles:

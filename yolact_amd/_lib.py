@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libyolact_amd.so')
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 ACT_NONE, ACT_RELU, ACT_LEAKY01, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 RES_NONE, RES_ADD, RES_BILINEAR = 0, 1, 2
@@ -45,7 +45,7 @@ class ConvDesc(C.Structure):
                 ('Kpad', C.c_int32), ('res_mode', C.c_int32), ('res_ld', C.c_int32),
                 ('res_H', C.c_int32), ('res_W', C.c_int32), ('res_after_act', C.c_int32),
                 ('nseg', C.c_int32), ('tile', C.c_int32), ('cin_alg', C.c_int32), ('_pad0', C.c_int32),
-                ('seg', ConvSeg * 3)]
+                ('seg', ConvSeg * 3), ('w_x3', C.c_void_p)]
 
 
 class WinoDesc(C.Structure):
@@ -53,7 +53,7 @@ class WinoDesc(C.Structure):
                 ('V', C.c_void_p), ('M', C.c_void_p),
                 ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('C', C.c_int32), ('Cout', C.c_int32),
                 ('act', C.c_int32), ('tile', C.c_int32), ('nseg', C.c_int32), ('m', C.c_int32), ('_pad0', C.c_int32),
-                ('seg', ConvSeg * 3)]
+                ('seg', ConvSeg * 3), ('u_x3', C.c_void_p)]
 
 
 class DcnDesc(C.Structure):

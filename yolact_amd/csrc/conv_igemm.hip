@@ -80,6 +80,8 @@ struct KParams {
   const float *offmask;           // DCN only
   int ldo;
   long x_gs, w_gs, y_gs;          // grouped GEMM (gridDim.y groups, Winograd): element strides of x / w / seg[0].ptr per group
+  const void *w3;                 // PREC == 2: filters pre-split into three bf16 planes [groups][3][CoutPad][Kpad]
+  unsigned w3_plane;              // PREC == 2: bytes between planes (CoutPad * Kpad * 2); a group is 3 planes
   unsigned long long *trace;      // diagnostics only (ymi_debug_set_trace): per block {hw id, t0, t_loop, t_epi, t1, t_transposed}
   int abl;                        // diagnostics only (env YMI_ABLATE): bit0 skip the staging of chunks > 0,
                                   // bit2 skip barriers in the K loop — wrong results, used to attribute stall time;
@@ -206,17 +208,21 @@ __device__ __forceinline__ void epilogue_general(const KParams &p, const float *
 //         what the layers whose grid gives each CU only 1-3 blocks need.
 // blocks per CU the LDS footprint allows (= waves per SIMD for 256-thread blocks): the register budget handed to the
 // compiler, so that the epilogue's prefetch registers never cost a resident block
+// floats of LDS per K chunk: A tile [BM][32] fp32 + B tile [BN][32] fp32, or (PREC == 2) B as three bf16 planes [3][BN][32]
+template <int BM, int BN, int PREC>
+constexpr int conv_sub_floats() { return BM * BK + (PREC == 2 ? BN * BK * 3 / 2 : BN * BK); }
+
 template <int WM, int WN, int WK, int TM, int TN, int NSTAGE, int LOADER, int PREC>
 constexpr int conv_occupancy() {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int ns = (LOADER == 2) ? 2 : NSTAGE;
-  constexpr int stage_b = ns * (BM + BN) * BK * WK * 4, epi_b = WK * BM * (BN + 4) * 4;
+  constexpr int stage_b = ns * conv_sub_floats<BM, BN, PREC>() * WK * 4, epi_b = WK * BM * (BN + 4) * 4;
   constexpr int lds_b = stage_b > epi_b ? stage_b : epi_b;
   constexpr int occ = (160 * 1024) / lds_b;
   // the DCN gather keeps per-tap geometry in registers; the bf16x3 path holds 12 registers of split pieces per 32-row
   // fragment on top of the raw fp32 fragment: budget registers (= blocks per CU) so that neither spills
   constexpr int cap = (LOADER == 2) ? 3
-                      : (PREC == 1 ? (WM * WN * WK == 8 ? 1 : (TM * TN >= 4 ? 2 : (TM * TN == 2 ? 3 : 4))) : 5);
+                      : (PREC >= 1 ? (WM * WN * WK == 8 ? 1 : (TM * TN >= 4 ? 2 : (TM * TN == 2 ? 3 : 4))) : 5);
   return occ > cap ? cap : (occ < 1 ? 1 : occ);
 }
 
@@ -228,9 +234,12 @@ void conv_igemm_f32(const KParams p) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int NWAVE = WM * WN * WK, NTHR = 64 * NWAVE;   // 4 waves (256 threads) or 8 waves (512 threads)
   constexpr int RPP = NTHR / 8;               // tile rows staged by one pass of the block (8 lanes per row)
-  constexpr int RA = BM / RPP, RB = BN / RPP;  // 8-row DMA pieces per wave per chunk for the A / B tile
-  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the rows per staging pass");
-  constexpr int SUB = (BM + BN) * BK;        // floats per chunk image [BM + BN rows][32]
+  // DMA pieces per wave per chunk: A tile 8 rows x 128 bytes each; B tile likewise, or (PREC == 2, three bf16 planes of
+  // 64-byte rows) 16 rows x 64 bytes of one plane each
+  constexpr int RA = BM / RPP, RB = (PREC == 2) ? (3 * BN) / (16 * NWAVE) : BN / RPP;
+  static_assert(BM % RPP == 0 && (PREC == 2 ? (3 * BN) % (16 * NWAVE) == 0 : BN % RPP == 0),
+                "tile rows must be a multiple of the rows per staging pass");
+  constexpr int SUB = conv_sub_floats<BM, BN, PREC>();        // floats per chunk image
   constexpr int STAGE = SUB * WK;            // floats per pipeline stage
   constexpr int NS = (LOADER == 2) ? 2 : NSTAGE;   // the register-staged DCN gather keeps the simple 2-stage drain
   constexpr int DMA_PER_STEP = (RA + RB) * WK;     // LDS-DMA instructions every wave issues per step
@@ -240,6 +249,7 @@ void conv_igemm_f32(const KParams p) {
   static_assert(WM * WN * WK == 4 || WM * WN * WK == 8, "4 or 8 waves per block");
   static_assert(LOADER != 2 || WK == 1, "DCN gather runs without the K split");
   static_assert(PREC == 0 || LOADER == 0 || LOADER == 3, "the bf16x3 path exists for the LDS-DMA loaders only");
+  static_assert(PREC != 2 || BN % 16 == 0, "bf16 planes: 16-row DMA pieces");
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
   const ymi_conv_desc &d = p.d;
@@ -259,8 +269,9 @@ void conv_igemm_f32(const KParams p) {
   const int grp = blockIdx.y;    // group of a grouped GEMM (the 16 Winograd components); 0 otherwise
   const __amdgpu_buffer_rsrc_t xrs =
       __builtin_amdgcn_make_buffer_rsrc((void *)(d.x + (size_t)grp * p.x_gs), 0, (int)p.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t wrs =
-      __builtin_amdgcn_make_buffer_rsrc((void *)(d.w + (size_t)grp * p.w_gs), 0, (int)p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = (PREC == 2)
+      ? __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.w3 + (size_t)grp * 3 * p.w3_plane), 0, (int)(3 * p.w3_plane), 0x00020000)
+      : __builtin_amdgcn_make_buffer_rsrc((void *)(d.w + (size_t)grp * p.w_gs), 0, (int)p.w_bytes, 0x00020000);
 
   // ---- epilogue thread mapping + residual prefetch -----------------------------------------------
   // Each thread owns 4 consecutive output channels of RPT rows.  A plain residual (bottleneck shortcut) is fetched
@@ -317,8 +328,28 @@ void conv_igemm_f32(const KParams p) {
     }
   }
   unsigned b_off[RB];                           // byte offset of (filter row, k-slot sl) for chunk 0
+  if (PREC == 2) {
+    // piece i of this wave = unit u = wave + NWAVE * i of the 3 * BN / 16 (plane, 16-row group) units; lane l fills row
+    // l >> 2, physical 16-byte slot l & 3 (64-byte rows); logical slot = physical ^ ((row >> 2) & 3)
 #pragma unroll
-  for (int i = 0; i < RB; ++i) b_off[i] = (unsigned)(((n0 + r0 + RPP * i) * d.Kpad + 4 * sl) * 4);
+    for (int i = 0; i < RB; ++i) {
+      const int u = wave + NWAVE * i, plane = u / (BN / 16), rg = u - plane * (BN / 16);
+      const int row = rg * 16 + (lane >> 2), lsl = (lane & 3) ^ ((row >> 2) & 3);
+      b_off[i] = (unsigned)plane * p.w3_plane + (unsigned)(((n0 + row) * d.Kpad + 8 * lsl) * 2);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < RB; ++i) b_off[i] = (unsigned)(((n0 + r0 + RPP * i) * d.Kpad + 4 * sl) * 4);
+  }
+  // LDS destination (floats from the chunk's B base) and per-chunk byte advance of a B piece
+  auto b_lds = [&](int i) -> int {
+    if (PREC == 2) {
+      const int u = wave + NWAVE * i, plane = u / (BN / 16), rg = u - plane * (BN / 16);
+      return plane * (BN * 16) + rg * 256;
+    }
+    return (wave * 8 + RPP * i) * BK;
+  };
+  constexpr int B_CHUNK_BYTES = (PREC == 2) ? BK * 2 : BK * 4;
 
   // incremental (tap, channel-chunk) state of the next chunk to stage for each of the WK chunk slots (LOADER 0 / 2)
   int nx_c[WK], nx_ky[WK], nx_kx[WK];
@@ -413,8 +444,8 @@ void conv_igemm_f32(const KParams p) {
       }
 #pragma unroll
       for (int i = 0; i < RB; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(Bs + (wave * 8 + RPP * i) * BK), 16,
-                                                 live ? b_off[i] : OOB, live ? kc * (BK * 4) : 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(Bs + b_lds(i)), 16,
+                                                 live ? b_off[i] : OOB, live ? kc * B_CHUNK_BYTES : 0, 0, 0);
       if (LOADER != 1) {  // this slot's next chunk is WK chunks further
 #pragma unroll
         for (int a = 0; a < WK; ++a) advance(j);
@@ -458,8 +489,8 @@ void conv_igemm_f32(const KParams p) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(As + (wave * 8 + RPP * i) * BK), 16, voff, 0, 0, 0);
     } else {
       const int i = r - RA;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(Bs + (wave * 8 + RPP * i) * BK), 16,
-                                               live ? b_off[i] : OOB, live ? kc * (BK * 4) : 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(Bs + b_lds(i)), 16,
+                                               live ? b_off[i] : OOB, live ? kc * B_CHUNK_BYTES : 0, 0, 0);
       if (r == RA + RB - 1 && LOADER != 1) {   // last piece of slot j: its next chunk is WK chunks further
 #pragma unroll
         for (int a = 0; a < WK; ++a) advance(j);
@@ -530,23 +561,35 @@ void conv_igemm_f32(const KParams p) {
   // Raw fp32 fragments of step s + 1 are requested right after step s has been split, so their LDS latency and the
   // splitting VALU work of the next step overlap this step's 6 * TM * TN bf16 MFMAs (VALU and matrix pipes are separate).
   f32x4 rwa[TM][2], rwb[TN][2];       // (dead, hence register-free, when PREC == 0)
+  Split3 pbn[TN];                     // PREC == 2: the B pieces of the next step, read straight from the LDS planes
   int fo2[2][2];
 #pragma unroll
   for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
     for (int q = 0; q < 2; ++q) fo2[s2][q] = frag_row + 4 * ((4 * s2 + 2 * hh_ + q) ^ fsw);
+  const int psw = ((lane & 31) >> 2) & 3;   // plane image: 64-byte rows, 16-byte slot s of row n lives at slot s ^ ((n >> 2) & 3)
   auto load_raw = [&](int buf, int s2) {
     const float *As = lds + buf * STAGE + wk * SUB + (wm * TM * 32) * BK;
-    const float *Bs = lds + buf * STAGE + wk * SUB + BM * BK + (wn * TN * 32) * BK;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       rwa[i][0] = *reinterpret_cast<const f32x4 *>(As + i * 32 * BK + fo2[s2][0]);
       rwa[i][1] = *reinterpret_cast<const f32x4 *>(As + i * 32 * BK + fo2[s2][1]);
     }
+    if constexpr (PREC == 2) {
+      const float *Bp = lds + buf * STAGE + wk * SUB + BM * BK + ((wn * TN * 32 + (lane & 31)) * 16 + 4 * ((2 * s2 + hh_) ^ psw));
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      rwb[j][0] = *reinterpret_cast<const f32x4 *>(Bs + j * 32 * BK + fo2[s2][0]);
-      rwb[j][1] = *reinterpret_cast<const f32x4 *>(Bs + j * 32 * BK + fo2[s2][1]);
+      for (int j = 0; j < TN; ++j) {
+        pbn[j].h = *reinterpret_cast<const bf16x8 *>(Bp + j * 32 * 16);
+        pbn[j].m = *reinterpret_cast<const bf16x8 *>(Bp + j * 32 * 16 + BN * 16);
+        pbn[j].l = *reinterpret_cast<const bf16x8 *>(Bp + j * 32 * 16 + 2 * BN * 16);
+      }
+    } else {
+      const float *Bs = lds + buf * STAGE + wk * SUB + BM * BK + (wn * TN * 32) * BK;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        rwb[j][0] = *reinterpret_cast<const f32x4 *>(Bs + j * 32 * BK + fo2[s2][0]);
+        rwb[j][1] = *reinterpret_cast<const f32x4 *>(Bs + j * 32 * BK + fo2[s2][1]);
+      }
     }
   };
   auto compute_x3 = [&](int buf, bool stage_next, int nst, int nbuf) {
@@ -557,7 +600,10 @@ void conv_igemm_f32(const KParams p) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) xa[i] = split8(rwa[i][0], rwa[i][1]);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) xb[j] = split8(rwb[j][0], rwb[j][1]);
+      for (int j = 0; j < TN; ++j) {
+        if constexpr (PREC == 2) xb[j] = pbn[j];
+        else xb[j] = split8(rwb[j][0], rwb[j][1]);
+      }
       if (s2 == 0) load_raw(buf, 1);
       // product-major order: consecutive MFMAs hit different accumulators (no back-to-back dependent issue); per
       // accumulator the small cross terms still come first and the dominant h*h product last
@@ -584,7 +630,7 @@ void conv_igemm_f32(const KParams p) {
   };
   // precision-independent entry points of the main loop
   auto prefetch_frags = [&](int buf) {
-    if constexpr (PREC == 1) {
+    if constexpr (PREC >= 1) {
       load_raw(buf, 0);
     } else {
       load_frag(buf, 0, 0);
@@ -592,7 +638,7 @@ void conv_igemm_f32(const KParams p) {
     }
   };
   auto compute_chunk = [&](int buf, bool stage_next, int nst, int nbuf) {
-    if constexpr (PREC == 1) compute_x3(buf, stage_next, nst, nbuf);
+    if constexpr (PREC >= 1) compute_x3(buf, stage_next, nst, nbuf);
     else compute(buf, stage_next, nst, nbuf);
   };
   // a wave without a chunk of its own in a ragged K-split step still stages its share
@@ -763,7 +809,7 @@ constexpr int LDS_PER_CU = 160 * 1024, NUM_CU = 256;
 template <int WM, int WN, int WK, int TM, int TN, int NS, bool ALL_LOADERS, int PREC>
 int launch_cfg(const KParams &kp, int loader, hipStream_t s, int groups) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr int ns_eff_bytes = NS * (BM + BN) * BK * WK * 4, epi_bytes = WK * BM * (BN + 4) * 4;
+  constexpr int ns_eff_bytes = NS * conv_sub_floats<BM, BN, PREC>() * WK * 4, epi_bytes = WK * BM * (BN + 4) * 4;
   constexpr int static_lds = ns_eff_bytes > epi_bytes ? ns_eff_bytes : epi_bytes;
   KParams p = kp;
   const int tiles_m = (p.M + BM - 1) / BM;
@@ -773,7 +819,7 @@ int launch_cfg(const KParams &kp, int loader, hipStream_t s, int groups) {
   int dyn = 0;
   {
     int occ = LDS_PER_CU / static_lds;                     // LDS-limited residency (VGPRs allow >= this for every fp32 tile)
-    if (PREC == 1) {
+    if (PREC >= 1) {
       constexpr int occ_regs = conv_occupancy<WM, WN, WK, TM, TN, NS, 0, PREC>();
       occ = occ < occ_regs ? occ : occ_regs;
     }
@@ -794,6 +840,18 @@ int launch_cfg(const KParams &kp, int loader, hipStream_t s, int groups) {
     return YMI_EARG;
   }
   return ymi_launch_status();
+}
+
+// bf16x3 tiles: with pre-split filter planes (d->w_x3) only the activations are split on the fly (PREC 2), else both (PREC 1)
+template <int WM, int WN, int WK, int TM, int TN, int NS, bool ALL_LOADERS, int PREC>
+int launch_prec(const KParams &kp, int loader, hipStream_t s, int groups) {
+  if constexpr (PREC == 1) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NWAVE = WM * WN * WK;
+    if constexpr (BN % 16 == 0 && (3 * BN) % (16 * NWAVE) == 0 && NS * conv_sub_floats<BM, BN, 2>() * WK * 4 <= 160 * 1024) {
+      if (kp.w3 != nullptr) return launch_cfg<WM, WN, WK, TM, TN, NS, ALL_LOADERS, 2>(kp, loader, s, groups);
+    }
+  }
+  return launch_cfg<WM, WN, WK, TM, TN, NS, ALL_LOADERS, PREC>(kp, loader, s, groups);
 }
 
 // tile id -> (WM, WN, WK, TM, TN, NSTAGE, all loaders?, PREC).  ids | YMI_TILE_X3 (32): the same block tile computed as
@@ -943,6 +1001,9 @@ int run_conv(const ymi_conv_desc *d, int loader, const float *offmask, int ldo, 
   kp.offmask = offmask;
   kp.ldo = ldo;
   kp.x_gs = x_gs; kp.w_gs = w_gs; kp.y_gs = y_gs;
+  kp.w3 = d->w_x3;
+  kp.w3_plane = (unsigned)((((long)d->Cout + 127) / 128 * 128) * d->Kpad * 2L);
+  if (kp.w3 && (((uintptr_t)kp.w3) & 15)) return YMI_ESHAPE;
   kp.abl = 0;
 #ifdef YMI_DIAGNOSTICS   // `make DIAG=1`: ablation switches for tools/conv_probe.py — they produce WRONG results by design
   { const char *e = getenv("YMI_ABLATE"); kp.abl = e ? atoi(e) : 0; }
@@ -965,7 +1026,7 @@ int run_conv(const ymi_conv_desc *d, int loader, const float *offmask, int ldo, 
     }
   }
   switch (tile) {
-#define X(id, wm, wn, wk, tm, tn, ns, all, prec) case id: rc = launch_cfg<wm, wn, wk, tm, tn, ns, all, prec>(kp, loader, s, groups); break;
+#define X(id, wm, wn, wk, tm, tn, ns, all, prec) case id: rc = launch_prec<wm, wn, wk, tm, tn, ns, all, prec>(kp, loader, s, groups); break;
     YMI_TILE_TABLE(X)
 #undef X
     default: return YMI_EARG;

@@ -380,6 +380,7 @@ extern "C" int ymi_conv3x3_winograd_f32(const ymi_wino_desc *d, void *stream) {
   g.Ho = (int)T; g.Wo = 1; g.Cout = Ng;
   g.kh = g.kw = 1; g.stride = 1; g.pad = 0; g.Kpad = d->C;
   g.nseg = 1; g.tile = d->tile;
+  g.w_x3 = d->u_x3;                    // [G][3][CoutPad][C] bf16 planes (optional)
   g.seg[0].n0 = 0; g.seg[0].n1 = Ng; g.seg[0].act = YMI_ACT_NONE; g.seg[0].row_stride = Ng;
   g.seg[0].batch_stride = T * Ng; g.seg[0].ptr = d->M;
   const long cout_pad = ((long)d->Cout + 127) / 128 * 128;

@@ -64,6 +64,27 @@ def load_tune_table(device):
     return dict(_table_cache[arch])
 
 
+def split3_planes(w: torch.Tensor) -> torch.Tensor:
+    """fp32 [..., R, K] -> bf16 bit patterns int16 [..., 3, R, K]: plane 0 = the top 8 significant bits of every value (its
+    upper 16 bits, i.e. truncation to bf16), plane 1 = the top 8 bits of the exact remainder, plane 2 = what is left (at most
+    8 bits, exactly a bf16).  plane0 + plane1 + plane2 == w bit for bit (csrc/conv_igemm.hip split8 does the same to the
+    activations on the fly); used as `ymi_conv_desc.w_x3` by the bf16x3 tiles."""
+    w = w.detach().to(torch.float32).contiguous()
+    mask = -65536                                    # 0xFFFF0000 as int32
+
+    def hi(t):                                       # (truncated value as fp32, its upper 16 bits as int16)
+        u = t.view(torch.int32) & mask
+        return u.view(torch.float32), (u >> 16).to(torch.int16)
+    h, hb = hi(w)
+    r = w - h
+    m, mb = hi(r)
+    r2 = r - m
+    l, lb = hi(r2)
+    # exact for every normal fp32 value; a subnormal input (|w| < 1.2e-38) keeps its top 7 mantissa bits only (error < 1e-40)
+    assert bool(((h + m + l - w).abs() <= 1e-38).all()) or not torch.isfinite(w).all()
+    return torch.stack([hb, mb, lb], dim=-3).contiguous()
+
+
 class Packed:
     """A convolution's filters in the engine layout [CoutPad][Kpad] (k = (ky*kw+kx)*Cin + c) + folded epilogue."""
 
@@ -80,6 +101,7 @@ class Packed:
         wp = torch.zeros(self.CoutPad, self.Kpad, dtype=torch.float32, device=weight.device)
         wp[:Cout, :K] = w.reshape(Cout, K)
         self.w = wp.to(device).contiguous()
+        self._wp_host, self._w3 = wp, None
         self.weight_oihw = weight if (kh == 3 and kw == 3) else None     # Winograd transform source
         self.Cin, self.Cout, self.kh, self.kw, self.stride, self.pad = cin_p, Cout, kh, kw, stride, pad
         self.cin_alg = Cin
@@ -95,6 +117,12 @@ class Packed:
             shift = bias.detach().float()
         self.scale = scale.to(device).contiguous() if scale is not None else None
         self.bias = shift.to(device).contiguous() if shift is not None else None
+
+    def w3(self):
+        """[3][CoutPad][Kpad] bf16 planes of the same filters for the bf16x3 tiles (built on first use)."""
+        if self._w3 is None:
+            self._w3 = split3_planes(self._wp_host.cpu()).to(self.w.device)
+        return self._w3
 
 
 class WinoPacked:
@@ -116,6 +144,13 @@ class WinoPacked:
         up = torch.zeros(a * a, self.CoutPad, Cin, dtype=torch.float32)
         up[:, :Cout] = u.reshape(a * a, Cout, Cin).to(torch.float32)
         self.u = up.to(device).contiguous()
+        self._up_host, self._u3 = up, None
+
+    def u3(self):
+        """[G][3][CoutPad][C] bf16 planes of U for the bf16x3 GEMM tiles."""
+        if self._u3 is None:
+            self._u3 = split3_planes(self._up_host).to(self.u.device)
+        return self._u3
 
 
 def wino_eligible(pk, res, segs, act, x_C):
@@ -261,6 +296,8 @@ class Plan:
                 assert (res.B, res.H, res.W, res.C) == (x.B, Ho, Wo, pk.Cout), name
         d.tile = L.TILE_AUTO
         d.cin_alg = pk.cin_alg
+        if self.split and pk.Cin % 32 == 0:
+            d.w_x3 = pk.w3().data_ptr()
         y = None
         if segs is None:
             y = out if out is not None else self._new(x.B, Ho, Wo, pk.Cout)
@@ -309,6 +346,8 @@ class Plan:
             ws[1] = torch.empty(need_m, dtype=torch.float32, device=self.device)
         d = L.WinoDesc()
         d.x, d.u = x.ptr, wp.u.data_ptr()
+        if self.split:
+            d.u_x3 = wp.u3().data_ptr()
         if segs is None:
             d.y = y.ptr
         else:
