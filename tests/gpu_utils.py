@@ -45,7 +45,7 @@ def run_conv(x, weight, bias=None, bn=None, stride=1, pad=0, act=L.ACT_NONE, res
         d.res, d.res_ld, d.res_H, d.res_W = rd.data_ptr(), rd.shape[3], rd.shape[1], rd.shape[2]
     d.nseg, d.tile = 1, tile
     d.seg[0] = L.ConvSeg(0, pk.Cout, act, pk.Cout, Ho * Wo * pk.Cout, y.data_ptr())
-    if (tile & L.TILE_X3) and planes and pk.Cin % 32 == 0:
+    if (tile & L.TILE_X3) and planes and dcn_offmask is None:
         d.w_x3 = pk.w3().data_ptr()
     s = L.stream_ptr()
     if dcn_offmask is not None:

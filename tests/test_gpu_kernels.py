@@ -100,6 +100,10 @@ def test_conv_stem_7x7_c4_loader():
     y = run_conv(x, w, None, None, 2, 3, act=L.ACT_RELU, cin_pad=4)
     ref = F.relu(F.conv2d(x, w, None, 2, 3))
     assert rel_err(y, ref) < 2e-5
+    for tile in (L.TILE_64x64, L.TILE_128x64):                 # the stem on the bf16x3 tiles, with and without filter planes
+        for planes in (True, False):
+            yx = run_conv(x, w, None, None, 2, 3, act=L.ACT_RELU, cin_pad=4, tile=tile | L.TILE_X3, planes=planes)
+            assert rel_err(yx, ref) < 2e-5
     # darknet pre-conv: 3x3 / s1 / p1 on 3 channels
     w3 = torch.randn(32, 3, 3, 3, generator=g) / 5
     y3 = run_conv(x, w3, None, None, 1, 1, cin_pad=4)

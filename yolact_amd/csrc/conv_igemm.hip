@@ -194,8 +194,11 @@ __device__ __forceinline__ void epilogue_general(const KParams &p, const float *
 // LOADER: 0 = Cin % 32 == 0 (a K chunk lies inside one filter tap; tap is block-uniform)
 //         1 = Cin == 4 (stem; a K chunk = 8 taps x 4 channels; tap is per-lane)
 //         2 = DCNv2 modulated deformable gather (Cin % 32 == 0, 3x3, pad 1): A through registers, B by DMA (WK == 1)
-//         3 = loader 0 instantiated separately for the grouped (Winograd, gridDim.y = 16) launches, so that profilers
-//             list them under their own kernel name
+//         3 = POINTWISE: kh = kw = 1, pad = 0 (any stride) — every 1x1 convolution and the grouped Winograd GEMMs
+//             (gridDim.y = groups).  A row's source offset is fixed for the whole K loop (one tap, always in range), so a
+//             staging piece is ONE buffer_load..lds whose only varying operand is the scalar K-chunk offset: no per-piece
+//             predicate / address VALU (the generic loader spends ~10 VALU + SALU per piece on tap bookkeeping, which the
+//             bf16x3 tiles — half the matrix-pipe time per chunk — can no longer hide: ablation in profiles/r02_*)
 // WK:     waves along K.  WM*WN*WK == 4.  With WK > 1 a pipeline stage holds WK consecutive 32-deep chunks and wave
 //         (wm, wn, wk) multiplies chunk wk of every stage; the WK partial tiles are summed (fixed order) in the
 //         epilogue's LDS tile.  This quarters the block tile (32x32 with WK = 4) without an inter-block reduction:
@@ -248,7 +251,7 @@ void conv_igemm_f32(const KParams p) {
   static_assert(DMA_PER_STEP * (NS - 2) <= 63, "vmcnt is a 6-bit counter");
   static_assert(WM * WN * WK == 4 || WM * WN * WK == 8, "4 or 8 waves per block");
   static_assert(LOADER != 2 || WK == 1, "DCN gather runs without the K split");
-  static_assert(PREC == 0 || LOADER == 0 || LOADER == 3, "the bf16x3 path exists for the LDS-DMA loaders only");
+  static_assert(PREC == 0 || LOADER != 2, "the bf16x3 path exists for the LDS-DMA loaders only");
   static_assert(PREC != 2 || BN % 16 == 0, "bf16 planes: 16-row DMA pieces");
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
@@ -327,6 +330,11 @@ void conv_igemm_f32(const KParams p) {
       a_base[i] = 0;
     }
   }
+  unsigned a_voff[LOADER == 3 ? RA : 1];       // POINTWISE: the row's byte offset (or OOB past M), fixed over the K loop
+  if (LOADER == 3) {
+#pragma unroll
+    for (int i = 0; i < RA; ++i) a_voff[i] = (a_iy0[i] > -(1 << 27)) ? (unsigned)a_base[i] : OOB;
+  }
   unsigned b_off[RB];                           // byte offset of (filter row, k-slot sl) for chunk 0
   if (PREC == 2) {
     // piece i of this wave = unit u = wave + NWAVE * i of the 3 * BN / 16 (plane, 16-row group) units; lane l fills row
@@ -376,7 +384,12 @@ void conv_igemm_f32(const KParams p) {
                                                      // step issues the same number of DMAs (vmcnt accounting)
       float *As = lds + buf * STAGE + j * SUB;
       float *Bs = As + BM * BK;
-      if (LOADER == 0 || LOADER == 3) {
+      if (LOADER == 3) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(As + (wave * 8 + RPP * i) * BK), 16,
+                                                   live ? a_voff[i] : OOB, live ? kc * (BK * 4) : 0, 0, 0);
+      } else if (LOADER == 0) {
         const int koff = ((nx_ky[j] * d.W + nx_kx[j]) * d.ldx + nx_c[j]) * 4;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
@@ -446,7 +459,7 @@ void conv_igemm_f32(const KParams p) {
       for (int i = 0; i < RB; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(Bs + b_lds(i)), 16,
                                                  live ? b_off[i] : OOB, live ? kc * B_CHUNK_BYTES : 0, 0, 0);
-      if (LOADER != 1) {  // this slot's next chunk is WK chunks further
+      if (LOADER != 1 && LOADER != 3) {  // this slot's next chunk is WK chunks further
 #pragma unroll
         for (int a = 0; a < WK; ++a) advance(j);
       }
@@ -472,11 +485,14 @@ void conv_igemm_f32(const KParams p) {
     const bool live = (WK == 1) || (kc < p.nk);
     float *As = lds + buf * STAGE + j * SUB;
     float *Bs = As + BM * BK;
-    if (r < RA) {
+    if (r < RA && LOADER == 3) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(As + (wave * 8 + RPP * r) * BK), 16,
+                                               live ? a_voff[r] : OOB, live ? kc * (BK * 4) : 0, 0, 0);
+    } else if (r < RA) {
       const int i = r;
       bool ok;
       int koff;
-      if (LOADER == 0 || LOADER == 3) {
+      if (LOADER == 0) {
         koff = ((nx_ky[j] * d.W + nx_kx[j]) * d.ldx + nx_c[j]) * 4;
         ok = live && (unsigned)(a_iy0[i] + nx_ky[j]) < (unsigned)d.H && (unsigned)(a_ix0[i] + nx_kx[j]) < (unsigned)d.W;
       } else {   // LOADER == 1
@@ -491,7 +507,7 @@ void conv_igemm_f32(const KParams p) {
       const int i = r - RA;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(Bs + b_lds(i)), 16,
                                                live ? b_off[i] : OOB, live ? kc * B_CHUNK_BYTES : 0, 0, 0);
-      if (r == RA + RB - 1 && LOADER != 1) {   // last piece of slot j: its next chunk is WK chunks further
+      if (r == RA + RB - 1 && LOADER != 1 && LOADER != 3) {   // last piece of slot j: its next chunk is WK chunks further
 #pragma unroll
         for (int a = 0; a < WK; ++a) advance(j);
       }
@@ -829,13 +845,15 @@ int launch_cfg(const KParams &kp, int loader, hipStream_t s, int groups) {
       if (want > static_lds && want <= LDS_PER_CU / k) dyn = want - static_lds;
     }
   }
-  if (loader == 0 && groups > 1) {
+  const bool pointwise = p.d.kh == 1 && p.d.kw == 1 && p.d.pad == 0;
+  if (loader == 0 && (groups > 1 || pointwise)) {
     hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, NS, 3, PREC>), dim3(grid, groups), dim3(64 * WM * WN * WK), dyn, s, p);
   } else if (loader == 0) {
     hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, NS, 0, PREC>), dim3(grid, groups), dim3(64 * WM * WN * WK), dyn, s, p);
-  } else if constexpr (ALL_LOADERS && PREC == 0) {   // stem (Cin = 4) and DCN gather loaders: basic fp32 tiles only
-    if (loader == 1) hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, NS, 1, 0>), dim3(grid, groups), dim3(64 * WM * WN * WK), dyn, s, p);
-    else hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, NS, 2, 0>), dim3(grid, groups), dim3(64 * WM * WN * WK), dyn, s, p);
+  } else if constexpr (ALL_LOADERS) {   // stem (Cin = 4) and DCN gather loaders: basic tiles only; DCN: exact-fp32 MFMA only
+    if (loader == 1) hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, NS, 1, PREC>), dim3(grid, groups), dim3(64 * WM * WN * WK), dyn, s, p);
+    else if constexpr (PREC == 0) hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, NS, 2, 0>), dim3(grid, groups), dim3(64 * WM * WN * WK), dyn, s, p);
+    else return YMI_EARG;
   } else {
     return YMI_EARG;
   }
@@ -879,10 +897,10 @@ int launch_prec(const KParams &kp, int loader, hipStream_t s, int groups) {
   X(YMI_TILE_128x128_W8_S3, 4, 2, 1, 1, 2, 3, false, 0)        \
   X(YMI_TILE_256x128_W8_S3, 4, 2, 1, 2, 2, 3, false, 0)        \
   X(YMI_TILE_128x128_W8_S4, 4, 2, 1, 1, 2, 4, false, 0)        \
-  X(YMI_TILE_X3 | YMI_TILE_128x128, 2, 2, 1, 2, 2, 2, false, 1)     \
-  X(YMI_TILE_X3 | YMI_TILE_128x64, 2, 2, 1, 2, 1, 2, false, 1)      \
-  X(YMI_TILE_X3 | YMI_TILE_64x64, 2, 2, 1, 1, 1, 2, false, 1)       \
-  X(YMI_TILE_X3 | YMI_TILE_64x128, 2, 2, 1, 1, 2, 2, false, 1)      \
+  X(YMI_TILE_X3 | YMI_TILE_128x128, 2, 2, 1, 2, 2, 2, true, 1)      \
+  X(YMI_TILE_X3 | YMI_TILE_128x64, 2, 2, 1, 2, 1, 2, true, 1)       \
+  X(YMI_TILE_X3 | YMI_TILE_64x64, 2, 2, 1, 1, 1, 2, true, 1)        \
+  X(YMI_TILE_X3 | YMI_TILE_64x128, 2, 2, 1, 1, 2, 2, true, 1)       \
   X(YMI_TILE_X3 | YMI_TILE_32x32_K4, 1, 1, 4, 1, 1, 2, false, 1)    \
   X(YMI_TILE_X3 | YMI_TILE_64x32_K2, 2, 1, 2, 1, 1, 2, false, 1)    \
   X(YMI_TILE_X3 | YMI_TILE_32x64_K2, 1, 2, 2, 1, 1, 2, false, 1)    \
@@ -1010,7 +1028,7 @@ int run_conv(const ymi_conv_desc *d, int loader, const float *offmask, int ldo, 
 #endif
   kp.trace = g_trace;
   int tile = d->tile ? d->tile : pick_tile(d);
-  if (loader != 0 && !tile_all_loaders(tile)) {
+  if (loader != 0 && (!tile_all_loaders(tile) || (loader == 2 && (tile & YMI_TILE_X3)))) {
     if (d->tile) return YMI_EARG;   // explicit request the stem / DCN loaders cannot honour
     tile = YMI_TILE_64x64;
   }

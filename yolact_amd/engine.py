@@ -296,7 +296,7 @@ class Plan:
                 assert (res.B, res.H, res.W, res.C) == (x.B, Ho, Wo, pk.Cout), name
         d.tile = L.TILE_AUTO
         d.cin_alg = pk.cin_alg
-        if self.split and pk.Cin % 32 == 0:
+        if self.split and dcn_offmask is None:
             d.w_x3 = pk.w3().data_ptr()
         y = None
         if segs is None:
@@ -771,8 +771,9 @@ class Plan:
                     cands = [t for t in sorted(L.TILE_NAMES) if t != L.TILE_128x32 and not (t & L.TILE_X3)]
                     if d.Cout < 256:
                         cands = [t for t in cands if t != L.TILE_128x256_W8]
-                if self.split and d.Cin % 32 == 0:
-                    cands = cands + [t | L.TILE_X3 for t in cands if t in L.X3_BASE_TILES]
+                if self.split:      # (the Cin = 4 stem loader has the basic tiles only)
+                    cands = cands + [t | L.TILE_X3 for t in cands if t in L.X3_BASE_TILES
+                                     and (d.Cin % 32 == 0 or t in L.BASIC_TILES)]
                 best, best_ms, times = None, 1e30, {}
                 ok_cands = []
                 for t in cands:                       # warm every candidate once (code fetch, clocks); skip the
