@@ -98,9 +98,10 @@ def roofline(net, x, reps=3):
         os.environ['YOLACT_AMD_GRAPH'] = graph
     n = lib.ymi_prof_count()
     ms, fl, tile, kind = C.c_float(), C.c_double(), C.c_int32(), C.c_int32()
-    # record kinds: 0/1/2 = one direct conv launch (loader id); 3 / 4 = a whole Winograd F(2x2) / F(4x4) layer (input
-    # transform + 16- / 36-group GEMM + output transform, ALGORITHMIC conv FLOPs); 5 / 6 = the Winograd GEMM launch alone
-    # (the FLOPs it executes).  Layer table / all_conv: kinds 0-4.  Single-kernel roofline: kinds 0-2, 5 and 6.
+    # record kinds: 0/1/2 = one direct conv launch (loader id), 7 = a direct 1x1 launch on the pointwise loader (kernel
+    # template LOADER 3); 3 / 4 = a whole Winograd F(2x2) / F(4x4) layer (input transform + 16- / 36-group GEMM + output
+    # transform, ALGORITHMIC conv FLOPs); 5 / 6 = the Winograd GEMM launch alone (the FLOPs it executes).
+    # Layer table / all_conv: kinds 0-4 and 7.  Single-kernel roofline: kinds 0-2, 7, 5 and 6.
     by_kernel, layers = {}, {}
     tot_ms = tot_fl = 0.0
     li = -1
@@ -111,14 +112,14 @@ def roofline(net, x, reps=3):
         if kind.value not in (5, 6):
             li += 1
             lkey = ('winograd F(%dx%d,3x3) <gemm %s> (3 launches)' % (2 * kind.value - 4, 2 * kind.value - 4, tname)) \
-                if kind.value in (3, 4) else 'conv_igemm_f32<%s,loader%d>' % (tname, kind.value)
+                if kind.value in (3, 4) else 'conv_igemm_f32<%s,loader%d>' % (tname, 3 if kind.value == 7 else kind.value)
             la = layers.setdefault(names[li % nl], [0.0, fl.value, lkey])
             la[0] += ms.value / reps
             la[2] = lkey
             tot_ms += ms.value; tot_fl += fl.value
         if kind.value not in (3, 4):
             key = ('conv_igemm_f32<%s,winograd grouped GEMM>' % tname) if kind.value in (5, 6) else \
-                'conv_igemm_f32<%s,loader%d>' % (tname, kind.value)
+                'conv_igemm_f32<%s,loader%d>' % (tname, 3 if kind.value == 7 else kind.value)
             a = by_kernel.setdefault(key, [0.0, 0.0, 0])
             a[0] += ms.value; a[1] += fl.value; a[2] += 1
     lib.ymi_prof_reset()

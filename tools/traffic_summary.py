@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Aggregate two rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE) of bench.py into HBM bytes per launch per conv
 kernel, keyed like bench.py's roofline.kernel.  FETCH_SIZE is doubled (gfx950 counts 128-byte requests as 64 B,
-MI355X_MICROARCH.md "HBM").   python tools/traffic_summary.py FETCH_DIR WRITE_DIR > profiles/r01_traffic.json"""
+MI355X_MICROARCH.md "HBM").   python tools/traffic_summary.py FETCH_DIR WRITE_DIR > profiles/r02_traffic.json"""
 import csv, glob, json, os, re, sys
 from collections import defaultdict
 
@@ -9,7 +9,20 @@ TILES = {(2, 2, 1, 2, 2, 2): '128x128', (2, 2, 1, 2, 1, 2): '128x64', (2, 2, 1, 
          (2, 2, 1, 1, 2, 2): '64x128', (1, 1, 4, 1, 1, 2): '32x32k4', (2, 1, 2, 1, 1, 2): '64x32k2', (1, 2, 2, 1, 1, 2): '32x64k2',
          (2, 2, 1, 1, 1, 3): '64x64s3', (2, 2, 1, 1, 1, 4): '64x64s4', (2, 2, 1, 1, 2, 3): '64x128s3', (2, 2, 1, 2, 1, 3): '128x64s3',
          (1, 1, 4, 1, 1, 4): '32x32k4s4', (2, 1, 2, 1, 1, 3): '64x32k2s3', (1, 2, 2, 1, 1, 3): '32x64k2s3',
-         (4, 2, 1, 1, 2, 2): '128x128w8', (4, 2, 1, 2, 2, 2): '256x128w8', (4, 2, 1, 1, 4, 2): '128x256w8'}
+         (4, 2, 1, 1, 2, 2): '128x128w8', (4, 2, 1, 2, 2, 2): '256x128w8', (4, 2, 1, 1, 4, 2): '128x256w8',
+         (2, 2, 1, 2, 2, 3): '128x128s3', (4, 2, 1, 1, 2, 3): '128x128w8s3', (4, 2, 1, 2, 2, 3): '256x128w8s3',
+         (4, 2, 1, 1, 2, 4): '128x128w8s4'}
+
+
+def grouped_dispatches(counter_csv):
+    """Dispatch ids of launches with gridDim.y > 1 (the grouped Winograd GEMMs), from the kernel trace of the same run:
+    the pointwise loader (template LOADER 3) serves both the 1x1 convolutions and the grouped GEMMs."""
+    out = set()
+    for f in glob.glob(os.path.join(os.path.dirname(counter_csv), '*kernel_trace.csv')):
+        for r in csv.DictReader(open(f)):
+            if 'conv_igemm' in r['Kernel_Name'] and int(r.get('Grid_Size_Y', 1) or 1) > 1:
+                out.add(r['Dispatch_Id'])
+    return out
 
 
 def steady_rows(f, counter):
@@ -31,13 +44,15 @@ def collect(root, counter):
     acc = defaultdict(lambda: [0.0, 0])
     files = sorted(glob.glob(os.path.join(root, '**', '*counter_collection.csv'), recursive=True), key=os.path.getmtime)
     for f in files[-1:]:                      # the newest run only (gpurun_out/ accumulates earlier sessions)
+        grouped = grouped_dispatches(f)
         for r in steady_rows(f, counter):
-            m = re.search(r'conv_igemm_f32<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>', r['Kernel_Name'])
+            m = re.search(r'conv_igemm_f32<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>', r['Kernel_Name'])
             if not m:
                 continue
             v = tuple(int(x) for x in m.groups())
-            key = ('conv_igemm_f32<%s,winograd grouped GEMM>' % TILES.get(v[:6], str(v[:6]))) if v[6] == 3 else \
-                'conv_igemm_f32<%s,loader%d>' % (TILES.get(v[:6], str(v[:6])), v[6])
+            tile = TILES.get(v[:6], str(v[:6])) + ('x3' if v[7] else '')
+            key = ('conv_igemm_f32<%s,winograd grouped GEMM>' % tile) if (v[6] == 3 and r['Dispatch_Id'] in grouped) else \
+                'conv_igemm_f32<%s,loader%d>' % (tile, v[6])
             a = acc[key]
             a[0] += float(r['Counter_Value']); a[1] += 1
     return acc

@@ -1039,7 +1039,10 @@ int run_conv(const ymi_conv_desc *d, int loader, const float *offmask, int ldo, 
     if (g_prof_n < PROF_MAX) {
       pr = &g_prof[g_prof_n];
       if (g_prof_n >= g_prof_alloc) { hipEventCreate(&pr->e0); hipEventCreate(&pr->e1); g_prof_alloc = g_prof_n + 1; }
-      pr->flops = prof_flops >= 0 ? prof_flops : ymi_conv_flops(d); pr->tile = tile; pr->kind = prof_kind >= 0 ? prof_kind : loader;
+      // record kind: 0 / 1 / 2 = the loader of a direct launch, 7 = a direct 1x1 launch on the pointwise loader (template
+      // LOADER 3); 3 .. 6 are the Winograd records of csrc/winograd.hip
+      const bool pw = loader == 0 && d->kh == 1 && d->kw == 1 && d->pad == 0;
+      pr->flops = prof_flops >= 0 ? prof_flops : ymi_conv_flops(d); pr->tile = tile; pr->kind = prof_kind >= 0 ? prof_kind : (pw ? 7 : loader);
       hipEventRecord(pr->e0, s);
     }
   }

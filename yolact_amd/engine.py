@@ -25,8 +25,8 @@ def _ceil(a, b):
 
 
 # ---- shipped tile / algorithm table ------------------------------------------------------------------------------
-SPLIT_DEFAULT = '0'   # default of YOLACT_AMD_SPLIT (see Plan.__init__)
-TUNE_GEN = 2          # bump whenever tile ids or kernel variants change meaning: older tables are ignored
+SPLIT_DEFAULT = '1'   # default of YOLACT_AMD_SPLIT (see Plan.__init__)
+TUNE_GEN = 3          # bump whenever tile ids or kernel variants change meaning: older tables are ignored
 TUNE_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tune')
 _table_cache = {}
 
