@@ -59,12 +59,17 @@ typedef struct {
   int32_t nseg;         /* 1..3 */
   int32_t tile;         /* 0 = auto; else YMI_TILE_* override (tests / tuning) */
   int32_t cin_alg;      /* real (un-padded) input channels for FLOP accounting; 0 = Cin */
-  int32_t _pad0;
+  int32_t split_k;      /* 0 / 1: off.  S > 1: 1x1 convolutions only — the K = Cin reduction is cut into S ranges computed by S
+                         * times as many blocks (small maps, long K: too few output tiles to fill 256 CUs otherwise); the
+                         * partial sums go through `split_ws` and are added in a fixed order (deterministic) by a second
+                         * launch that applies scale / bias / residual / activation.  Needs (Kpad / 32) % S == 0, one dense
+                         * output segment, activation none / ReLU / LeakyReLU, residual none / add. */
   ymi_conv_seg seg[3];
   const void *w_x3;     /* optional, for tile | YMI_TILE_X3: the SAME filters pre-split into three bf16 planes
                          * [3][CoutPad][Kpad] (uint16 bit patterns; plane 0 = top 8 significant bits by truncation, 1 = next 8,
                          * 2 = last 8; plane0 + plane1 + plane2 == w exactly).  With it the kernel splits only the activations
                          * on the fly (a third of the VALU work); NULL: both operands are split on the fly. */
+  float *split_ws;      /* split_k > 1: workspace of split_k * B*Ho*Wo * Cout floats, 16-byte aligned */
 } ymi_conv_desc;
 
 /* block tile BMxBN; _Kn = the block's 4 waves also split K n ways (partial sums reduced in LDS in a fixed order:

@@ -20,7 +20,7 @@ def nchw(x_nhwc):
 
 
 def run_conv(x, weight, bias=None, bn=None, stride=1, pad=0, act=L.ACT_NONE, res=None, res_mode=L.RES_NONE,
-             res_after_act=0, tile=L.TILE_AUTO, cin_pad=None, dcn_offmask=None, planes=True):
+             res_after_act=0, tile=L.TILE_AUTO, cin_pad=None, dcn_offmask=None, planes=True, split_k=0):
     """x: CPU NCHW tensor. Returns CPU NCHW output of the HIP conv.  `planes`: for bf16x3 tiles also hand the kernel the
     pre-split filter planes (ymi_conv_desc.w_x3); False = both operands are split on the fly."""
     pk = Packed(weight, bias, bn, stride, pad, cin_pad, DEV)
@@ -47,6 +47,10 @@ def run_conv(x, weight, bias=None, bn=None, stride=1, pad=0, act=L.ACT_NONE, res
     d.seg[0] = L.ConvSeg(0, pk.Cout, act, pk.Cout, Ho * Wo * pk.Cout, y.data_ptr())
     if (tile & L.TILE_X3) and planes and dcn_offmask is None:
         d.w_x3 = pk.w3().data_ptr()
+    ws = None
+    if split_k > 1:
+        ws = torch.full((split_k * B * Ho * Wo * pk.Cout,), float('nan'), device=DEV)
+        d.split_k, d.split_ws = split_k, ws.data_ptr()
     s = L.stream_ptr()
     if dcn_offmask is not None:
         om = nhwc(dcn_offmask).to(DEV)

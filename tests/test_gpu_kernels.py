@@ -328,3 +328,47 @@ def test_conv_bf16x3_is_fp32_class(base):
             L.TILE_NAMES[base], e32, 'filter planes' if planes else 'both split on the fly', ex3))
         assert e32 < 1e-5 and ex3 < 1e-5      # K = 2304 products of mixed magnitude: both are fp32-rounding class
         assert ex3 < 2 * e32 + 1e-7           # measured: the split path is the MORE accurate one (2.0e-6 vs 4.0e-6, 64x64 tile)
+
+
+@pytest.mark.parametrize('tile', [L.TILE_128x128, L.TILE_64x128 | L.TILE_X3, L.TILE_128x128 | L.TILE_X3, L.TILE_256x128_W8 | L.TILE_X3,
+                                  L.TILE_64x64 | L.TILE_X3])
+@pytest.mark.parametrize('S', [2, 4])
+def test_conv_1x1_split_k(tile, S):
+    """split_k: the K reduction of a 1x1 convolution cut into S ranges (S x the blocks), partial sums added in a fixed
+    order by the second pass together with folded BN + residual + ReLU / LeakyReLU (darknet order too); stride 2 as well."""
+    from gpu_utils import run_conv, rel_err
+    import torch.nn as nn
+    g = _g(400 + S)
+    for (B, Cin, H, W, Cout, stride) in ((2, 512, 13, 11, 256, 1), (1, 1024, 9, 9, 2048, 2), (3, 256, 7, 5, 132, 1)):
+        x = torch.randn(B, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+        bn = nn.BatchNorm2d(Cout).eval()
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(Cout, generator=g) + 0.5)
+            bn.bias.copy_(torch.randn(Cout, generator=g) * 0.1)
+            bn.running_mean.copy_(torch.randn(Cout, generator=g) * 0.1)
+            bn.running_var.copy_(torch.rand(Cout, generator=g) + 0.5)
+            conv = bn(F.conv2d(x, w, None, stride))
+        res = torch.randn(conv.shape, generator=g)
+        y = run_conv(x, w, None, bn, stride, 0, act=L.ACT_RELU, res=res, res_mode=L.RES_ADD, tile=tile, split_k=S)
+        assert rel_err(y, F.relu(conv + res)) < 2e-5
+        y2 = run_conv(x, w, None, bn, stride, 0, act=L.ACT_LEAKY01, res=res, res_mode=L.RES_ADD, res_after_act=1, tile=tile, split_k=S)
+        assert rel_err(y2, F.leaky_relu(conv, 0.1) + res) < 2e-5
+        y3 = run_conv(x, w, torch.randn(Cout, generator=_g(5)), None, stride, 0, tile=tile, split_k=S)
+        assert rel_err(y3, F.conv2d(x, w, torch.randn(Cout, generator=_g(5)), stride)) < 2e-5
+        # unsplit launch of the same tile: same sums up to the fp32 association of the S partials
+        y0 = run_conv(x, w, None, bn, stride, 0, act=L.ACT_RELU, res=res, res_mode=L.RES_ADD, tile=tile)
+        assert rel_err(y, y0) < 5e-6
+
+
+def test_conv_split_k_rejects_unsupported():
+    from gpu_utils import run_conv
+    x = torch.randn(1, 64, 8, 8, generator=_g(1))
+    w3 = torch.randn(64, 64, 3, 3, generator=_g(2)) / 24
+    with pytest.raises(RuntimeError):
+        run_conv(x, w3, None, None, 1, 1, split_k=2)                     # 3x3: not a pointwise layer
+    w1 = torch.randn(64, 64, 1, 1, generator=_g(3)) / 8
+    with pytest.raises(RuntimeError):
+        run_conv(x, w1, None, None, 1, 0, split_k=4)                     # K = 64 = 2 chunks: not divisible into 4 ranges
+    with pytest.raises(RuntimeError):
+        run_conv(x, w1, None, None, 1, 0, act=L.ACT_TANH, split_k=2)     # epilogue outside the second pass's repertoire

@@ -44,8 +44,8 @@ class ConvDesc(C.Structure):
                 ('kh', C.c_int32), ('kw', C.c_int32), ('stride', C.c_int32), ('pad', C.c_int32),
                 ('Kpad', C.c_int32), ('res_mode', C.c_int32), ('res_ld', C.c_int32),
                 ('res_H', C.c_int32), ('res_W', C.c_int32), ('res_after_act', C.c_int32),
-                ('nseg', C.c_int32), ('tile', C.c_int32), ('cin_alg', C.c_int32), ('_pad0', C.c_int32),
-                ('seg', ConvSeg * 3), ('w_x3', C.c_void_p)]
+                ('nseg', C.c_int32), ('tile', C.c_int32), ('cin_alg', C.c_int32), ('split_k', C.c_int32),
+                ('seg', ConvSeg * 3), ('w_x3', C.c_void_p), ('split_ws', C.c_void_p)]
 
 
 class WinoDesc(C.Structure):

@@ -81,7 +81,8 @@ struct KParams {
   int ldo;
   long x_gs, w_gs, y_gs;          // grouped GEMM (gridDim.y groups, Winograd): element strides of x / w / seg[0].ptr per group
   const void *w3;                 // PREC == 2: filters pre-split into three bf16 planes [groups][3][CoutPad][Kpad]
-  unsigned w3_plane;              // PREC == 2: bytes between planes (CoutPad * Kpad * 2); a group is 3 planes
+  unsigned w3_plane;              // PREC == 2: bytes between planes (CoutPad * Kpad * 2)
+  unsigned w3_gs;                 // PREC == 2: bytes between groups (3 planes for a Winograd component, K range * 2 for split-K)
   unsigned long long *trace;      // diagnostics only (ymi_debug_set_trace): per block {hw id, t0, t_loop, t_epi, t1, t_transposed}
   int abl;                        // diagnostics only (env YMI_ABLATE): bit0 skip the staging of chunks > 0,
                                   // bit2 skip barriers in the K loop — wrong results, used to attribute stall time;
@@ -273,7 +274,7 @@ void conv_igemm_f32(const KParams p) {
   const __amdgpu_buffer_rsrc_t xrs =
       __builtin_amdgcn_make_buffer_rsrc((void *)(d.x + (size_t)grp * p.x_gs), 0, (int)p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wrs = (PREC == 2)
-      ? __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.w3 + (size_t)grp * 3 * p.w3_plane), 0, (int)(3 * p.w3_plane), 0x00020000)
+      ? __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.w3 + (size_t)grp * p.w3_gs), 0, (int)(3 * p.w3_plane), 0x00020000)
       : __builtin_amdgcn_make_buffer_rsrc((void *)(d.w + (size_t)grp * p.w_gs), 0, (int)p.w_bytes, 0x00020000);
 
   // ---- epilogue thread mapping + residual prefetch -----------------------------------------------
@@ -995,8 +996,11 @@ int validate(const ymi_conv_desc *d, int loader) {
   return YMI_OK;
 }
 
+// split_k > 1 (internal, ymi_conv2d_nhwc_f32 with desc->split_k): the `groups` of the launch are K ranges of ONE pointwise
+// GEMM — group g multiplies channels [g*K/S, (g+1)*K/S) and writes its raw partial sums to ws + g*M*Cout (fast-path
+// epilogue, no scale / bias / activation); splitk_fixup_k then adds the partials in a fixed order and applies the epilogue.
 int run_conv(const ymi_conv_desc *d, int loader, const float *offmask, int ldo, hipStream_t s, int groups = 1, long x_gs = 0,
-             long w_gs = 0, long y_gs = 0, double prof_flops = -1.0, int prof_kind = -1) {
+             long w_gs = 0, long y_gs = 0, double prof_flops = -1.0, int prof_kind = -1, int split_k = 1) {
   int rc = validate(d, loader);
   // grouped launches take the fast-path epilogue only (it applies the group's output offset)
   if (rc == YMI_OK && groups > 1 &&
@@ -1009,7 +1013,7 @@ int run_conv(const ymi_conv_desc *d, int loader, const float *offmask, int ldo, 
   kp.d = *d;
   kp.HoWo = d->Ho * d->Wo;
   kp.M = d->B * kp.HoWo;
-  kp.nk = d->Kpad / BK;
+  kp.nk = d->Kpad / BK / split_k;
   kp.tiles_n = 0;
   kp.x_bytes = (unsigned)((size_t)d->B * d->H * d->W * d->ldx * sizeof(float));
   {
@@ -1021,6 +1025,7 @@ int run_conv(const ymi_conv_desc *d, int loader, const float *offmask, int ldo, 
   kp.x_gs = x_gs; kp.w_gs = w_gs; kp.y_gs = y_gs;
   kp.w3 = d->w_x3;
   kp.w3_plane = (unsigned)((((long)d->Cout + 127) / 128 * 128) * d->Kpad * 2L);
+  kp.w3_gs = split_k > 1 ? (unsigned)(d->Kpad / split_k * 2) : 3u * kp.w3_plane;
   if (kp.w3 && (((uintptr_t)kp.w3) & 15)) return YMI_ESHAPE;
   kp.abl = 0;
 #ifdef YMI_DIAGNOSTICS   // `make DIAG=1`: ablation switches for tools/conv_probe.py — they produce WRONG results by design
@@ -1034,7 +1039,7 @@ int run_conv(const ymi_conv_desc *d, int loader, const float *offmask, int ldo, 
   }
   ProfRec *pr = nullptr;
   std::unique_lock<std::mutex> prof_lock(g_prof_mu, std::defer_lock);
-  if (g_prof_on) {
+  if (g_prof_on && prof_kind != -2) {       // (-2: the caller brackets several launches with its own record)
     prof_lock.lock();            // held across the launch so e0 / launch / e1 of one record stay together on the stream
     if (g_prof_n < PROF_MAX) {
       pr = &g_prof[g_prof_n];
@@ -1056,6 +1061,70 @@ int run_conv(const ymi_conv_desc *d, int loader, const float *offmask, int ldo, 
   return rc;
 }
 
+// ---- split-K second pass: y = act(scale * sum_g partial[g] + bias (+ res)) ------------------------------------------
+// One float4 of output channels per thread; partials are added in the order g = 0 .. S-1 (bit-reproducible).
+__global__ __launch_bounds__(256) void splitk_fixup_k(const float *__restrict__ part, long gstride, int S, long M, int N4, int ldy,
+                                                      float *__restrict__ y, const float *__restrict__ scale,
+                                                      const float *__restrict__ bias, const float *__restrict__ res, int res_ld,
+                                                      int act, int res_after_act) {
+  const long total = M * N4;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    const long m = i / N4;
+    const int n = (int)(i - m * N4) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4 *>(part + m * (N4 * 4L) + n);
+    for (int g = 1; g < S; ++g) v += *reinterpret_cast<const f32x4 *>(part + g * gstride + m * (N4 * 4L) + n);
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f}, rv = {0.f, 0.f, 0.f, 0.f};
+    if (scale) sc = *reinterpret_cast<const f32x4 *>(scale + n);
+    if (bias) bi = *reinterpret_cast<const f32x4 *>(bias + n);
+    if (res) rv = *reinterpret_cast<const f32x4 *>(res + m * res_ld + n);
+    v = v * sc + bi;
+    const float slope = act == YMI_ACT_RELU ? 0.f : (act == YMI_ACT_LEAKY01 ? 0.1f : 1.f);
+    if (!res_after_act) v += rv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], slope * v[e]);
+    if (res_after_act) v += rv;
+    *reinterpret_cast<f32x4 *>(y + m * ldy + n) = v;
+  }
+}
+
+int ymi_internal_prof_begin_fwd(double flops, int tile, int kind, hipStream_t s);
+void ymi_internal_prof_end_fwd(int idx, hipStream_t s);
+
+int run_splitk(const ymi_conv_desc *d, hipStream_t s) {
+  const int S = d->split_k;
+  int rc = validate(d, 0);
+  if (rc) return rc;
+  const ymi_conv_seg &g0 = d->seg[0];
+  const long HoWo = (long)d->Ho * d->Wo, M = (long)d->B * HoWo;
+  if (d->kh != 1 || d->kw != 1 || d->pad != 0 || d->Cin != d->Kpad || S < 2 || S > 16 || (d->Kpad / BK) % S != 0) return YMI_EARG;
+  if (d->nseg != 1 || g0.n0 != 0 || g0.n1 < d->Cout || (d->Cout & 3) || (g0.row_stride & 3) || (((uintptr_t)g0.ptr) & 15) ||
+      g0.batch_stride != HoWo * g0.row_stride || g0.act > YMI_ACT_LEAKY01 || g0.act < 0)
+    return YMI_ESHAPE;
+  if (d->res_mode != YMI_RES_NONE && (d->res_mode != YMI_RES_ADD || (d->res_ld & 3) || (((uintptr_t)d->res) & 15))) return YMI_ESHAPE;
+  if ((((uintptr_t)d->scale) | ((uintptr_t)d->bias)) & 15) return YMI_ESHAPE;
+  if (!d->split_ws) return YMI_ENULL;
+  if (((uintptr_t)d->split_ws) & 15) return YMI_ESHAPE;
+  if (M * d->Cout >= (1L << 29)) return YMI_ESHAPE;
+  ymi_conv_desc pd = *d;
+  pd.split_k = 0;
+  pd.scale = nullptr; pd.bias = nullptr; pd.res = nullptr; pd.res_mode = YMI_RES_NONE; pd.res_after_act = 0;
+  pd.seg[0].n0 = 0; pd.seg[0].n1 = d->Cout; pd.seg[0].act = YMI_ACT_NONE; pd.seg[0].row_stride = d->Cout;
+  pd.seg[0].batch_stride = HoWo * d->Cout; pd.seg[0].ptr = d->split_ws;
+  const int outer = ymi_internal_prof_begin_fwd(ymi_conv_flops(d), d->tile ? d->tile : pick_tile(d), 7, s);
+  const long ksub = d->Kpad / S;
+  rc = run_conv(&pd, 0, nullptr, 0, s, S, ksub, ksub, M * d->Cout, -1.0, -2, S);
+  if (rc) return rc;
+  const long total = M * (d->Cout / 4);
+  long gsz = (total + 255) / 256;
+  const long cap = 256L * 32;
+  hipLaunchKernelGGL(splitk_fixup_k, dim3((unsigned)(gsz > cap ? cap : gsz)), dim3(256), 0, s, d->split_ws, M * (long)d->Cout, S, M,
+                     d->Cout / 4, g0.row_stride, g0.ptr, d->scale, d->bias, d->res_mode == YMI_RES_ADD ? d->res : nullptr,
+                     d->res_ld, g0.act, d->res_after_act);
+  rc = ymi_launch_status();
+  ymi_internal_prof_end_fwd(outer, s);
+  return rc;
+}
+
 }  // namespace
 
 // internal (not part of the C ABI): profiling brackets for composite ops (csrc/winograd.hip): a record that spans
@@ -1073,6 +1142,10 @@ int ymi_internal_prof_begin(double flops, int tile, int kind, hipStream_t s) {
 void ymi_internal_prof_end(int idx, hipStream_t s) {
   if (idx >= 0) hipEventRecord(g_prof[idx].e1, s);
 }
+namespace {
+int ymi_internal_prof_begin_fwd(double flops, int tile, int kind, hipStream_t s) { return ymi_internal_prof_begin(flops, tile, kind, s); }
+void ymi_internal_prof_end_fwd(int idx, hipStream_t s) { ymi_internal_prof_end(idx, s); }
+}  // namespace
 
 // internal (not part of the C ABI): grouped GEMM for csrc/winograd.hip — `groups` independent 1x1 GEMMs that share the
 // descriptor's shape; group g reads x + g*x_gs, w + g*w_gs and writes seg[0].ptr + g*y_gs.
@@ -1091,6 +1164,7 @@ int ymi_conv_pick_tile(const ymi_conv_desc *d) { return d ? pick_tile(d) : YMI_E
 
 int ymi_conv2d_nhwc_f32(const ymi_conv_desc *d, void *stream) {
   if (!d) return YMI_ENULL;
+  if (d->split_k > 1) return run_splitk(d, (hipStream_t)stream);
   return run_conv(d, d->Cin == 4 ? 1 : 0, nullptr, 0, (hipStream_t)stream);
 }
 

@@ -249,6 +249,9 @@ class Plan:
         # MFMAs per product at 16x the fp32-MFMA rate, csrc/conv_igemm.hip split8) join the candidates of every Cin % 32
         # == 0 layer and of the Winograd GEMMs; the measurement decides per shape
         self.split = os.environ.get('YOLACT_AMD_SPLIT', SPLIT_DEFAULT) == '1'
+        # YOLACT_AMD_SPLITK=0 keeps every GEMM a single pass (no split-K candidates in the tuner)
+        self.splitk = os.environ.get('YOLACT_AMD_SPLITK', '1') == '1'
+        self._sk_ws = {}
         self.down_on_side_stream = os.environ.get('YOLACT_AMD_DOWN_STREAM', 'B') == 'B'      # measured +1 %
         self.wino_alt, self._wino_packed, self._wino_ws = {}, {}, {}
         self._done_event = None
@@ -740,23 +743,53 @@ class Plan:
 
     autotune = tune      # round-1 name
 
+    def _splitk_ws(self, where, numel):
+        """Per-stream workspace of the split-K partial sums (grown on demand; every layer of a stream shares it)."""
+        ws = self._sk_ws.get(where)
+        if ws is None or ws.numel() < numel:
+            ws = self._sk_ws[where] = torch.empty(numel, dtype=torch.float32, device=self.device)
+            for fn, dptr, _n, w in self.ops:          # re-point descriptors that already use the old buffer
+                if fn is self.lib.ymi_conv2d_nhwc_f32 and w == where and dptr.contents.split_k > 1:
+                    dptr.contents.split_ws = ws.data_ptr()
+        return ws
+
+    @staticmethod
+    def _splitk_ok(d):
+        """Shapes the split-K path takes (csrc/conv_igemm.hip run_splitk): small-map 1x1 convolutions with a long K."""
+        return (d.kh == 1 and d.kw == 1 and d.pad == 0 and d.Cin == d.Kpad and d.Cin % 32 == 0 and d.nseg == 1
+                and d.Cout % 4 == 0 and d.seg[0].act <= L.ACT_LEAKY01 and d.res_mode in (L.RES_NONE, L.RES_ADD)
+                and d.B * d.Ho * d.Wo <= 16384 and d.Kpad >= 256)
+
+    def _apply_choice(self, fn, dptr, where, val, s):
+        """Install a table value (tile id + 256 * split_k) in a descriptor; returns the launch status of one run."""
+        d = dptr.contents
+        tile, S = int(val) & 255, int(val) >> 8
+        d.tile = tile
+        if S > 1:
+            if not self._splitk_ok(d) or (d.Kpad // 32) % S:
+                return -1
+            d.split_k = S
+            d.split_ws = self._splitk_ws(where, S * d.B * d.Ho * d.Wo * d.Cout).data_ptr()
+        else:
+            d.split_k = 0
+        return fn(dptr, s)
+
     def _tune_direct(self, e0, e1, s, reps, disk, measure):
         cache = {}
-        for fn, dptr, name, _where in self.ops:
+        for fn, dptr, name, where in self.ops:
             if fn is not self.lib.ymi_conv2d_nhwc_f32:
                 continue
             d = dptr.contents
             key = (d.B, d.H, d.W, d.Cin, d.Cout, d.kh, d.kw, d.stride, d.pad, d.res_mode, d.nseg, d.Kpad)
             skey = str(key) + ('|x3' if self.split else '')
             if key not in cache and skey in disk:
-                d.tile = int(disk[skey])
-                if fn(dptr, s) == 0:                      # a stale / foreign entry must not make every forward raise
-                    cache[key] = d.tile
+                if self._apply_choice(fn, dptr, where, disk[skey], s) == 0:   # a stale / foreign entry must not make every forward raise
+                    cache[key] = int(disk[skey])
             if key not in cache:
                 self.tune_misses += 1
                 if not measure:
                     cache[key] = L.TILE_AUTO
-                    d.tile = L.TILE_AUTO
+                    d.tile, d.split_k = L.TILE_AUTO, 0
                     continue
                 if d.Cin % 32 != 0:          # stem loader: basic tiles only
                     cands = [L.TILE_128x64, L.TILE_64x64] if d.Cout <= 64 else list(L.BASIC_TILES)
@@ -774,31 +807,39 @@ class Plan:
                 if self.split:      # (the Cin = 4 stem loader has the basic tiles only)
                     cands = cands + [t | L.TILE_X3 for t in cands if t in L.X3_BASE_TILES
                                      and (d.Cin % 32 == 0 or t in L.BASIC_TILES)]
+                if self._splitk_ok(d) and self.splitk:
+                    # split-K candidates: big tiles whose grid alone cannot fill the chip, K cut 2 / 4 ways
+                    x3 = L.TILE_X3 if self.split else 0
+                    for S in (2, 4):
+                        if (d.Kpad // 32) % S == 0 and d.Kpad // S >= 128:
+                            cands += [(t | x3) + 256 * S for t in (L.TILE_128x128, L.TILE_64x128, L.TILE_128x64, L.TILE_64x64,
+                                                                  L.TILE_256x128_W8)]
+
+                def cname(v):
+                    return L.TILE_NAMES[v & 255] + ('/k%d' % (v >> 8) if v >> 8 else '')
                 best, best_ms, times = None, 1e30, {}
                 ok_cands = []
                 for t in cands:                       # warm every candidate once (code fetch, clocks); skip the
-                    d.tile = t                        # ones this layer cannot use
-                    if fn(dptr, s) == 0:
+                    if self._apply_choice(fn, dptr, where, t, s) == 0:        # ones this layer cannot use
                         ok_cands.append(t)
                 for rnd in range(2):                  # two interleaved rounds, keep each tile's best time: a single
                     for t in ok_cands:                # noisy sample used to flip near-ties and move bench by +-3 %
-                        d.tile = t
+                        self._apply_choice(fn, dptr, where, t, s)
                         e0.record()
                         for _ in range(reps):
                             fn(dptr, s)
                         e1.record()
                         e1.synchronize()
                         ms = e0.elapsed_time(e1) / reps
-                        name_t = L.TILE_NAMES[t]
-                        times[name_t] = round(min(ms, times.get(name_t, 1e30)), 4)
+                        times[cname(t)] = round(min(ms, times.get(cname(t), 1e30)), 4)
                 for t in ok_cands:
-                    if times[L.TILE_NAMES[t]] < best_ms:
-                        best, best_ms = t, times[L.TILE_NAMES[t]]
+                    if times[cname(t)] < best_ms:
+                        best, best_ms = t, times[cname(t)]
                 assert best is not None, name
                 cache[key] = best
                 disk[skey] = best
-                self.tune_table.append((name, L.TILE_NAMES[best], times))
-            d.tile = cache[key]
+                self.tune_table.append((name, cname(best), times))
+            self._apply_choice(fn, dptr, where, cache[key], s)
 
     def _tune_winograd(self, e0, e1, s, reps, disk, measure):
         """Per eligible layer: best GEMM tile of the Winograd path, then Winograd vs the (already tuned) direct kernel.
