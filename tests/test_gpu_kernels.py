@@ -372,3 +372,54 @@ def test_conv_split_k_rejects_unsupported():
         run_conv(x, w1, None, None, 1, 0, split_k=4)                     # K = 64 = 2 chunks: not divisible into 4 ranges
     with pytest.raises(RuntimeError):
         run_conv(x, w1, None, None, 1, 0, act=L.ACT_TANH, split_k=2)     # epilogue outside the second pass's repertoire
+
+
+@pytest.mark.parametrize('mode', ['direct', 'direct_x3', 'wino2', 'wino4', 'wino4_x3'])
+def test_merged_two_output_conv(mode):
+    """The merged head0.upfeature + proto_net[0] launch (engine.Plan: one 3x3 conv of P3 with the two filter banks
+    concatenated along Cout, scattering to two dense NHWC tensors with ReLU): direct kernel (segment epilogue) and the
+    segmented Winograd output transform (16-byte store path), against two separate torch convolutions."""
+    from gpu_utils import nhwc, nchw, DEV
+    from yolact_amd.engine import Packed, WinoPacked
+    g = _g(77)
+    B, Cin, H, W, C1, C2 = 2, 64, 11, 9, 64, 32
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w1, w2 = torch.randn(C1, Cin, 3, 3, generator=g) / 24, torch.randn(C2, Cin, 3, 3, generator=g) / 24
+    b1, b2 = torch.randn(C1, generator=g), torch.randn(C2, generator=g)
+    wcat, bcat = torch.cat([w1, w2]), torch.cat([b1, b2])
+    pk = Packed(wcat, bcat, None, 1, 1, None, DEV)
+    xd = nhwc(x).to(DEV)
+    y1 = torch.full((B, H, W, C1), float('nan'), device=DEV)
+    y2 = torch.full((B, H, W, C2), float('nan'), device=DEV)
+    segs = [L.ConvSeg(0, C1, L.ACT_RELU, C1, H * W * C1, y1.data_ptr()), L.ConvSeg(C1, C1 + C2, L.ACT_RELU, C2, H * W * C2, y2.data_ptr())]
+    x3 = L.TILE_X3 if mode.endswith('x3') else 0
+    if mode.startswith('direct'):
+        d = L.ConvDesc()
+        d.x, d.w, d.bias = xd.data_ptr(), pk.w.data_ptr(), pk.bias.data_ptr()
+        d.B, d.H, d.W, d.Cin, d.ldx, d.Ho, d.Wo, d.Cout = B, H, W, Cin, Cin, H, W, C1 + C2
+        d.kh, d.kw, d.stride, d.pad, d.Kpad = 3, 3, 1, 1, pk.Kpad
+        d.nseg, d.tile = 2, L.TILE_64x64 | x3
+        d.seg[0], d.seg[1] = segs
+        if x3:
+            d.w_x3 = pk.w3().data_ptr()
+        L.check(L.lib().ymi_conv2d_nhwc_f32(C.byref(d), L.stream_ptr()), 'merged direct')
+        tol = 2e-5
+    else:
+        m = 2 if mode == 'wino2' else 4
+        wp = WinoPacked(wcat, DEV, m)
+        T = B * ((H + m - 1) // m) * ((W + m - 1) // m)
+        V = torch.empty((m + 2) ** 2 * T * Cin, device=DEV)
+        Mw = torch.empty((m + 2) ** 2 * T * (C1 + C2), device=DEV)
+        d = L.WinoDesc()
+        d.x, d.u, d.bias, d.V, d.M = xd.data_ptr(), wp.u.data_ptr(), pk.bias.data_ptr(), V.data_ptr(), Mw.data_ptr()
+        d.B, d.H, d.W, d.C, d.Cout, d.m, d.nseg = B, H, W, Cin, C1 + C2, m, 2
+        d.tile = L.TILE_64x64 | x3
+        d.seg[0], d.seg[1] = segs
+        if x3:
+            d.u_x3 = wp.u3().data_ptr()
+        L.check(L.lib().ymi_conv3x3_winograd_f32(C.byref(d), L.stream_ptr()), 'merged winograd')
+        tol = 2e-5 if m == 2 else 5e-5
+    torch.cuda.synchronize()
+    r1, r2 = F.relu(F.conv2d(x, w1, b1, 1, 1)), F.relu(F.conv2d(x, w2, b2, 1, 1))
+    from gpu_utils import rel_err
+    assert rel_err(nchw(y1.cpu()), r1) < tol and rel_err(nchw(y2.cpu()), r2) < tol

@@ -130,6 +130,30 @@ __device__ __forceinline__ float wino_act(float v, int act) {
   }
 }
 
+// The 4 channels n .. n+3 of a thread lie in ONE segment whose rows can take 16-byte stores (the two dense halves of the
+// merged head0.upfeature + proto_net[0] layer, the loc and coefficient rows of the prediction heads; NOT the 243-float
+// class rows): returns the segment index or -1.
+__device__ __forceinline__ int seg_vec4(const SegTab &st, int n, int Cout) {
+  if (n + 3 >= Cout) return -1;
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    if (k < st.nseg && n >= st.seg[k].n0 && n + 3 < st.seg[k].n1 && ((n - st.seg[k].n0) & 3) == 0 &&
+        (st.seg[k].row_stride & 3) == 0 && (st.seg[k].batch_stride & 3) == 0 && (((uintptr_t)st.seg[k].ptr) & 15) == 0)
+      return k;
+  return -1;
+}
+
+// o = act(o * scale + bias) for 4 consecutive channels of segment k, stored as one float4
+__device__ __forceinline__ void seg_store4(const SegTab &st, int k, f32x4 v, const float *__restrict__ scale,
+                                           const float *__restrict__ bias, int n, long b, long pix) {
+  ymi_conv_seg sg = st.seg[0];
+  if (k == 1) sg = st.seg[1];
+  if (k == 2) sg = st.seg[2];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = wino_act(v[e] * (scale ? scale[n + e] : 1.f) + (bias ? bias[n + e] : 0.f), sg.act);
+  *reinterpret_cast<f32x4 *>(sg.ptr + b * sg.batch_stride + pix * sg.row_stride + (n - sg.n0)) = v;
+}
+
 __global__ __launch_bounds__(256) void wino_out_seg_k(const float *__restrict__ Mm, const SegTab st,
                                                       const float *__restrict__ scale, const float *__restrict__ bias,
                                                       int Ho, int Wo, int N4, int Cout, int th, int tw, long T, long total) {
@@ -156,6 +180,17 @@ __global__ __launch_bounds__(256) void wino_out_seg_k(const float *__restrict__ 
     for (int iy = 0; iy < 2; ++iy) {
       o[iy][0] = (s[iy][0] + s[iy][1]) + s[iy][2];
       o[iy][1] = (s[iy][1] - s[iy][2]) - s[iy][3];
+    }
+    const int kv = seg_vec4(st, n4 * 4, Cout);
+    if (kv >= 0) {
+#pragma unroll
+      for (int iy = 0; iy < 2; ++iy)
+#pragma unroll
+        for (int ix = 0; ix < 2; ++ix) {
+          const int oy = 2 * ty + iy, ox = 2 * tx + ix;
+          if (oy < Ho && ox < Wo) seg_store4(st, kv, o[iy][ix], scale, bias, n4 * 4, b, (long)oy * Wo + ox);
+        }
+      continue;
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -312,6 +347,17 @@ __global__ __launch_bounds__(256) void wino43_out_seg_k(const float *__restrict_
     const long b = r / th;
     f32x4 o[4][4];
     wino43_out_tile(Mm + t * (N4 * 4L) + n4 * 4, T * (N4 * 4L), o);
+    const int kv = seg_vec4(st, n4 * 4, Cout);
+    if (kv >= 0) {
+#pragma unroll
+      for (int iy = 0; iy < 4; ++iy)
+#pragma unroll
+        for (int ix = 0; ix < 4; ++ix) {
+          const int oy = 4 * ty + iy, ox = 4 * tx + ix;
+          if (oy < Ho && ox < Wo) seg_store4(st, kv, o[iy][ix], scale, bias, n4 * 4, b, (long)oy * Wo + ox);
+        }
+      continue;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int n = n4 * 4 + e;

@@ -457,14 +457,39 @@ class Plan:
         for lvl, (fh, fw) in enumerate(shapes):
             pri += make_priors_host(fh, fw, bbc.pred_scales[lvl], bbc.pred_aspect_ratios[lvl], cfg.max_size, bbc)
 
+        # head0.upfeature and proto_net[0] are both 3x3 / pad 1 / 256 -> 256 + ReLU convolutions of the SAME tensor (P3): one
+        # launch with their filters concatenated along Cout shares the input tile (direct kernel) or the whole Winograd input
+        # transform V (one transform instead of two, one 512-column GEMM), and scatters to two dense outputs
+        pmods = list(net.proto_net)
+        up_convs = [m for m in pm.upfeature if isinstance(m, nn.Conv2d)] if hasattr(pm, 'upfeature') else []
+        self._merged_p3 = None
+        merge_p3 = (os.environ.get('YOLACT_AMD_MERGE_P3', '1') == '1' and len(up_convs) == 1 and len(pmods) > 2
+                    and isinstance(pmods[0], nn.Conv2d) and isinstance(pmods[1], nn.ReLU)
+                    and all(c.kernel_size == (3, 3) and c.padding == (1, 1) and c.stride == (1, 1) and c.bias is not None
+                            for c in (up_convs[0], pmods[0]))
+                    and up_convs[0].in_channels == pmods[0].in_channels and up_convs[0].out_channels % 4 == 0
+                    and pmods[0].out_channels % 4 == 0)
+
         def head(lvl, f):
             off = offs[lvl]
             u = f
-            for k, pk in enumerate(up_pk):
-                nu = self.conv('head%d.up%d' % (lvl, k), u, pk, act=L.ACT_RELU)
-                if u is not f:
-                    self.free(u)
-                u = nu
+            if lvl == 0 and merge_p3:
+                cu, cp = up_convs[0], pmods[0]
+                u = self._new(f.B, f.H, f.W, cu.out_channels)
+                t0 = self._new(f.B, f.H, f.W, cp.out_channels)
+                pkm = Packed(torch.cat([cu.weight, cp.weight], 0), torch.cat([cu.bias, cp.bias], 0), None, 1, 1, None, dev)
+                hw = f.H * f.W
+                self.conv('head0.up0+proto.0', f, pkm, segs=[
+                    (0, cu.out_channels, L.ACT_RELU, cu.out_channels, hw * cu.out_channels, u.ptr),
+                    (cu.out_channels, cu.out_channels + cp.out_channels, L.ACT_RELU, cp.out_channels, hw * cp.out_channels,
+                     t0.ptr)])
+                self._merged_p3 = t0
+            else:
+                for k, pk in enumerate(up_pk):
+                    nu = self.conv('head%d.up%d' % (lvl, k), u, pk, act=L.ACT_RELU)
+                    if u is not f:
+                        self.free(u)
+                    u = nu
             segs = [
                 (0, n_b, L.ACT_NONE, n_b, P * 4, self.loc.data_ptr() + off * 4 * 4),
                 (n_b, n_b + n_m, coef_act, n_m, P * D, self.coef.data_ptr() + off * D * 4),
@@ -512,6 +537,10 @@ class Plan:
         conv_idx = [i for i, m in enumerate(mods) if isinstance(m, nn.Conv2d)]
         self.proto_patch = None
         for i, m in enumerate(mods):
+            if i == 0 and self._merged_p3 is not None:      # proto.0 was computed together with head0.up0
+                self.free(t)
+                t = self._merged_p3
+                continue
             if isinstance(m, nn.Conv2d):
                 last = i == conv_idx[-1]
                 has_relu = (i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU))
