@@ -1,4 +1,4 @@
-"""The bench.py output contract, checked on the committed result of the last GPU session (profiles/r01_bench_v9.json): the
+"""The bench.py output contract, checked on the committed result of the last GPU session (profiles/r02_bench_v2.json): the
 keys the driver and the judge read, their types, and the internal consistency of the roofline block."""
 import json
 import os
@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _load():
-    with open(os.path.join(ROOT, 'profiles', 'r01_bench_v9.json')) as f:
+    with open(os.path.join(ROOT, 'profiles', 'r02_bench_v2.json')) as f:
         return json.loads(f.read())
 
 
@@ -20,18 +20,24 @@ def test_top_level_fields():
                    ('config', dict), ('roofline', dict), ('cpu_baseline', dict)):
         assert isinstance(b[k], typ), (k, type(b[k]))
     assert b['vs_baseline'] is None                      # BASELINE.md publishes no number for this metric on MI355X
-    assert b['unit'] == 'images/s' and b['higher_is_better'] is True and b['scaling'] == 'weak' and b['dtype'] == 'f32'
+    assert b['unit'] == 'images/s' and b['higher_is_better'] is True and b['scaling'] == 'weak' and b['dtype'].startswith('f32')
     assert b['data'] == 'synthetic' and 'workload' in b['config'] and 'configs[1]' in b['config']['workload']
     assert 'model' not in b['config']
     # value = images of the whole job / wall time of the timed region
     imgs = b['config']['global_batch'] * b['steps']
     assert abs(b['value'] - imgs / (b['ms_per_step'] * b['steps'] / 1e3)) / b['value'] < 1e-3
+    # the exchange step really ran on RCCL and every image's record arrived
+    assert b['rccl_ranks'] == b['n_gpus'] and b['gathered_records'] == b['config']['global_batch']
+    assert b['config']['plan']['tune_misses'] == 0           # the timed plan is the shipped (deterministic) one
+    sec = b['secondary']
+    assert sec['batch_with_postprocess']['value'] > 0 and sec['reference_fps_definition_batch1']['value'] > 0
 
 
 def test_roofline_block():
     r = _load()['roofline']
     assert r['bound'] in ('hbm', 'mfma') and r['unit'] in ('GB/s', 'TFLOP/s')
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and 0 < r['frac'] <= 1.0
+    assert r['peak'] in (157.3, 416.7) and ('x3' in r['kernel']) == (r['peak'] == 416.7)   # per-kernel peak
     assert r['traffic'] is None or r['traffic'] > 0
     # achieved = FLOPs per launch / average launch duration
     assert abs(r['achieved'] - r['flops_per_launch'] / (r['avg_launch_ms'] * 1e-3) / 1e12) / r['achieved'] < 0.01
@@ -42,6 +48,8 @@ def test_roofline_block():
     assert abs(ac['gflop_per_step'] - 8 * 118.28) < 1.0  # 118.28 GFLOP per image
     assert abs(ac['tflops'] - ac['gflop_per_step'] / ac['ms_per_step']) < 0.5
     assert 0 < r['engine']['frac'] <= 1.0
+    for k, v in r['per_kernel'].items():
+        assert 0 < v['frac'] <= 1.0 and abs(v['frac'] - v['tflops'] / v['peak']) < 2e-3, k
 
 
 def test_cpu_baseline_block():
