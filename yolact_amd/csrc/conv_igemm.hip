@@ -29,6 +29,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <mutex>
+#include <type_traits>
 #include "../../include/yolact_amd.h"
 
 namespace {
@@ -226,7 +227,7 @@ constexpr int conv_occupancy() {
   // the DCN gather keeps per-tap geometry in registers; the bf16x3 path holds 12 registers of split pieces per 32-row
   // fragment on top of the raw fp32 fragment: budget registers (= blocks per CU) so that neither spills
   constexpr int cap = (LOADER == 2) ? 3
-                      : (PREC >= 1 ? (WM * WN * WK == 8 ? 1 : (TM * TN >= 4 ? 2 : (TM * TN == 2 ? 3 : 4))) : 5);
+                      : (PREC >= 1 ? (WM * WN * WK == 8 ? 1 : (TM * TN >= 4 ? 2 : (TM * TN == 2 ? (PREC == 1 ? 2 : 3) : 4))) : 5);
   return occ > cap ? cap : (occ < 1 ? 1 : occ);
 }
 
@@ -577,51 +578,55 @@ void conv_igemm_f32(const KParams p) {
   // slots 4s + 2h and 4s + 2h + 1 of its row (A and B agree on the K order, which is all a dot product needs).
   // Raw fp32 fragments of step s + 1 are requested right after step s has been split, so their LDS latency and the
   // splitting VALU work of the next step overlap this step's 6 * TM * TN bf16 MFMAs (VALU and matrix pipes are separate).
-  f32x4 rwa[TM][2], rwb[TN][2];       // (dead, hence register-free, when PREC == 0)
-  Split3 pbn[TN];                     // PREC == 2: the B pieces of the next step, read straight from the LDS planes
+  // raw fp32 fragments / filter-plane fragments, one set per step of the chunk (compile-time indexed: no register copies)
+  f32x4 rwa[2][TM][2], rwb[2][TN][2];     // (dead, hence register-free, when PREC == 0)
+  Split3 pbn[2][TN];                      // PREC == 2: the B pieces, read straight from the LDS planes
   int fo2[2][2];
 #pragma unroll
   for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
     for (int q = 0; q < 2; ++q) fo2[s2][q] = frag_row + 4 * ((4 * s2 + 2 * hh_ + q) ^ fsw);
   const int psw = ((lane & 31) >> 2) & 3;   // plane image: 64-byte rows, 16-byte slot s of row n lives at slot s ^ ((n >> 2) & 3)
-  auto load_raw = [&](int buf, int s2) {
+  auto load_raw = [&](int buf, auto s2c) {
+    constexpr int s2 = decltype(s2c)::value;
     const float *As = lds + buf * STAGE + wk * SUB + (wm * TM * 32) * BK;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      rwa[i][0] = *reinterpret_cast<const f32x4 *>(As + i * 32 * BK + fo2[s2][0]);
-      rwa[i][1] = *reinterpret_cast<const f32x4 *>(As + i * 32 * BK + fo2[s2][1]);
+      rwa[s2][i][0] = *reinterpret_cast<const f32x4 *>(As + i * 32 * BK + fo2[s2][0]);
+      rwa[s2][i][1] = *reinterpret_cast<const f32x4 *>(As + i * 32 * BK + fo2[s2][1]);
     }
     if constexpr (PREC == 2) {
       const float *Bp = lds + buf * STAGE + wk * SUB + BM * BK + ((wn * TN * 32 + (lane & 31)) * 16 + 4 * ((2 * s2 + hh_) ^ psw));
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        pbn[j].h = *reinterpret_cast<const bf16x8 *>(Bp + j * 32 * 16);
-        pbn[j].m = *reinterpret_cast<const bf16x8 *>(Bp + j * 32 * 16 + BN * 16);
-        pbn[j].l = *reinterpret_cast<const bf16x8 *>(Bp + j * 32 * 16 + 2 * BN * 16);
+        pbn[s2][j].h = *reinterpret_cast<const bf16x8 *>(Bp + j * 32 * 16);
+        pbn[s2][j].m = *reinterpret_cast<const bf16x8 *>(Bp + j * 32 * 16 + BN * 16);
+        pbn[s2][j].l = *reinterpret_cast<const bf16x8 *>(Bp + j * 32 * 16 + 2 * BN * 16);
       }
     } else {
       const float *Bs = lds + buf * STAGE + wk * SUB + BM * BK + (wn * TN * 32) * BK;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        rwb[j][0] = *reinterpret_cast<const f32x4 *>(Bs + j * 32 * BK + fo2[s2][0]);
-        rwb[j][1] = *reinterpret_cast<const f32x4 *>(Bs + j * 32 * BK + fo2[s2][1]);
+        rwb[s2][j][0] = *reinterpret_cast<const f32x4 *>(Bs + j * 32 * BK + fo2[s2][0]);
+        rwb[s2][j][1] = *reinterpret_cast<const f32x4 *>(Bs + j * 32 * BK + fo2[s2][1]);
       }
     }
   };
-  auto compute_x3 = [&](int buf, bool stage_next, int nst, int nbuf) {
+  // STAGE_NEXT is a compile-time flag: the staging pieces sit between the MFMAs unconditionally, and the (rare) steps that
+  // stage nothing run a second copy of the loop body without them — instead of one scalar branch per piece per chunk
+  auto compute_x3 = [&](int buf, auto stage_c, int nst, int nbuf) {
+    constexpr bool STAGE_NEXT = decltype(stage_c)::value;
     constexpr int NPOS = 12 * TM * TN;         // hook positions: behind every MFMA
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
-      Split3 xa[TM], xb[TN];
+      Split3 xa[TM], xbs[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) xa[i] = split8(rwa[i][0], rwa[i][1]);
+      for (int i = 0; i < TM; ++i) xa[i] = split8(rwa[s2][i][0], rwa[s2][i][1]);
+      if constexpr (PREC != 2) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        if constexpr (PREC == 2) xb[j] = pbn[j];
-        else xb[j] = split8(rwb[j][0], rwb[j][1]);
+        for (int j = 0; j < TN; ++j) xbs[j] = split8(rwb[s2][j][0], rwb[s2][j][1]);
       }
-      if (s2 == 0) load_raw(buf, 1);
+      if (s2 == 0) load_raw(buf, std::integral_constant<int, 1>{});
       // product-major order: consecutive MFMAs hit different accumulators (no back-to-back dependent issue); per
       // accumulator the small cross terms still come first and the dominant h*h product last
 #pragma unroll
@@ -630,16 +635,19 @@ void conv_igemm_f32(const KParams p) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
+            const Split3 &xb = (PREC == 2) ? pbn[s2][j] : xbs[j];
             const bf16x8 fa_ = pr == 0 ? xa[i].h : pr == 1 ? xa[i].l : pr == 2 ? xa[i].m : pr == 3 ? xa[i].h : pr == 4 ? xa[i].m : xa[i].h;
-            const bf16x8 fb_ = pr == 0 ? xb[j].l : pr == 1 ? xb[j].h : pr == 2 ? xb[j].m : pr == 3 ? xb[j].m : pr == 4 ? xb[j].h : xb[j].h;
+            const bf16x8 fb_ = pr == 0 ? xb.l : pr == 1 ? xb.h : pr == 2 ? xb.m : pr == 3 ? xb.m : pr == 4 ? xb.h : xb.h;
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_, fb_, acc[i][j], 0, 0, 0);
-            const int pos = ((s2 * 6 + pr) * TM + i) * TN + j;
+            if constexpr (STAGE_NEXT) {
+              const int pos = ((s2 * 6 + pr) * TM + i) * TN + j;
 #pragma unroll
-            for (int q = 0; q < NP; ++q) {
-              if ((NPOS * q) / NP == pos) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (stage_next) issue_piece(nst, nbuf, q);
-                __builtin_amdgcn_sched_barrier(0);
+              for (int q = 0; q < NP; ++q) {
+                if ((NPOS * q) / NP == pos) {
+                  __builtin_amdgcn_sched_barrier(0);
+                  issue_piece(nst, nbuf, q);
+                  __builtin_amdgcn_sched_barrier(0);
+                }
               }
             }
           }
@@ -648,15 +656,19 @@ void conv_igemm_f32(const KParams p) {
   // precision-independent entry points of the main loop
   auto prefetch_frags = [&](int buf) {
     if constexpr (PREC >= 1) {
-      load_raw(buf, 0);
+      load_raw(buf, std::integral_constant<int, 0>{});
     } else {
       load_frag(buf, 0, 0);
       load_frag(buf, 1, 1);
     }
   };
   auto compute_chunk = [&](int buf, bool stage_next, int nst, int nbuf) {
-    if constexpr (PREC >= 1) compute_x3(buf, stage_next, nst, nbuf);
-    else compute(buf, stage_next, nst, nbuf);
+    if constexpr (PREC >= 1) {
+      if (stage_next) compute_x3(buf, std::true_type{}, nst, nbuf);
+      else compute_x3(buf, std::false_type{}, nst, nbuf);
+    } else {
+      compute(buf, stage_next, nst, nbuf);
+    }
   };
   // a wave without a chunk of its own in a ragged K-split step still stages its share
   auto stage_only = [&](int nst, int nbuf) {
@@ -671,6 +683,81 @@ void conv_igemm_f32(const KParams p) {
 #define YMI_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
   const int nsteps = (p.nk + WK - 1) / WK;
   if (p.trace) tr_loop = __builtin_readcyclecounter();
+  // bf16x3 tiles without an intra-block K split: the loop is peeled into "every step stages the next one" + the final
+  // NS-1 steps that stage nothing, so the body has no runtime branch around the staging pieces and the accumulators flow
+  // through straight-line code (a join of two body variants inside the loop costs 16 v_mov per accumulator per chunk)
+  constexpr bool PEELED = PREC >= 1 && WK == 1 && LOADER != 2;
+#ifdef YMI_DIAGNOSTICS
+  const bool no_ablation = p.abl == 0;     // the ablation switches live in the generic loop below
+#else
+  constexpr bool no_ablation = true;       // product build: the generic loop is not even compiled into the peeled kernels
+#endif
+  if (PEELED && no_ablation) {
+    if (NS == 2) {
+      issue_tile(0, 0);
+      __syncthreads();   // drains the DMA (vmcnt(0)) then barrier
+      // two steps per trip with compile-time buffer indices: the compiler copies every accumulator once per loop trip
+      // (16 v_mov per 32x32 tile; it does not coalesce the loop-carried MFMA accumulators), so a longer trip halves that
+      // (only where the longer trip fits the register budget: the 1x2 wave tiles; 1x1 and 2x2 tiles spill with it)
+      constexpr bool UNROLL2 = TM * TN == 2;
+      int st = 0;
+      for (; UNROLL2 && st + 2 < nsteps; st += 2) {
+        prefetch_frags(0);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_x3(0, std::true_type{}, st + 1, 1);
+        __syncthreads();
+        prefetch_frags(1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_x3(1, std::true_type{}, st + 2, 0);
+        __syncthreads();
+      }
+      for (; st + 1 < nsteps; ++st) {              // remaining staged steps (all of them without UNROLL2)
+        const int cur = st & 1;
+        prefetch_frags(cur);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_x3(cur, std::true_type{}, st + 1, cur ^ 1);
+        __syncthreads();
+      }
+      prefetch_frags(st & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      compute_x3(st & 1, std::false_type{}, 0, 0);
+      __syncthreads();
+    } else {
+#pragma unroll
+      for (int s0 = 0; s0 < NS - 1; ++s0)
+        if (s0 < nsteps) issue_tile(s0, s0);
+      {
+        const int fl = (nsteps < NS - 1 ? nsteps : NS - 1) - 1;
+        if (NS >= 4 && fl >= 2) YMI_WAIT_VM(2 * DMA_PER_STEP);
+        else if (fl >= 1) YMI_WAIT_VM(DMA_PER_STEP);
+        else YMI_WAIT_VM(0);
+      }
+      YMI_BARRIER();
+      int cur = 0, nxt = NS - 1, st = 0;
+      for (; st + NS - 1 < nsteps; ++st) {          // steady state: NS - 2 later steps stay in flight behind step st + 1
+        prefetch_frags(cur);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_x3(cur, std::true_type{}, st + NS - 1, nxt);
+        if (NS >= 4) YMI_WAIT_VM(2 * DMA_PER_STEP); else YMI_WAIT_VM(DMA_PER_STEP);
+        YMI_BARRIER();
+        cur = (cur + 1 == NS) ? 0 : cur + 1;
+        nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+      }
+      for (; st < nsteps; ++st) {                   // drain: nothing left to stage
+        prefetch_frags(cur);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_x3(cur, std::false_type{}, 0, 0);
+        if (st + 1 < nsteps) {
+          const int rem = nsteps - 2 - st;
+          if (NS >= 4 && rem >= 2) YMI_WAIT_VM(2 * DMA_PER_STEP);
+          else if (rem >= 1) YMI_WAIT_VM(DMA_PER_STEP);
+          else YMI_WAIT_VM(0);
+        }
+        YMI_BARRIER();
+        cur = (cur + 1 == NS) ? 0 : cur + 1;
+      }
+    }
+  } else
   if (NS == 2) {
     issue_tile(0, 0);
     store_a_regs(0);
