@@ -297,6 +297,12 @@ def main():
                          '%d-GPU number measured on fewer devices' % (args.gpus, n_dev, args.gpus))
     if not launched and args.gpus > 1:
         relaunch_under_torchrun(args)
+    # stdout carries exactly ONE line — the result JSON.  RCCL prints a version banner through C stdio at start-up /
+    # tear-down, and buffered library output can land after Python's own line; so file descriptor 1 is pointed at stderr
+    # for the whole run and the JSON is written to the saved original descriptor at the very end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -403,11 +409,13 @@ def main():
                 result['secondary'] = secondary_lines(net, x, size)
         if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == CONFIG:
             result['cpu_baseline'] = cpu_baseline(sd, size, args.batch)
-        if rank == 0:
-            print(json.dumps(result))
     if have_pg:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    if rank == 0 and result is not None:
+        os.write(real_stdout, (json.dumps(result) + '\n').encode())
+    os.close(real_stdout)
 
 
 if __name__ == '__main__':

@@ -70,6 +70,8 @@ typedef struct {
                          * 2 = last 8; plane0 + plane1 + plane2 == w exactly).  With it the kernel splits only the activations
                          * on the fly (a third of the VALU work); NULL: both operands are split on the fly. */
   float *split_ws;      /* split_k > 1: workspace of split_k * B*Ho*Wo * Cout floats, 16-byte aligned */
+  int32_t cout_alg;     /* real output channels for FLOP accounting when Cout carries zero-filter padding columns; 0 = Cout */
+  int32_t _pad2;
 } ymi_conv_desc;
 
 /* block tile BMxBN; _Kn = the block's 4 waves also split K n ways (partial sums reduced in LDS in a fixed order:
@@ -124,6 +126,8 @@ typedef struct {
   int32_t _pad0;
   ymi_conv_seg seg[3];
   const void *u_x3;     /* optional, for tile | YMI_TILE_X3: u pre-split into bf16 planes [G][3][CoutPad][C] (see ymi_conv_desc.w_x3) */
+  int32_t cout_alg;     /* real output channels for FLOP accounting (see ymi_conv_desc.cout_alg); 0 = Cout */
+  int32_t _pad2;
 } ymi_wino_desc;
 int ymi_conv3x3_winograd_f32(const ymi_wino_desc *d, void *stream);
 
@@ -162,6 +166,10 @@ typedef struct {
   float conf_thresh;    /* 0.05 */
   float nms_thresh;     /* 0.5 */
   int32_t cross_class;  /* detection.py:111-135 variant */
+  int32_t conf_ld;      /* floats between consecutive priors' class rows in `conf`; 0 = C (dense).  The engine pads the rows
+                         * to a multiple of 4 (81 -> 84) so that the head GEMM / Winograd output transform can write them
+                         * with 16-byte stores */
+  int32_t _pad1;
   /* workspaces (caller-allocated) */
   float *scores_t;      /* [B,C-1,P] class-major foreground scores */
   int32_t *keep;        /* [B,P] 1 if max fg score > conf_thresh */

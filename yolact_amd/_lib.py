@@ -45,7 +45,8 @@ class ConvDesc(C.Structure):
                 ('Kpad', C.c_int32), ('res_mode', C.c_int32), ('res_ld', C.c_int32),
                 ('res_H', C.c_int32), ('res_W', C.c_int32), ('res_after_act', C.c_int32),
                 ('nseg', C.c_int32), ('tile', C.c_int32), ('cin_alg', C.c_int32), ('split_k', C.c_int32),
-                ('seg', ConvSeg * 3), ('w_x3', C.c_void_p), ('split_ws', C.c_void_p)]
+                ('seg', ConvSeg * 3), ('w_x3', C.c_void_p), ('split_ws', C.c_void_p), ('cout_alg', C.c_int32),
+                ('_pad2', C.c_int32)]
 
 
 class WinoDesc(C.Structure):
@@ -53,7 +54,7 @@ class WinoDesc(C.Structure):
                 ('V', C.c_void_p), ('M', C.c_void_p),
                 ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('C', C.c_int32), ('Cout', C.c_int32),
                 ('act', C.c_int32), ('tile', C.c_int32), ('nseg', C.c_int32), ('m', C.c_int32), ('_pad0', C.c_int32),
-                ('seg', ConvSeg * 3), ('u_x3', C.c_void_p)]
+                ('seg', ConvSeg * 3), ('u_x3', C.c_void_p), ('cout_alg', C.c_int32), ('_pad2', C.c_int32)]
 
 
 class DcnDesc(C.Structure):
@@ -65,6 +66,7 @@ class DetectDesc(C.Structure):
                 ('B', C.c_int32), ('P', C.c_int32), ('C', C.c_int32), ('D', C.c_int32),
                 ('conf_is_logits', C.c_int32), ('top_k', C.c_int32), ('max_det', C.c_int32),
                 ('conf_thresh', C.c_float), ('nms_thresh', C.c_float), ('cross_class', C.c_int32),
+                ('conf_ld', C.c_int32), ('_pad1', C.c_int32),
                 ('scores_t', C.c_void_p), ('keep', C.c_void_p), ('num_keep', C.c_void_p),
                 ('maxsc', C.c_void_p), ('argmax', C.c_void_p),
                 ('cand_score', C.c_void_p), ('cand_prior', C.c_void_p),

@@ -1244,7 +1244,8 @@ int ymi_internal_grouped_gemm(const ymi_conv_desc *d, int groups, long x_gs, lon
 extern "C" {
 
 double ymi_conv_flops(const ymi_conv_desc *d) {
-  return 2.0 * d->B * d->Ho * d->Wo * (double)d->Cout * d->kh * d->kw * (double)(d->cin_alg > 0 ? d->cin_alg : d->Cin);
+  return 2.0 * d->B * d->Ho * d->Wo * (double)(d->cout_alg > 0 ? d->cout_alg : d->Cout) * d->kh * d->kw *
+         (double)(d->cin_alg > 0 ? d->cin_alg : d->Cin);
 }
 
 int ymi_conv_pick_tile(const ymi_conv_desc *d) { return d ? pick_tile(d) : YMI_ENULL; }

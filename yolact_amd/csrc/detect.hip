@@ -43,7 +43,7 @@ __device__ __forceinline__ f32x4 decode_box(const float *loc, const float *pr) {
 
 // ------------------------------------------------------------------------------------------------
 // K1: softmax + keep.  Block = 64 priors x C classes staged in LDS (row stride C, C odd => conflict free).
-__global__ __launch_bounds__(256) void softmax_keep_k(const float *__restrict__ conf, int P, int C, int is_logits,
+__global__ __launch_bounds__(256) void softmax_keep_k(const float *__restrict__ conf, int P, int C, int ld, int is_logits,
                                                       float thresh, float *__restrict__ scores_t,
                                                       int *__restrict__ keep, int *__restrict__ num_keep,
                                                       float *__restrict__ maxsc, int *__restrict__ argmax) {
@@ -53,8 +53,12 @@ __global__ __launch_bounds__(256) void softmax_keep_k(const float *__restrict__ 
   const int np = min(64, P - p0);
   const int t = threadIdx.x;
   if (t == 0) blk_cnt = 0;
-  const float *src = conf + ((size_t)b * P + p0) * C;
-  for (int i = t; i < np * C; i += 256) s[i] = src[i];
+  const float *src = conf + ((size_t)b * P + p0) * ld;
+  if (ld == C) {
+    for (int i = t; i < np * C; i += 256) s[i] = src[i];
+  } else {                                       // padded class rows (ld > C): drop the padding while staging
+    for (int i = t; i < np * C; i += 256) { const int jj = i / C, c = i - jj * C; s[i] = src[jj * ld + c]; }
+  }
   __syncthreads();
 
   const int j = t >> 2, sub = t & 3;  // 4 lanes per prior
@@ -395,7 +399,7 @@ extern "C" int ymi_detect_f32(const ymi_detect_desc *d, void *stream) {
       !d->cand_prior || !d->out_count || !d->out_box || !d->out_score || !d->out_class || !d->out_coef ||
       !d->out_prior || !d->maxsc || !d->argmax)
     return YMI_ENULL;
-  if (d->B <= 0 || d->P <= 0 || d->C < 2 || d->D <= 0) return YMI_EARG;
+  if (d->B <= 0 || d->P <= 0 || d->C < 2 || d->D <= 0 || (d->conf_ld != 0 && d->conf_ld < d->C)) return YMI_EARG;
   if (d->top_k <= 0 || d->top_k > SORT_N || d->max_det <= 0 || d->max_det > SORT_N) return YMI_EARG;
   if (d->B > 65535) return YMI_EARG;
   if ((size_t)64 * d->C * sizeof(float) > 60000) return YMI_ESHAPE;
@@ -404,7 +408,7 @@ extern "C" int ymi_detect_f32(const ymi_detect_desc *d, void *stream) {
   if (e != hipSuccess) return (int)e;
   const int nfg = d->C - 1;
   hipLaunchKernelGGL(softmax_keep_k, dim3((d->P + 63) / 64, d->B), dim3(256), 64 * d->C * sizeof(float), s, d->conf,
-                     d->P, d->C, d->conf_is_logits, d->conf_thresh, d->scores_t, d->keep, d->num_keep, d->maxsc,
+                     d->P, d->C, d->conf_ld > 0 ? d->conf_ld : d->C, d->conf_is_logits, d->conf_thresh, d->scores_t, d->keep, d->num_keep, d->maxsc,
                      d->argmax);
   int rc = ymi_launch_status();
   if (rc) return rc;

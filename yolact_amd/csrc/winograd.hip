@@ -143,15 +143,33 @@ __device__ __forceinline__ int seg_vec4(const SegTab &st, int n, int Cout) {
   return -1;
 }
 
-// o = act(o * scale + bias) for 4 consecutive channels of segment k, stored as one float4
-__device__ __forceinline__ void seg_store4(const SegTab &st, int k, f32x4 v, const float *__restrict__ scale,
-                                           const float *__restrict__ bias, int n, long b, long pix) {
+// per-thread constants of the 16-byte store path: resolved ONCE per (tile, channel group), not per pixel
+struct SegVec {
+  float *ptr; long bs; int rs, act;
+  f32x4 sc, bi;
+};
+__device__ __forceinline__ SegVec seg_vec_setup(const SegTab &st, int k, const float *__restrict__ scale,
+                                                const float *__restrict__ bias, int n) {
   ymi_conv_seg sg = st.seg[0];
   if (k == 1) sg = st.seg[1];
   if (k == 2) sg = st.seg[2];
+  SegVec v;
+  v.ptr = sg.ptr + (n - sg.n0); v.bs = sg.batch_stride; v.rs = sg.row_stride; v.act = sg.act;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) v[e] = wino_act(v[e] * (scale ? scale[n + e] : 1.f) + (bias ? bias[n + e] : 0.f), sg.act);
-  *reinterpret_cast<f32x4 *>(sg.ptr + b * sg.batch_stride + pix * sg.row_stride + (n - sg.n0)) = v;
+  for (int e = 0; e < 4; ++e) { v.sc[e] = scale ? scale[n + e] : 1.f; v.bi[e] = bias ? bias[n + e] : 0.f; }
+  return v;
+}
+__device__ __forceinline__ void seg_vec_store(const SegVec &sv, f32x4 v, long b, long pix) {
+  v = v * sv.sc + sv.bi;
+  if (sv.act <= YMI_ACT_LEAKY01) {      // none / ReLU / LeakyReLU: max(x, slope x)
+    const float slope = sv.act == YMI_ACT_RELU ? 0.f : (sv.act == YMI_ACT_LEAKY01 ? 0.1f : 1.f);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], slope * v[e]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = wino_act(v[e], sv.act);
+  }
+  *reinterpret_cast<f32x4 *>(sv.ptr + b * sv.bs + pix * sv.rs) = v;
 }
 
 __global__ __launch_bounds__(256) void wino_out_seg_k(const float *__restrict__ Mm, const SegTab st,
@@ -183,12 +201,13 @@ __global__ __launch_bounds__(256) void wino_out_seg_k(const float *__restrict__ 
     }
     const int kv = seg_vec4(st, n4 * 4, Cout);
     if (kv >= 0) {
+      const SegVec sv = seg_vec_setup(st, kv, scale, bias, n4 * 4);
 #pragma unroll
       for (int iy = 0; iy < 2; ++iy)
 #pragma unroll
         for (int ix = 0; ix < 2; ++ix) {
           const int oy = 2 * ty + iy, ox = 2 * tx + ix;
-          if (oy < Ho && ox < Wo) seg_store4(st, kv, o[iy][ix], scale, bias, n4 * 4, b, (long)oy * Wo + ox);
+          if (oy < Ho && ox < Wo) seg_vec_store(sv, o[iy][ix], b, (long)oy * Wo + ox);
         }
       continue;
     }
@@ -349,12 +368,13 @@ __global__ __launch_bounds__(256) void wino43_out_seg_k(const float *__restrict_
     wino43_out_tile(Mm + t * (N4 * 4L) + n4 * 4, T * (N4 * 4L), o);
     const int kv = seg_vec4(st, n4 * 4, Cout);
     if (kv >= 0) {
+      const SegVec sv = seg_vec_setup(st, kv, scale, bias, n4 * 4);
 #pragma unroll
       for (int iy = 0; iy < 4; ++iy)
 #pragma unroll
         for (int ix = 0; ix < 4; ++ix) {
           const int oy = 4 * ty + iy, ox = 4 * tx + ix;
-          if (oy < Ho && ox < Wo) seg_store4(st, kv, o[iy][ix], scale, bias, n4 * 4, b, (long)oy * Wo + ox);
+          if (oy < Ho && ox < Wo) seg_vec_store(sv, o[iy][ix], b, (long)oy * Wo + ox);
         }
       continue;
     }
@@ -411,7 +431,7 @@ extern "C" int ymi_conv3x3_winograd_f32(const ymi_wino_desc *d, void *stream) {
   // profiling: record kind 3 (F(2x2)) / 4 (F(4x4)) = the whole layer (3 launches) with the layer's ALGORITHMIC FLOPs (2*9*C*Cout per output
   // pixel, like the direct kernel); record kind 5 / 6 (inside the GEMM launch) = the 16- / 36-group GEMM alone with the FLOPs
   // it executes (2*ng*T*C*Cout = algorithmic / 2.25 resp. / 4 for sizes that are multiples of the tile)
-  const double alg = 2.0 * d->B * d->H * d->W * (double)d->Cout * 9.0 * d->C;
+  const double alg = 2.0 * d->B * d->H * d->W * (double)(d->cout_alg > 0 ? d->cout_alg : d->Cout) * 9.0 * d->C;
   const double exe = 2.0 * ng * (double)T * d->C * Ng;
   const int outer = ymi_internal_prof_begin(alg, d->tile ? d->tile : YMI_TILE_64x64, mt == 4 ? 4 : 3, s);
   if (mt == 4)

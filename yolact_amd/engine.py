@@ -105,6 +105,7 @@ class Packed:
         self.weight_oihw = weight if (kh == 3 and kw == 3) else None     # Winograd transform source
         self.Cin, self.Cout, self.kh, self.kw, self.stride, self.pad = cin_p, Cout, kh, kw, stride, pad
         self.cin_alg = Cin
+        self.cout_alg = Cout           # real output channels when Cout carries zero-filter padding (FLOP accounting)
         scale = shift = None
         if bn is not None:
             # torch's eval BatchNorm: alpha = gamma * rsqrt(var + eps); y = x*alpha + (beta - mean*alpha), fp32
@@ -299,6 +300,7 @@ class Plan:
                 assert (res.B, res.H, res.W, res.C) == (x.B, Ho, Wo, pk.Cout), name
         d.tile = L.TILE_AUTO
         d.cin_alg = pk.cin_alg
+        d.cout_alg = pk.cout_alg
         if self.split and dcn_offmask is None:
             d.w_x3 = pk.w3().data_ptr()
         y = None
@@ -360,6 +362,7 @@ class Plan:
         d.scale = pk.scale.data_ptr() if pk.scale is not None else None
         d.bias = pk.bias.data_ptr() if pk.bias is not None else None
         d.B, d.H, d.W, d.C, d.Cout, d.act, d.tile, d.m = x.B, x.H, x.W, pk.Cin, pk.Cout, act, L.TILE_AUTO, m
+        d.cout_alg = pk.cout_alg
         return d
 
     def _bind_wino_workspaces(self):
@@ -438,19 +441,29 @@ class Plan:
         cells = [h * w for h, w in shapes]
         P = sum(cells) * A
         self.P, self.A, self.D, self.Ccls = P, A, D, Ccls
+        # class rows are padded to a multiple of 4 floats (81 -> 84): every head output row is then 16-byte aligned and the
+        # head GEMM / Winograd output transform store float4s (the 243-float rows of the dense layout forced scalar
+        # stores on 69 % of the head's output channels); Detect reads the rows with stride `conf_ld`
+        Cp = _ceil(Ccls, 4) if os.environ.get('YOLACT_AMD_PAD_CONF', '1') == '1' else Ccls
+        self.conf_ld = Cp
         self.loc = torch.empty(B, P, 4, device=dev)
-        self.conf = torch.empty(B, P, Ccls, device=dev)
+        self.conf = torch.zeros(B, P, Cp, device=dev)
         self.coef = torch.empty(B, P, D, device=dev)
         up_pk = [pack_module(m, device=dev) for m in pm.upfeature if isinstance(m, nn.Conv2d)] \
             if hasattr(pm, 'upfeature') else []
         # row order bbox | coef | conf keeps the bbox and coef segments 16-byte aligned (vector stores)
-        wcat = torch.cat([pm.bbox_layer.weight, pm.mask_layer.weight, pm.conf_layer.weight], 0)
-        bcat = torch.cat([pm.bbox_layer.bias, pm.mask_layer.bias, pm.conf_layer.bias], 0)
+        cw, cb = pm.conf_layer.weight, pm.conf_layer.bias
+        if Cp != Ccls:      # zero filters for the padding columns of every anchor's class row
+            cw = torch.nn.functional.pad(cw.view(A, Ccls, *cw.shape[1:]), (0, 0, 0, 0, 0, 0, 0, Cp - Ccls)).reshape(A * Cp, *cw.shape[1:])
+            cb = torch.nn.functional.pad(cb.view(A, Ccls), (0, Cp - Ccls)).reshape(A * Cp)
+        wcat = torch.cat([pm.bbox_layer.weight, pm.mask_layer.weight, cw], 0)
+        bcat = torch.cat([pm.bbox_layer.bias, pm.mask_layer.bias, cb], 0)
         hp = pm.bbox_layer
         head_pk = Packed(wcat, bcat, None, hp.stride[0], hp.padding[0], None, dev)
+        head_pk.cout_alg = A * (4 + D + Ccls)
         coef_act = {'tanh': L.ACT_TANH, 'sigmoid': L.ACT_SIGMOID, 'relu': L.ACT_RELU, 'none': L.ACT_NONE}[
             act_name(cfg.mask_proto_coeff_activation)]
-        n_b, n_c, n_m = A * 4, A * Ccls, A * D
+        n_b, n_c, n_m = A * 4, A * Cp, A * D
         offs = [sum(cells[:l]) * A for l in range(nlev)]
         bbc = cfg.backbone
         pri = []
@@ -493,7 +506,7 @@ class Plan:
             segs = [
                 (0, n_b, L.ACT_NONE, n_b, P * 4, self.loc.data_ptr() + off * 4 * 4),
                 (n_b, n_b + n_m, coef_act, n_m, P * D, self.coef.data_ptr() + off * D * 4),
-                (n_b + n_m, n_b + n_m + n_c, L.ACT_NONE, n_c, P * Ccls, self.conf.data_ptr() + off * Ccls * 4),
+                (n_b + n_m, n_b + n_m + n_c, L.ACT_NONE, n_c, P * Cp, self.conf.data_ptr() + off * Cp * 4),
             ]
             self.conv('head%d.out' % lvl, u, head_pk, segs=segs)
             if u is not f:

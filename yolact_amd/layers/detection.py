@@ -59,7 +59,7 @@ class Detect(object):
                     self._ws[key] = ws
         return ws
 
-    def run_device(self, loc, conf, mask, priors, conf_is_logits, stream=None, slot=0):
+    def run_device(self, loc, conf, mask, priors, conf_is_logits, stream=None, slot=0, conf_ld=0):
         """Launch the Detect kernels; returns fixed-capacity device tensors (no host sync).  `stream`: raw
         hipStream_t (ctypes void*) to launch on — the execution plan passes its side stream — default: torch's
         current stream.  Output tensors are always allocated under the ambient stream."""
@@ -68,12 +68,15 @@ class Detect(object):
             L.require_cuda(t, name)
         cfg = active_cfg()
         B, P, Ccls = conf.shape
+        if conf_ld:                      # the engine's padded class rows [B, P, conf_ld]: num_classes of them are real
+            Ccls = self.num_classes
+            assert conf.shape[2] == conf_ld >= Ccls
         D = mask.shape[2]
         dev = conf.device
         max_det = int(cfg.max_num_detections)
         cap = self.top_k if self.use_cross_class_nms else max_det
         ws = self._workspace(B, P, Ccls, D, cap, dev, slot)
-        return self._launch(loc, conf, mask, priors, conf_is_logits, stream, ws, B, P, Ccls, D, dev, max_det, cap)
+        return self._launch(loc, conf, mask, priors, conf_is_logits, stream, ws, B, P, Ccls, D, dev, max_det, cap, conf_ld)
 
     def _require_fast_nms(self):
         if not self.use_fast_nms:
@@ -84,7 +87,7 @@ class Detect(object):
                 'Detect.use_fast_nms is False (the reference default): traditional Cython/CPU NMS is not part of the '
                 'MI355X hot path.  Set net.detect.use_fast_nms = True, as eval.py:871 does for its default --fast_nms.')
 
-    def _launch(self, loc, conf, mask, priors, conf_is_logits, stream, ws, B, P, Ccls, D, dev, max_det, cap):
+    def _launch(self, loc, conf, mask, priors, conf_is_logits, stream, ws, B, P, Ccls, D, dev, max_det, cap, conf_ld=0):
         out = dict(count=torch.empty(B, dtype=torch.int32, device=dev), box=torch.empty(B, cap, 4, device=dev),
                    score=torch.empty(B, cap, device=dev), cls=torch.empty(B, cap, dtype=torch.int64, device=dev),
                    coef=torch.empty(B, cap, D, device=dev), prior=torch.empty(B, cap, dtype=torch.int32, device=dev))
@@ -92,6 +95,7 @@ class Detect(object):
         loc, conf, mask, priors = (t.contiguous() for t in (loc.float(), conf.float(), mask.float(), priors.float()))
         d.conf, d.loc, d.coef, d.priors = conf.data_ptr(), loc.data_ptr(), mask.data_ptr(), priors.data_ptr()
         d.B, d.P, d.C, d.D = B, P, Ccls, D
+        d.conf_ld = int(conf_ld)
         d.conf_is_logits = 1 if conf_is_logits else 0
         d.top_k, d.max_det = int(self.top_k), max_det
         d.conf_thresh, d.nms_thresh = float(self.conf_thresh), float(self.nms_thresh)

@@ -183,7 +183,8 @@ class Yolact(nn.Module):
             # the op list carries the reference's timer sections (backbone / fpn / proto / pred_heads, yolact.py:570-607)
             with self._run_lock:
                 proto, dev_out = plan.run(x, detect=lambda s: self.detect.run_device(
-                    plan.loc, plan.conf, plan.coef, plan.priors, True, stream=s), timer=sys.modules.get('utils.timer'))
+                    plan.loc, plan.conf, plan.coef, plan.priors, True, stream=s, conf_ld=plan.conf_ld),
+                    timer=sys.modules.get('utils.timer'))
             return self.detect.finish(dev_out, proto, self)
 
     def maskiou_forward(self, masks_lo):
@@ -226,7 +227,7 @@ class Yolact(nn.Module):
             return self._forward_device_graph(plan, x, slot)
         with self._run_lock:    # a plan's arena / head buffers are shared state: one forward at a time per model
             proto, out = plan.run(x, detect=lambda s: self.detect.run_device(
-                plan.loc, plan.conf, plan.coef, plan.priors, True, stream=s, slot=slot))
+                plan.loc, plan.conf, plan.coef, plan.priors, True, stream=s, slot=slot, conf_ld=plan.conf_ld))
         out['proto'] = proto
         return out
 
@@ -241,7 +242,7 @@ class Yolact(nn.Module):
         if rec is None:
             def body(inp):
                 proto, out = plan.run(inp, detect=lambda s: self.detect.run_device(
-                    plan.loc, plan.conf, plan.coef, plan.priors, True, stream=s, slot=slot))
+                    plan.loc, plan.conf, plan.coef, plan.priors, True, stream=s, slot=slot, conf_ld=plan.conf_ld))
                 out['proto'] = proto
                 return out
             static_x = x.clone()
@@ -273,7 +274,8 @@ class Yolact(nn.Module):
             plan = self.plan_for(x)
             with self._run_lock:
                 proto, _ = plan.run(x)
-                out = {'loc': plan.loc.clone(), 'conf_logits': plan.conf.clone(), 'mask': plan.coef.clone(),
+                out = {'loc': plan.loc.clone(), 'conf_logits': plan.conf[..., :plan.Ccls].contiguous().clone(),
+                       'mask': plan.coef.clone(),
                        'priors': plan.priors, 'proto': proto}
                 plan.mark_done()      # the clones read the plan's persistent head buffers
             return out
