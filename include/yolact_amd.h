@@ -10,6 +10,7 @@
  */
 #ifndef YOLACT_AMD_H
 #define YOLACT_AMD_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -17,6 +18,10 @@ extern "C" {
 #endif
 
 #define YMI_ABI_VERSION 2
+
+/* negative return codes (ymi_strerror) */
+#define YMI_EFORMAT (-4)       /* corrupt or truncated input stream (ymi_jpeg_*) */
+#define YMI_EUNSUPPORTED (-5)  /* valid input outside the supported subset (ymi_jpeg_*) */
 
 /* activation codes (epilogue) */
 enum { YMI_ACT_NONE = 0, YMI_ACT_RELU = 1, YMI_ACT_LEAKY01 = 2, YMI_ACT_TANH = 3, YMI_ACT_SIGMOID = 4 };
@@ -235,6 +240,46 @@ int ymi_mask_rle_f32(const float *masks, int N, int h, int w, uint32_t *counts, 
  * 0x20 = continuation, + 48).  str [N,cap_chars] bytes, nchars [N] = true length (> cap_chars: truncated). */
 int ymi_rle_to_string(const uint32_t *counts, const int32_t *nruns, int N, int cap, uint8_t *str, int32_t *nchars,
                       int cap_chars, void *stream);
+
+/* -- COCODetection.pull_item's image read (data/coco.py:138-141: `img = cv2.imread(path)` -> uint8 BGR [h,w,3]) ----------
+ * cv2.imread on a JPEG = libjpeg-turbo with the library defaults (ISLOW IDCT, fancy upsampling) + EXIF orientation.
+ * Split: the serial half (markers + Huffman decoding, baseline and progressive) runs on the HOST and yields the quantised
+ * coefficient blocks; dequantisation, IDCT, chroma upsampling, YCbCr -> BGR and the orientation run on the GPU.
+ * Bit-exact against libjpeg-turbo (pinned through oracle/jpeg_oracle.py).  Errors: YMI_EFORMAT corrupt / truncated
+ * stream, YMI_EUNSUPPORTED a valid file outside this subset (arithmetic coding, lossless, 12-bit, CMYK / YCCK,
+ * fractional sampling ratios). */
+enum { YMI_JPEG_YCBCR = 0, YMI_JPEG_RGB = 1, YMI_JPEG_GRAY = 2 };
+typedef struct {
+  int32_t width, height;          /* as stored in the file (before the EXIF orientation is applied) */
+  int32_t ncomp;                  /* 1 or 3 */
+  int32_t progressive;
+  int32_t orientation;            /* EXIF tag 0x0112, 1..8 (1 when absent) */
+  int32_t color;                  /* YMI_JPEG_* : how the components map to BGR */
+  int32_t out_width, out_height;  /* of the decoded image = (height, width) swapped for orientations 5..8 */
+  int32_t hs[3], vs[3];           /* sampling factors as declared */
+  int32_t hf[3], vf[3];           /* upsampling factors max_h / h, max_v / v */
+  int32_t bw[3], bh[3];           /* block grid of each component, padded to whole MCUs */
+  int32_t dw[3], dh[3];           /* real (downsampled) size of each component in samples */
+  int64_t coef_count;             /* int16 coefficients in total = sum bw*bh*64 */
+  int64_t plane_bytes;            /* device workspace for ymi_jpeg_reconstruct_bgr_u8 (uint8 planes) */
+} ymi_jpeg_info;
+/* HOST.  Header only: sizes for the caller's allocations. */
+int ymi_jpeg_parse(const uint8_t *data, size_t n, ymi_jpeg_info *info);
+/* HOST.  Entropy-decode every scan into coefs (host memory, coef_capacity int16; layout [component][by][bx][64], natural
+ * (row-major) order inside a block, zero where no scan wrote) and latch the quantisation tables: qt [3][64] natural order. */
+int ymi_jpeg_decode_coefs(const uint8_t *data, size_t n, int16_t *coefs, int64_t coef_capacity, uint16_t *qt,
+                          ymi_jpeg_info *info);
+/* DEVICE.  coefs / qt: device copies of the host results; planes_ws: info->plane_bytes; out: [out_height,out_width,3] uint8 BGR. */
+int ymi_jpeg_reconstruct_bgr_u8(const ymi_jpeg_info *info, const int16_t *coefs, const uint16_t *qt, uint8_t *planes_ws,
+                                uint8_t *out, void *stream);
+
+/* -- COCODetection.pull_item's ground-truth masks (data/coco.py:144-148: `self.coco.annToMask(obj)`), HOST code -----------
+ * pycocotools maskApi.c restated (pycocotools is an unpinned pip dependency of the reference, environment.yml:30):
+ * rleFrPoly / rleFrString / rleDecode.  Every call ORs its region into mask [h,w] uint8 ROW-major (0/1), so a polygon
+ * list (union of polygons, rleMerge intersect = 0) is a loop of calls on one zeroed mask. */
+int ymi_coco_poly_fill_u8(const double *xy, int k, int h, int w, uint8_t *mask);          /* k vertices, x0 y0 x1 y1 ... */
+int ymi_coco_rle_fill_u8(const uint32_t *counts, long n, int h, int w, uint8_t *mask);    /* uncompressed counts */
+int ymi_coco_rle_string_fill_u8(const char *s, long len, int h, int w, uint8_t *mask);    /* compressed 'counts' string */
 
 /* -- DCNv2 forward (external/DCNv2/src/vision.cpp:5, dcn_v2.h:9-39, dcn_v2_cuda.cu:42-172) ---- */
 typedef struct {

@@ -15,10 +15,10 @@ jidctint.c / jdsample.c / jdcolor.c arithmetic) in plain Python / numpy:
   ycc_to_bgr           jdcolor.c build_ycc_rgb_table / ycc_rgb_convert
   imread_bgr           the whole thing, + EXIF orientation
 
-PINNED: tests/test_jpeg_oracle.py checks it bit for bit against libjpeg-turbo itself — Pillow's decoder (libjpeg-turbo
+PINNED: tests/test_jpeg.py checks it bit for bit against libjpeg-turbo itself — Pillow's decoder (libjpeg-turbo
 3.1.4, the same library and defaults OpenCV wraps; `PIL.features.version_feature('libjpeg_turbo')`) — on photographs
 found in this image and on synthetic files written at every chroma subsampling, odd sizes, restart intervals, progressive
-mode, grayscale; the committed fixtures (tests/golden/jpeg_*.npz, made by oracle/make_golden_jpeg.py) carry the same
+mode, grayscale; the committed fixtures (tests/golden/jpeg.npz, made by oracle/make_golden_jpeg.py) carry the same
 bytes + pixels to the GPU box.  cv2 itself is absent here, so "cv2.imread == libjpeg-turbo defaults + EXIF rotate + BGR" is
 taken from OpenCV's published grfmt_jpeg.cpp, not executed.
 """
@@ -219,6 +219,8 @@ def parse(data: bytes) -> Dict:
                 if data[q] == 0xFF and data[q + 1] != 0 and not (0xD0 <= data[q + 1] <= 0xD7):
                     break
                 q += 1
+            else:
+                q = len(data)          # truncated file: no marker after the entropy-coded data
             p = q
             continue
         p += ln
@@ -247,6 +249,8 @@ def decode_coefficients(data: bytes, info: Dict) -> List[np.ndarray]:
         pred = [0] * len(comps)
         eobrun = 0
         if len(sel) > 1:
+            if sum(comps[ci]['h'] * comps[ci]['v'] for ci, _, _ in sel) > 10:
+                raise JpegError('more than 10 blocks per MCU (libjpeg D_MAX_BLOCKS_IN_MCU)')
             units = [(mx, my) for my in range(mcuy) for mx in range(mcux)]
         else:
             c = comps[sel[0][0]]
@@ -351,7 +355,7 @@ _C = dict(F0_298=2446, F0_390=3196, F0_541=4433, F0_765=6270, F0_899=7373, F1_17
           F1_961=16069, F2_053=16819, F2_562=20995, F3_072=25172)
 
 
-def _idct_1d(i0, i1, i2, i3, i4, i5, i6, i7, shift_in: bool):
+def _idct_1d(i0, i1, i2, i3, i4, i5, i6, i7):
     """One jidctint.c pass over 8 int64 arrays; returns the 8 un-descaled sums (tmp10+tmp3, ...)."""
     c = _C
     z2, z3 = i2, i6
@@ -379,9 +383,9 @@ def _descale(x, n):
 def idct_islow(coef: np.ndarray, qt: np.ndarray) -> np.ndarray:
     """coef [...,64] quantised natural order, qt [64] -> uint8 samples [...,8,8] (jidctint.c jpeg_idct_islow)."""
     d = (coef.astype(np.int64) * qt.astype(np.int64)).reshape(coef.shape[:-1] + (8, 8))     # [.., row, col]
-    cols = _idct_1d(*[d[..., r, :] for r in range(8)], shift_in=True)                       # pass 1: down the columns
+    cols = _idct_1d(*[d[..., r, :] for r in range(8)])                       # pass 1: down the columns
     ws = np.stack([_descale(v, 13 - 2) for v in cols], axis=-2)                              # [.., row, col]
-    rows = _idct_1d(*[ws[..., :, c] for c in range(8)], shift_in=False)                      # pass 2: along the rows
+    rows = _idct_1d(*[ws[..., :, c] for c in range(8)])                      # pass 2: along the rows
     out = np.stack([_descale(v, 13 + 2 + 3) for v in rows], axis=-1)
     # IDCT_range_limit: sample_range_limit + CENTERJSAMPLE indexed by (x & RANGE_MASK), RANGE_MASK = 1023
     x = out & 1023

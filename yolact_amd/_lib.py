@@ -74,6 +74,16 @@ class DetectDesc(C.Structure):
                 ('out_class', C.c_void_p), ('out_coef', C.c_void_p), ('out_prior', C.c_void_p)]
 
 
+class JpegInfo(C.Structure):
+    _fields_ = [('width', C.c_int32), ('height', C.c_int32), ('ncomp', C.c_int32), ('progressive', C.c_int32),
+                ('orientation', C.c_int32), ('color', C.c_int32), ('out_width', C.c_int32), ('out_height', C.c_int32),
+                ('hs', C.c_int32 * 3), ('vs', C.c_int32 * 3), ('hf', C.c_int32 * 3), ('vf', C.c_int32 * 3),
+                ('bw', C.c_int32 * 3), ('bh', C.c_int32 * 3), ('dw', C.c_int32 * 3), ('dh', C.c_int32 * 3),
+                ('coef_count', C.c_int64), ('plane_bytes', C.c_int64)]
+
+
+EFORMAT, EUNSUPPORTED = -4, -5
+
 # every symbol include/yolact_amd.h declares: (name, restype, argtypes)
 _P, _I, _F = C.c_void_p, C.c_int, C.c_float
 SYMBOLS = [
@@ -101,6 +111,12 @@ SYMBOLS = [
     ('ymi_mask_rle_f32', C.c_int, [_P, _I, _I, _I, _P, _P, _I, _P]),
     ('ymi_rle_to_string', C.c_int, [_P, _P, _I, _I, _P, _P, _I, _P]),
     ('ymi_fast_base_transform_f32', C.c_int, [_P, _P, _I, _I, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _I, _I, _P]),
+    ('ymi_jpeg_parse', C.c_int, [_P, C.c_size_t, C.POINTER(JpegInfo)]),
+    ('ymi_jpeg_decode_coefs', C.c_int, [_P, C.c_size_t, _P, C.c_int64, _P, C.POINTER(JpegInfo)]),
+    ('ymi_jpeg_reconstruct_bgr_u8', C.c_int, [C.POINTER(JpegInfo), _P, _P, _P, _P, _P]),
+    ('ymi_coco_poly_fill_u8', C.c_int, [_P, _I, _I, _I, _P]),
+    ('ymi_coco_rle_fill_u8', C.c_int, [_P, C.c_long, _I, _I, _P]),
+    ('ymi_coco_rle_string_fill_u8', C.c_int, [C.c_char_p, C.c_long, _I, _I, _P]),
     ('ymi_debug_set_trace', C.c_int, [_P, C.c_long]),
     ('ymi_prof_enable', C.c_int, [_I]),
     ('ymi_prof_count', C.c_int, []),

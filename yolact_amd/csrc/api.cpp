@@ -12,6 +12,8 @@ const char *ymi_strerror(int code) {
     case -1: return "bad argument / unsupported configuration";
     case -2: return "shape or alignment constraint violated";
     case -3: return "null pointer";
+    case YMI_EFORMAT: return "corrupt or truncated input stream";
+    case YMI_EUNSUPPORTED: return "valid input outside the supported subset";
   }
   if (code > 0) return hipGetErrorString((hipError_t)code);
   return "unknown error";

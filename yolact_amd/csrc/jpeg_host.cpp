@@ -294,6 +294,11 @@ struct Decoder {
         sel[i]->qt_latched = true;
       }
     }
+    if (ns > 1) {      // libjpeg: D_MAX_BLOCKS_IN_MCU = 10 (JERR_BAD_MCU_SIZE)
+      int nb = 0;
+      for (int i = 0; i < ns; ++i) nb += sel[i]->h * sel[i]->v;
+      if (nb > 10) return YMI_EUNSUPPORTED;
+    }
     const int Ss = s[1 + 2 * ns], Se = s[2 + 2 * ns], Ah = s[3 + 2 * ns] >> 4, Al = s[3 + 2 * ns] & 15;
     if (f.progressive) {
       if (Ss > Se || Se > 63 || Al > 13 || (Ss == 0 && Se != 0) || (Ss > 0 && ns != 1)) return YMI_EFORMAT;

@@ -74,3 +74,41 @@ class FastBaseTransform(torch.nn.Module):
 
     def to_nhwc4(self, img):
         return self._run(img, True)
+
+
+class BaseTransform:
+    """`BaseTransform` — utils/augmentations.py:601-612 (the `transform` eval.py hands COCODetection, eval.py:1097): the
+    pipeline ConvertFromInts -> Resize(resize_gt=False) -> BackboneTransform(cfg.backbone.transform, mean, std, 'BGR').
+
+    The image half is the FastBaseTransform kernel (bilinear resize with half-pixel centres, normalisation, BGR -> RGB): `img`
+    is the device tensor data.jpeg.imread returned (uint8 / float BGR [h,w,3]; a numpy array is uploaded) and comes back as a
+    float32 [S,S,3] device view (HWC like the reference's array, so `.permute(2, 0, 1)` gives the network input).
+    cv2.resize and this kernel evaluate the same bilinear formula in fp32 but round the sample coordinate differently
+    (cv2: double -> float; here: fp32 throughout, as F.interpolate), so values agree to ~1e-5 of the normalised range, not
+    bit for bit.  The ground-truth half is the reference's host code: `Resize(resize_gt=False)` leaves masks / boxes at
+    their size and drops boxes narrower than cfg.discard_box_width / height (utils/augmentations.py:170-178)."""
+
+    def __init__(self, mean=MEANS, std=STD):
+        self._fbt = FastBaseTransform()
+        self._fbt._mean = (C.c_float * 3)(*mean)
+        self._fbt._std = (C.c_float * 3)(*std)
+
+    def __call__(self, img, masks=None, boxes=None, labels=None):
+        import numpy as np
+        cfg = active_cfg()
+        if not torch.is_tensor(img):
+            img = torch.from_numpy(np.ascontiguousarray(img))
+        if not img.is_cuda:
+            if not torch.cuda.is_available():
+                L.require_cuda(img, 'image')
+            img = img.cuda()
+        out = self._fbt(img.unsqueeze(0))[0].permute(1, 2, 0)      # [S,S,3] view of the NCHW result
+        if boxes is not None and labels is not None:
+            w = boxes[:, 2] - boxes[:, 0]
+            h = boxes[:, 3] - boxes[:, 1]
+            keep = (w > getattr(cfg, 'discard_box_width', 4 / 550)) * (h > getattr(cfg, 'discard_box_height', 4 / 550))
+            masks = masks[keep]
+            boxes = boxes[keep]
+            labels['labels'] = labels['labels'][keep]
+            labels['num_crowds'] = (labels['labels'] < 0).sum()
+        return out, masks, boxes, labels
