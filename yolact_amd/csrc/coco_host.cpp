@@ -18,6 +18,7 @@ namespace {
 // runs of a column-major flattening, starting with zeros, OR-ed into a row-major mask
 int fill_runs(const uint32_t *cnt, long n, int h, int w, uint8_t *mask) {
   const long total = (long)h * w;
+  if (total > (1L << 31) - 1) return YMI_EARG;
   long pos = 0;
   int v = 0;
   for (long i = 0; i < n; ++i) {
@@ -38,7 +39,9 @@ extern "C" {
 
 int ymi_coco_poly_fill_u8(const double *xy, int k, int h, int w, uint8_t *mask) {
   if (!xy || !mask) return YMI_ENULL;
-  if (k < 1 || h <= 0 || w <= 0) return YMI_EARG;
+  if (k < 1 || h <= 0 || w <= 0 || (long)h * w > (1L << 31) - 1) return YMI_EARG;
+  // maskApi.c scales by 5 into int: coordinates that cannot be image coordinates (or NaN) are an argument error here
+  for (int j = 0; j < 2 * k; ++j) if (!(std::fabs(xy[j]) < 1.0e5)) return YMI_EARG;
   const double scale = 5;
   std::vector<int> x(k + 1), y(k + 1);
   for (int j = 0; j < k; ++j) x[j] = (int)(scale * xy[j * 2 + 0] + .5);
@@ -126,7 +129,7 @@ int ymi_coco_rle_string_fill_u8(const char *s, long len, int h, int w, uint8_t *
       more = (int)(c & 0x20);
       ++p;
       ++k;
-      if (!more && (c & 0x10)) x |= -1L << (5 * k);
+      if (!more && (c & 0x10)) x |= (long)(~0UL << (5 * k));   // sign extension (maskApi.c: x |= -1 << 5*k)
       if (k > 12) return YMI_EFORMAT;
     }
     if (cnts.size() > 2) x += (long)cnts[cnts.size() - 2];

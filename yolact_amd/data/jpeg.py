@@ -18,6 +18,9 @@ import torch
 from .. import _lib as L
 
 
+MAX_COEFS = 1 << 29        # 512 M coefficients (a 16k x 16k 4:4:4 image); a corrupt header must not allocate 26 GB
+
+
 class JpegInfo:
     """Plain-Python view of ymi_jpeg_info."""
 
@@ -46,6 +49,8 @@ def parse(src) -> JpegInfo:
         raise ValueError('not a JPEG stream (no SOI marker)')
     raw = L.JpegInfo()
     L.check(L.lib().ymi_jpeg_parse(data, len(data), C.byref(raw)), 'ymi_jpeg_parse')
+    if raw.coef_count > MAX_COEFS:
+        raise ValueError('JPEG header declares %d x %d pixels: larger than this reader accepts' % (raw.width, raw.height))
     return JpegInfo(raw)
 
 
