@@ -91,104 +91,104 @@ def ann_to_mask(ann, h: int, w: int) -> np.ndarray:
 
 
 class COCOAnnotationTransform:
-    """data/coco.py:19-51: COCO annotation dicts -> [[xmin, ymin, xmax, ymax, label_idx], ...] in relative coordinates."""
+    """data/coco.py:19-51: COCO annotation dicts -> one row [xmin, ymin, xmax, ymax, label_idx] per annotation that has a
+    'bbox', corners relative to the image size; label_idx = label_map[category_id] - 1, crowds (category_id < 0) keep -1."""
 
     def __init__(self):
         self.label_map = get_label_map()
 
     def __call__(self, target, width, height):
-        scale = np.array([width, height, width, height])
-        res = []
-        for obj in target:
-            if 'bbox' in obj:
-                bbox = obj['bbox']
-                label_idx = obj['category_id']
-                if label_idx >= 0:
-                    label_idx = self.label_map[label_idx] - 1
-                final_box = list(np.array([bbox[0], bbox[1], bbox[0] + bbox[2], bbox[1] + bbox[3]]) / scale)
-                final_box.append(label_idx)
-                res += [final_box]
-            else:
-                print('No bbox found for object ', obj)
-        return res
+        rows = []
+        size = np.array([width, height, width, height])
+        for ann in target:
+            box = ann.get('bbox')
+            if box is None:
+                print('No bbox found for object ', ann)
+                continue
+            x, y, bw, bh = box
+            cat = ann['category_id']
+            label = self.label_map[cat] - 1 if cat >= 0 else cat
+            rows.append(list(np.array([x, y, x + bw, y + bh]) / size) + [label])
+        return rows
+
+
+def _split_crowds(anns):
+    """Crowd annotations (iscrowd truthy) go to the END of the list and get category_id -1 (data/coco.py:117-128: both in
+    training and in evaluation they are neutral regions, and eval.py slices them off by count)."""
+    crowd = [a for a in anns if a.get('iscrowd')]
+    solid = [a for a in anns if not a.get('iscrowd')]
+    for a in crowd:
+        a['category_id'] = -1
+    return solid + crowd, len(crowd)
 
 
 class COCODetection(torch.utils.data.Dataset):
-    """data/coco.py:54-212.  `transform` is called like the reference's (img, masks, boxes, labels-dict); with
+    """data/coco.py:54-212 with the reference's constructor arguments and return values.  `transform` is called the way
+    the reference calls it — (img, masks, boxes, {'num_crowds', 'labels'}) — and with
     yolact_amd.utils.augmentations.BaseTransform the image goes in and comes out as a device tensor."""
 
     def __init__(self, image_path, info_file, transform=None, target_transform=None, dataset_name='MS COCO', has_gt=True,
                  device=None):
         self.root = image_path
         self.coco = COCOIndex(info_file)
-        self.ids = list(self.coco.imgToAnns.keys())
-        if len(self.ids) == 0 or not has_gt:
-            self.ids = list(self.coco.imgs.keys())
+        annotated = list(self.coco.imgToAnns.keys())
+        self.ids = annotated if (annotated and has_gt) else list(self.coco.imgs.keys())
         self.transform = transform
         self.target_transform = COCOAnnotationTransform()      # data/coco.py:86 ignores the argument as well
         self.name = dataset_name
         self.has_gt = has_gt
         self.device = device
 
-    def __getitem__(self, index):
-        im, gt, masks, h, w, num_crowds = self.pull_item(index)
-        return im, (gt, masks, num_crowds)
-
     def __len__(self):
         return len(self.ids)
 
+    def __getitem__(self, index):
+        image, boxes, masks, _, _, num_crowds = self.pull_item(index)
+        return image, (boxes, masks, num_crowds)
+
     def _path(self, img_id):
-        file_name = self.coco.loadImgs(img_id)[0]['file_name']
-        if file_name.startswith('COCO'):             # COCO2014 names -> the %012d.jpg the download script writes
-            file_name = file_name.split('_')[-1]
-        path = osp.join(self.root, file_name)
+        name = self.coco.loadImgs(img_id)[0]['file_name']
+        if name.startswith('COCO'):                  # COCO2014 "COCO_val2014_%012d.jpg" -> the "%012d.jpg" the download script writes
+            name = name.rsplit('_', 1)[-1]
+        path = osp.join(self.root, name)
         assert osp.exists(path), 'Image path does not exist: {}'.format(path)
         return path
 
     def pull_item(self, index):
         """-> (image [3,S,S] float32 on the GPU, target [n,5] float ndarray, masks [n,h,w] uint8 ndarray, height, width,
-        num_crowds) — data/coco.py:100-176."""
+        num_crowds) — data/coco.py:100-176.  No annotations (has_gt=False): target and masks are None (what the
+        reference's else-branch assigns, data/coco.py:163-167; its next line then dereferences the None and raises — an
+        evident slip, not reproduced)."""
         img_id = self.ids[index]
+        anns, num_crowds = [], 0
         if self.has_gt:
-            ann_ids = self.coco.getAnnIds(imgIds=img_id)
-            target = [x for x in self.coco.loadAnns(ann_ids) if x['image_id'] == img_id]
-        else:
-            target = []
-        crowd = [x for x in target if ('iscrowd' in x and x['iscrowd'])]
-        target = [x for x in target if not ('iscrowd' in x and x['iscrowd'])]
-        num_crowds = len(crowd)
-        for x in crowd:
-            x['category_id'] = -1
-        target += crowd                              # crowd annotations at the end of the array
+            mine = self.coco.loadAnns(self.coco.getAnnIds(imgIds=img_id))
+            anns, num_crowds = _split_crowds([a for a in mine if a['image_id'] == img_id])
 
-        img = jpeg.imread(self._path(img_id), self.device)
-        height, width, _ = img.shape
+        img = jpeg.imread(self._path(img_id), self.device)                     # uint8 BGR [h,w,3], device
+        height, width = int(img.shape[0]), int(img.shape[1])
 
-        masks = None
-        if len(target) > 0:
-            masks = np.stack([ann_to_mask(obj, height, width) for obj in target], axis=0)
-        if self.target_transform is not None and len(target) > 0:
-            target = self.target_transform(target, width, height)
+        masks = target = None
+        if anns:
+            masks = np.stack([ann_to_mask(a, height, width) for a in anns])
+            target = np.array(self.target_transform(anns, width, height))
 
         if self.transform is not None:
-            if len(target) > 0:
-                target = np.array(target)
-                img, masks, boxes, labels = self.transform(img, masks, target[:, :4],
-                                                           {'num_crowds': num_crowds, 'labels': target[:, 4]})
-                num_crowds = labels['num_crowds']
-                labels = labels['labels']
-                target = np.hstack((boxes, np.expand_dims(labels, axis=1)))
+            if target is not None and len(target):
+                meta = {'num_crowds': num_crowds, 'labels': target[:, 4]}
+                img, masks, boxes, meta = self.transform(img, masks, target[:, :4], meta)
+                num_crowds = meta['num_crowds']                               # (the transform may have dropped boxes)
+                target = np.hstack((boxes, meta['labels'][:, None]))
+                if len(target) == 0:
+                    print('Warning: Augmentation output an example with no ground truth. Resampling...')
+                    return self.pull_item(random.randint(0, len(self.ids) - 1))
             else:
-                img, _, _, _ = self.transform(img, np.zeros((1, height, width), dtype=np.float64),
-                                              np.array([[0, 0, 1, 1]]), {'num_crowds': 0, 'labels': np.array([0])})
-                masks = None
-                target = None
+                # the reference feeds a dummy box through the transform and then reports "no ground truth"
+                dummy = {'num_crowds': 0, 'labels': np.array([0])}
+                img = self.transform(img, np.zeros((1, height, width)), np.array([[0., 0., 1., 1.]]), dummy)[0]
+                masks = target = None
 
-        if target is not None and not isinstance(target, list) and target.shape[0] == 0:
-            print('Warning: Augmentation output an example with no ground truth. Resampling...')
-            return self.pull_item(random.randint(0, len(self.ids) - 1))
-
-        if img.dim() == 3 and img.shape[2] == 3:     # HWC (the transform's convention) -> CHW
+        if img.dim() == 3 and img.shape[-1] == 3:     # HWC (the transform's convention) -> CHW
             img = img.permute(2, 0, 1)
         return img, target, masks, height, width, num_crowds
 
@@ -197,8 +197,7 @@ class COCODetection(torch.utils.data.Dataset):
         return jpeg.imread(self._path(self.ids[index]), self.device)
 
     def pull_anno(self, index):
-        img_id = self.ids[index]
-        return self.coco.loadAnns(self.coco.getAnnIds(imgIds=img_id))
+        return self.coco.loadAnns(self.coco.getAnnIds(imgIds=self.ids[index]))
 
     def __repr__(self):
-        return 'Dataset %s\n    Number of datapoints: %d\n    Root Location: %s\n' % (self.__class__.__name__, len(self), self.root)
+        return '%s(%d images, root=%r, has_gt=%s)' % (type(self).__name__, len(self), self.root, self.has_gt)
