@@ -139,6 +139,8 @@ def roofline(net, x, reps=3):
     return {
         'bound': 'mfma', 'kernel': name, 'achieved': round(ach, 2), 'peak': round(peak, 1),
         'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': traffic_from_profiles(name),
+        # continuity with round 1, where every tile ran on the exact-fp32 MFMA: the same achieved rate against THAT peak
+        'achieved_vs_fp32_mfma_peak': round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
         'peak_basis': ('fp32 MFMA (v_mfma_f32_32x32x2_f32), 157.3 TFLOP/s' if peak == FP32_MFMA_PEAK_TFLOPS else
                        'bf16x3 tile: every fp32 operand split exactly into 3 bf16 pieces, 6 piece products per fp32-class '
                        'product on v_mfma_f32_32x32x16_bf16 with fp32 accumulate -> peak = 2500 / 6 = 416.7 TFLOP/s of '
@@ -159,6 +161,8 @@ def roofline(net, x, reps=3):
                    'ms_per_step': round(eng_ms / reps, 3),
                    'executed_tflops': round(sum(v[1] for v in by_kernel.values()) / (eng_ms * 1e-3) / 1e12, 2),
                    'frac': round(eng_ideal_ms / eng_ms, 4),
+                   'executed_vs_fp32_mfma_peak': round(sum(v[1] for v in by_kernel.values()) / (eng_ms * 1e-3) / 1e12
+                                                       / FP32_MFMA_PEAK_TFLOPS, 4),
                    'x3_share_of_time': round(x3_ms / eng_ms, 3),
                    'basis': 'fp32(-equivalent) FLOPs executed by all GEMM launches of a step / their summed durations; frac '
                             '= matrix-pipe time at each launch\'s own peak (157.3 exact-fp32 tiles, 416.7 bf16x3 tiles) / '
