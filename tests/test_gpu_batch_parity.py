@@ -34,6 +34,9 @@ CASES = [
 ]
 
 
+_oracle_cache = {}      # (batch, size, image seed, config, weight seed, gain) -> the oracle's head tensors
+
+
 def _build(config, seed, gain):
     import yolact_amd
     yolact_amd.set_cfg(config)
@@ -42,6 +45,7 @@ def _build(config, seed, gain):
     sd = synth_state_dict([(k, tuple(v.shape)) for k, v in net.state_dict().items()], seed=seed, conf_gain=gain)
     net.load_state_dict_compat(sd)
     net.detect.use_fast_nms = True
+    net._synth_key = (config, seed, gain)      # two builds of the same synthetic model share the oracle's results
     return net.to(DEV), sd
 
 
@@ -50,8 +54,13 @@ def _compare(net, sd, config, B, size, img_seed, tag):
     from yolact_amd.layers.output_utils import postprocess
     cfg = CONFIGS[config].copy()
     x = synth_images(B, size, size, seed=img_seed)
+    key = (B, size, img_seed) + net._synth_key
+    if key not in _oracle_cache:      # the CPU oracle at the bench batch is the expensive part: one run per (model, input)
+        with torch.no_grad():
+            raw = O.forward_raw(x, sd, cfg)
+            _oracle_cache[key] = raw
+    raw = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in _oracle_cache[key].items()}     # consumers may write in place
     with torch.no_grad():
-        raw = O.forward_raw(x, sd, cfg)
         dets = O.detect(raw, cfg)
     xd = x.to(DEV)
     got = net.forward_raw(xd)
