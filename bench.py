@@ -289,6 +289,7 @@ def main():
     ap.add_argument('--with-postprocess', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true')
+    ap.add_argument('--no-pipeline', action='store_true', help='block on the host read of every step before launching the next')
     ap.add_argument('--layers', action='store_true', help='also print the per-layer conv table to stderr')
     args = ap.parse_args()
     if args.gpus < 1:
@@ -339,24 +340,54 @@ def main():
         have_pg = dist.is_initialized()
         got = {'n': 0}
 
-        def step():
+        # One step = forward + Detect + the RCCL gather of the records + the host read of the per-image counts (rank 0).
+        # The host read of step i is issued as an asynchronous device-to-host copy right behind that step's kernels and
+        # COLLECTED after step i+1 has been launched (depth-2 software pipeline, two pinned buffers), so the GPU does not
+        # idle while the host turns around; every step's counts still reach the host, in order, inside the timed region.
+        # --no-pipeline restores the launch / blocking read / launch sequence.
+        host_counts = [torch.empty(args.batch * world, dtype=torch.float32, pin_memory=True) for _ in range(2)]
+        turn = {'i': 0}
+
+        def launch():
             out = net.forward_device(x)
-            rec = parallel.gather_records(parallel.pack_records(out), dst=0, force_collective=have_pg)
+            rec = parallel.gather_records(parallel.pack_records(out), dst=0, rows_per_rank=args.batch,
+                                          force_collective=have_pg)
+            handle = None
             if rec is not None:
-                counts = rec[:, 0].tolist()                         # host read of the per-image counts (rank 0)
-                got['n'] = len(counts)
+                buf = host_counts[turn['i'] & 1]
+                turn['i'] += 1
+                buf[:rec.shape[0]].copy_(rec[:, 0], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                handle = (buf, ev, int(rec.shape[0]))
             if args.with_postprocess:
                 postprocess_batch(out, size, size)
-            return rec
+            return handle
 
-        for _ in range(args.warmup):
-            step()
+        def collect(handle):
+            if handle is not None:
+                buf, ev, n = handle
+                ev.synchronize()
+                counts = buf[:n].tolist()                           # the per-image detection counts, on the host
+                got['n'] = len(counts)
+
+        def run_steps(k):
+            prev = None
+            for _ in range(k):
+                cur = launch()
+                if args.no_pipeline:
+                    collect(cur)
+                else:
+                    collect(prev)
+                    prev = cur
+            collect(prev)
+
+        run_steps(args.warmup)
         if have_pg:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
+        run_steps(args.steps)
         if have_pg:
             dist.barrier()
         torch.cuda.synchronize()
@@ -385,6 +416,8 @@ def main():
                                        % ('configs[1]: ' if is_headline else '', args.config, size, size, args.batch),
                            'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
                            'postprocess_in_step': bool(args.with_postprocess),
+                           'host_read': ('blocking, every step' if args.no_pipeline else
+                                         'every step, asynchronous D2H copy collected after the next step is launched (depth 2)'),
                            'plan': {'source': 'shipped tune table yolact_amd/tune/gfx950.json' if plan.tune_misses == 0
                                     else 'tune table + %d shapes measured in this process' % plan.tune_misses,
                                     'tune_misses': plan.tune_misses}},
