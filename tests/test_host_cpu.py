@@ -121,15 +121,19 @@ def test_struct_layout_matches_c_compiler(tmp_path):
     import subprocess
     from yolact_amd import _lib as L
     src = tmp_path / 'sz.c'
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu\\n",'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu\\n",'
                    'sizeof(ymi_conv_seg),sizeof(ymi_conv_desc),sizeof(ymi_dcn_desc),sizeof(ymi_detect_desc),'
                    'offsetof(ymi_conv_desc,seg),offsetof(ymi_conv_desc,B),offsetof(ymi_detect_desc,scores_t),'
-                   'offsetof(ymi_dcn_desc,offmask));return 0;}' % os.path.join(ROOT, 'include', 'yolact_amd.h'))
+                   'offsetof(ymi_dcn_desc,offmask),sizeof(ymi_wino_desc),offsetof(ymi_wino_desc,u_x3),'
+                   'sizeof(ymi_jpeg_info),offsetof(ymi_jpeg_info,coef_count),offsetof(ymi_jpeg_info,dw));return 0;}'
+                   % os.path.join(ROOT, 'include', 'yolact_amd.h'))
     exe = tmp_path / 'sz'
     subprocess.run(['gcc', str(src), '-o', str(exe)], check=True)
     got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     want = [ctypes.sizeof(L.ConvSeg), ctypes.sizeof(L.ConvDesc), ctypes.sizeof(L.DcnDesc), ctypes.sizeof(L.DetectDesc),
-            L.ConvDesc.seg.offset, L.ConvDesc.B.offset, L.DetectDesc.scores_t.offset, L.DcnDesc.offmask.offset]
+            L.ConvDesc.seg.offset, L.ConvDesc.B.offset, L.DetectDesc.scores_t.offset, L.DcnDesc.offmask.offset,
+            ctypes.sizeof(L.WinoDesc), L.WinoDesc.u_x3.offset, ctypes.sizeof(L.JpegInfo), L.JpegInfo.coef_count.offset,
+            L.JpegInfo.dw.offset]
     assert got == want, (got, want)
 
 
