@@ -236,6 +236,12 @@ int ymi_composite_masks_u8(const float *img, const float *masks, const float *co
  * counts [N,cap] uint32, nruns [N] = true number of runs of each mask (a mask with nruns > cap was truncated: retry
  * with a larger cap). */
 int ymi_mask_rle_f32(const float *masks, int N, int h, int w, uint32_t *counts, int32_t *nruns, int cap, void *stream);
+/* The same counts for the masks `ymi_mask_upsample_f32(masks_lo, ..., thresh)` WOULD write, without writing them: upsample
+ * (bilinear, align_corners=False, output_utils.py:91), threshold (`> thresh`, :94) and run-length encoding in one kernel.
+ * masks_lo [N,ph,pw] = the cropped sigmoid masks at prototype resolution (ymi_lincomb_crop_f32).  The COCO result path
+ * (eval.py:403-429) then reads N*ph*pw*4 bytes instead of writing and re-reading N*h*w*4.  32*w + 12*h <= 65536 (LDS tables). */
+int ymi_mask_rle_upsampled_f32(const float *masks_lo, int N, int ph, int pw, int h, int w, float thresh, uint32_t *counts,
+                               int32_t *nruns, int cap, void *stream);
 /* counts -> the ASCII string pycocotools stores in 'counts' (delta to counts[i-2] for i > 2, 5 bits per character,
  * 0x20 = continuation, + 48).  str [N,cap_chars] bytes, nchars [N] = true length (> cap_chars: truncated). */
 int ymi_rle_to_string(const uint32_t *counts, const int32_t *nruns, int N, int cap, uint8_t *str, int32_t *nchars,

@@ -162,3 +162,100 @@ def test_gpu_detections_records_of_reference_postprocess_outputs(name, b):
         assert d.mask_data[k] == {'image_id': 42, 'category_id': inv[int(cl[i])], 'segmentation': R.encode(mk[i]),
                                   'score': float(mask_sc[i])}
     json.dumps(d.mask_data)                                                       # json.dump-able like the reference's
+
+
+# ------------------------------------------------------------------------------- GPU: upsample + threshold + RLE fused
+def _smooth_lowres(n, ph, pw, seed):
+    """Sigmoid-like low-resolution masks with structure at every scale (blobs, thin lines, values close to 0.5), cropped
+    to boxes like postprocess does (zeros outside)."""
+    g = torch.Generator().manual_seed(seed)
+    m = torch.rand(n, ph, pw, generator=g)
+    m = torch.nn.functional.avg_pool2d(m[:, None], 5, 1, 2)[:, 0] * 2.2 - 0.6          # smooth field around the threshold
+    m = torch.sigmoid(6 * (m - 0.5))
+    for i in range(n):
+        y0, x0 = int(torch.randint(0, ph // 2 + 1, (1,), generator=g)), int(torch.randint(0, pw // 2 + 1, (1,), generator=g))
+        y1, x1 = min(ph, y0 + 1 + int(torch.randint(0, ph, (1,), generator=g))), min(pw, x0 + 1 + int(torch.randint(0, pw, (1,), generator=g)))
+        crop = torch.zeros(ph, pw)
+        crop[y0:y1, x0:x1] = 1
+        m[i] *= crop
+    m[0] = 0.0                                                                         # an empty mask
+    if n > 1:
+        m[1] = 1.0                                                                     # a full one
+    return m
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('lo,hi', [((138, 138), (550, 550)), ((138, 138), (480, 640)), ((176, 176), (700, 700)),
+                                   ((7, 5), (3, 9)), ((20, 30), (20, 30)), ((138, 138), (97, 2000)), ((3, 3), (1, 1))])
+def test_gpu_fused_upsample_rle_equals_upsample_then_rle(lo, hi):
+    """ymi_mask_rle_upsampled_f32 (masks never materialised) == ymi_mask_upsample_f32 + ymi_mask_rle_f32, byte for byte, and
+    == the host codec applied to the device's upsampled masks."""
+    import ctypes as C
+    from yolact_amd import _lib as L
+    from yolact_amd.coco import rle_encode, rle_encode_lowres
+    (ph, pw), (h, w) = lo, hi
+    n = 12
+    mlo = _smooth_lowres(n, ph, pw, seed=ph * 1000 + w).cuda()
+    full = torch.empty(n, h, w, device='cuda')
+    L.check(L.lib().ymi_mask_upsample_f32(mlo.data_ptr(), full.data_ptr(), n, ph, pw, h, w, C.c_float(0.5), L.stream_ptr()))
+    want = rle_encode(full)
+    got = rle_encode_lowres(mlo, h, w, 0.5, cap=8)             # tiny initial capacity: exercises the retry path too
+    assert got == want
+    host = full.cpu().numpy()
+    for i in (0, 1, n - 1):
+        assert got[i] == R.encode(host[i])
+    assert got[0]['counts'] == R.rle_to_string([h * w]) and got[1]['counts'] == R.rle_to_string([0, h * w])
+
+
+@pytest.mark.gpu
+def test_gpu_fused_rle_rejects_bad_arguments():
+    from yolact_amd import _lib as L
+    lib = L.lib()
+    m = torch.zeros(2, 8, 8, device='cuda')
+    c = torch.zeros(2, 16, dtype=torch.int32, device='cuda')
+    nr = torch.zeros(2, dtype=torch.int32, device='cuda')
+    import ctypes as C
+    half = C.c_float(0.5)
+    assert lib.ymi_mask_rle_upsampled_f32(m.data_ptr(), 2, 8, 8, 0, 16, half, c.data_ptr(), nr.data_ptr(), 16, None) == -1
+    assert lib.ymi_mask_rle_upsampled_f32(None, 2, 8, 8, 16, 16, half, c.data_ptr(), nr.data_ptr(), 16, None) == -3
+    assert lib.ymi_mask_rle_upsampled_f32(m.data_ptr(), 2, 8, 8, 16, 4096, half, c.data_ptr(), nr.data_ptr(), 16, None) == -2
+    assert lib.ymi_mask_rle_upsampled_f32(m.data_ptr(), 0, 8, 8, 16, 16, half, c.data_ptr(), nr.data_ptr(), 16, None) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['r50_dense', 'plus_r50'])
+def test_gpu_postprocess_rle_equals_postprocess_then_encode(name):
+    """postprocess_rle (the COCO result path without full-resolution masks) == rle_encode(postprocess(...)) on the
+    detections of a golden case (incl. YOLACT++ re-scoring); Detections.add_records == Detections.add_image."""
+    import yolact_amd
+    from gpu_utils import build_net
+    from helpers import oracle_run
+    from yolact_amd.coco import COCO_LABEL_MAP, Detections, rle_encode
+    from yolact_amd.layers.output_utils import postprocess, postprocess_rle
+    meta, arrays, cfg, sd, raw, dets = oracle_run(name)
+    yolact_amd.set_cfg(meta['config'])
+    net = build_net(meta)
+    w, h = meta['post']
+    done = 0
+    for ref in dets:
+        if ref is None:
+            continue
+        mk = lambda: [{'detection': {k: ref[k].cuda().clone() for k in ('box', 'mask', 'class', 'score', 'proto')}, 'net': net}]  # noqa: E731
+        classes, scores, boxes, masks = postprocess(mk(), w, h, score_threshold=0.1)
+        c2, s2, b2, rles = postprocess_rle(mk(), w, h, score_threshold=0.1, fused=True)
+        assert postprocess_rle(mk(), w, h, score_threshold=0.1)[3] == rles          # the default (two kernels) gives the same records
+        assert torch.equal(classes, c2) and torch.equal(boxes, b2)
+        if isinstance(scores, list):
+            assert all(torch.equal(a, b_) for a, b_ in zip(scores, s2))
+            box_sc, mask_sc = scores
+        else:
+            assert torch.equal(scores, s2)
+            box_sc = mask_sc = scores
+        assert len(rles) == masks.shape[0] > 0 and rles == rle_encode(masks)
+        d1, d2 = Detections(label_map=COCO_LABEL_MAP), Detections(label_map=COCO_LABEL_MAP)
+        d1.add_image(7, classes, boxes, box_sc, masks, mask_sc)
+        d2.add_records(7, c2, b2, box_sc, rles, mask_sc)
+        assert d1.bbox_data == d2.bbox_data and d1.mask_data == d2.mask_data and len(d1.mask_data) > 0
+        done += 1
+    assert done > 0
+    assert postprocess_rle([{'detection': None, 'net': net}], w, h) == ([], [], [], [])

@@ -109,6 +109,7 @@ SYMBOLS = [
     ('ymi_composite_masks_u8', C.c_int, [_P, _P, _P, _I, _I, _I, _F, _P, _P]),
     ('ymi_mask_iou_f32', C.c_int, [_P, _P, _I, _I, C.c_long, _I, _P, _P, _P]),
     ('ymi_mask_rle_f32', C.c_int, [_P, _I, _I, _I, _P, _P, _I, _P]),
+    ('ymi_mask_rle_upsampled_f32', C.c_int, [_P, _I, _I, _I, _I, _I, _F, _P, _P, _I, _P]),
     ('ymi_rle_to_string', C.c_int, [_P, _P, _I, _I, _P, _P, _I, _P]),
     ('ymi_fast_base_transform_f32', C.c_int, [_P, _P, _I, _I, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _I, _I, _P]),
     ('ymi_jpeg_parse', C.c_int, [_P, C.c_size_t, C.POINTER(JpegInfo)]),

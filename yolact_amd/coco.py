@@ -10,6 +10,7 @@ layout; `add_masks` is the batched entry the device path wants (one launch pair 
 """
 from __future__ import annotations
 
+import ctypes as C
 import json
 
 import numpy as np
@@ -34,6 +35,31 @@ def get_label_map(cfg=None):
     return lm
 
 
+def _encode_strings(launch_counts, N, h, w, dev, cap):
+    """Run `launch_counts(counts, nruns, cap, stream)` + the string kernel, growing `cap` until no mask is truncated."""
+    lib = L.lib()
+    with torch.cuda.device(dev):
+        s = L.stream_ptr()
+        while True:
+            counts = torch.empty(N, cap, dtype=torch.int32, device=dev)
+            nruns = torch.empty(N, dtype=torch.int32, device=dev)
+            cap_chars = 7 * cap                       # a 32-bit (delta) count needs at most 7 characters of 5 bits
+            text = torch.empty(N, cap_chars, dtype=torch.uint8, device=dev)
+            nchars = torch.empty(N, dtype=torch.int32, device=dev)
+            launch_counts(counts, nruns, cap, s)
+            L.check(lib.ymi_rle_to_string(counts.data_ptr(), nruns.data_ptr(), N, cap, text.data_ptr(), nchars.data_ptr(),
+                                          cap_chars, s), 'rle_to_string')
+            both = torch.stack((nruns, nchars)).cpu()              # the one synchronising read
+            need = int(both[0].max())
+            if need <= cap:
+                break
+            cap = 1 << (need - 1).bit_length()                     # some mask was truncated: retry with room for it
+        lens = both[1].tolist()
+        width = max(lens)
+        host = text[:, :width].cpu().numpy()
+    return [{'size': [h, w], 'counts': host[i, :lens[i]].tobytes().decode('ascii')} for i in range(N)]
+
+
 def rle_encode(masks: torch.Tensor, cap: int = 4096):
     """masks: [N,h,w] float32 CUDA tensor (postprocess' {0,1} masks).  Returns N dicts {'size': [h, w], 'counts': str},
     byte-identical to pycocotools.mask.encode(...)['counts'].decode('ascii').  `cap` = initial run capacity per mask
@@ -46,27 +72,30 @@ def rle_encode(masks: torch.Tensor, cap: int = 4096):
         return []
     masks = masks.detach().to(torch.float32).contiguous()
     lib = L.lib()
-    dev = masks.device
-    with torch.cuda.device(dev):
-        s = L.stream_ptr()
-        while True:
-            counts = torch.empty(N, cap, dtype=torch.int32, device=dev)
-            nruns = torch.empty(N, dtype=torch.int32, device=dev)
-            cap_chars = 7 * cap                       # a 32-bit (delta) count needs at most 7 characters of 5 bits
-            text = torch.empty(N, cap_chars, dtype=torch.uint8, device=dev)
-            nchars = torch.empty(N, dtype=torch.int32, device=dev)
-            L.check(lib.ymi_mask_rle_f32(masks.data_ptr(), N, h, w, counts.data_ptr(), nruns.data_ptr(), cap, s), 'mask_rle')
-            L.check(lib.ymi_rle_to_string(counts.data_ptr(), nruns.data_ptr(), N, cap, text.data_ptr(), nchars.data_ptr(),
-                                          cap_chars, s), 'rle_to_string')
-            both = torch.stack((nruns, nchars)).cpu()              # the one synchronising read
-            need = int(both[0].max())
-            if need <= cap:
-                break
-            cap = 1 << (need - 1).bit_length()                     # some mask was truncated: retry with room for it
-        lens = both[1].tolist()
-        width = max(lens)
-        host = text[:, :width].cpu().numpy()
-    return [{'size': [h, w], 'counts': host[i, :lens[i]].tobytes().decode('ascii')} for i in range(N)]
+
+    def launch(counts, nruns, cap, s):
+        L.check(lib.ymi_mask_rle_f32(masks.data_ptr(), N, h, w, counts.data_ptr(), nruns.data_ptr(), cap, s), 'mask_rle')
+    return _encode_strings(launch, N, h, w, masks.device, cap)
+
+
+def rle_encode_lowres(masks_lo: torch.Tensor, h: int, w: int, thresh: float = 0.5, cap: int = 4096):
+    """masks_lo: [N,ph,pw] float32 CUDA tensor — the cropped sigmoid masks at prototype resolution (what `postprocess`
+    holds before its upsample, output_utils.py:69-88).  Returns the records rle_encode would return for
+    `F.interpolate(masks_lo, (h, w), 'bilinear', align_corners=False) > thresh` without materialising those masks: upsample,
+    threshold and run-length encoding are one kernel (same arithmetic as the upsample kernel, byte-identical strings)."""
+    L.require_cuda(masks_lo, 'masks_lo')
+    if masks_lo.dim() != 3:
+        raise ValueError('expected [N,ph,pw] masks, got %s' % (tuple(masks_lo.shape),))
+    N, ph, pw = (int(v) for v in masks_lo.shape)
+    if N == 0:
+        return []
+    masks_lo = masks_lo.detach().to(torch.float32).contiguous()
+    lib = L.lib()
+
+    def launch(counts, nruns, cap, s):
+        L.check(lib.ymi_mask_rle_upsampled_f32(masks_lo.data_ptr(), N, ph, pw, int(h), int(w), C.c_float(thresh),
+                                               counts.data_ptr(), nruns.data_ptr(), cap, s), 'mask_rle_upsampled')
+    return _encode_strings(launch, N, int(h), int(w), masks_lo.device, cap)
 
 
 def rle_counts(masks: torch.Tensor, cap: int = 4096):
@@ -138,6 +167,20 @@ class Detections:
         if keep:
             idx = torch.as_tensor(keep, device=masks.device)
             self.add_masks(image_id, [classes[i] for i in keep], masks.index_select(0, idx), [mask_scores[i] for i in keep])
+
+    def add_records(self, image_id: int, classes, boxes, box_scores, rles, mask_scores=None):
+        """add_image for masks that are already COCO RLE records (layers.output_utils.postprocess_rle): the same filter
+        (boxes of positive area, eval.py:426) and the same JSON records, without full-resolution masks."""
+        classes = [int(c) for c in (classes.tolist() if torch.is_tensor(classes) else classes)]
+        boxes = boxes.detach().cpu().numpy() if torch.is_tensor(boxes) else np.asarray(boxes)
+        to_list = lambda v: v.detach().cpu().tolist() if torch.is_tensor(v) else list(v)   # noqa: E731
+        box_scores = to_list(box_scores)
+        mask_scores = box_scores if mask_scores is None else to_list(mask_scores)
+        for i in range(len(classes)):
+            if (boxes[i, 3] - boxes[i, 1]) * (boxes[i, 2] - boxes[i, 0]) > 0:
+                self.add_bbox(image_id, classes[i], boxes[i, :], box_scores[i])
+                self.mask_data.append({'image_id': int(image_id), 'category_id': self.get_coco_cat(classes[i]),
+                                       'segmentation': rles[i], 'score': float(mask_scores[i])})
 
     def dump(self):
         for data, path in ((self.bbox_data, self.bbox_path), (self.mask_data, self.mask_path)):

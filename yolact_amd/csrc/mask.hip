@@ -2,6 +2,7 @@
 // then bilinear upsample to the image size + binarise, and box sanitising.
 // Reference: layers/output_utils.py:69-99, layers/box_utils.py:327-373 (sanitize_coordinates, crop).
 #include "common.h"
+#include "upsample_math.h"
 #include <stdlib.h>
 #include "../../include/yolact_amd.h"
 
@@ -97,15 +98,6 @@ __global__ __launch_bounds__(256) void lincomb_crop_k(const float *__restrict__ 
   }
 }
 
-__device__ __forceinline__ void up_coord(int dst, float scale, int in_size, int &i0, int &i1, float &l1) {
-  float src = scale * ((float)dst + 0.5f) - 0.5f;
-  src = src < 0.f ? 0.f : src;
-  i0 = (int)src;
-  if (i0 > in_size - 1) i0 = in_size - 1;
-  i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
-  l1 = src - (float)i0;
-}
-
 // out[n,y,x] = (bilinear(masks_lo[n])[y,x] > thresh) ? 1 : 0.  Flat float4 stores: pure HBM-write stream
 // (N*h*w*4 bytes, 121 MB at N=100, 550x550) while the [N,ph,pw] source stays L2-resident.
 __global__ __launch_bounds__(256) void mask_upsample_k(const float *__restrict__ lo, float *__restrict__ out, int ph,
@@ -129,7 +121,7 @@ __global__ __launch_bounds__(256) void mask_upsample_k(const float *__restrict__
         const float *img = lo + n * (long)ph * pw;
         const float v00 = img[y0 * pw + x0], v01 = img[y0 * pw + x1];
         const float v10 = img[y1 * pw + x0], v11 = img[y1 * pw + x1];
-        const float v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+        const float v = up_lerp2(v00, v01, v10, v11, lx, ly);
         r = thresh < 0.f ? v : (v > thresh ? 1.f : 0.f);
       }
       o[e] = r;
@@ -177,7 +169,7 @@ __global__ __launch_bounds__(256) void mask_upsample_band_k(const float *__restr
       up_coord(y_begin + r, sh, ph, y0, y1, ly);
       if (y0 != cy0) { cy0 = y0; v00 = img[y0 * pw + x0]; v01 = img[y0 * pw + x1]; }
       if (y1 != cy1) { cy1 = y1; v10 = img[y1 * pw + x0]; v11 = img[y1 * pw + x1]; }
-      const float v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+      const float v = up_lerp2(v00, v01, v10, v11, lx, ly);
       band[shift + r * w + x] = thresh < 0.f ? v : (v > thresh ? 1.f : 0.f);
     }
   }

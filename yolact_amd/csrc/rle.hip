@@ -10,12 +10,64 @@
 //   transitions and remembers the last transition position per segment; a block scan over the segments in sequence order
 //   (column outer, band inner) yields each segment's output offset (sum) and its predecessor transition (max); pass 2
 //   (reads served by L2: a mask is 1.2 MB) writes the run lengths directly.  HBM-bound: N*h*w*4 bytes read once.
+//   The kernel is templated on where a mask's bits come from: a materialised [h,w] float mask (ymi_mask_rle_f32) or the
+//   prototype-resolution sigmoid mask of postprocess, upsampled and thresholded on the fly (ymi_mask_rle_upsampled_f32):
+//   then the full-resolution masks are never written and the kernel reads N*ph*pw*4 bytes (L1 / L2-resident per block).
 // rle_string_k: one block per mask; thread i turns count i (minus count i-2 for i > 2) into 1..7 characters (5 bits each,
 //   0x20 = continuation, + 48), a block scan of the lengths places them.
 #include "common.h"
+#include "upsample_math.h"
 #include "../../include/yolact_amd.h"
 
 namespace {
+
+// Where the bits of a mask come from.  A source hands out a per-column context (the thread walks one column downwards)
+// and the bit of a row of that column.
+//   PlainSrc  a materialised [h,w] float mask (nonzero = foreground);
+//   UpSrc     the low-resolution sigmoid mask of postprocess (output_utils.py:69-94): bit = bilinear(lo)[y,x] > thresh with
+//             exactly mask_upsample's arithmetic (upsample_math.h), so the [N,h,w] float masks never exist — the COCO result
+//             path reads N*ph*pw*4 bytes (7.6 MB at N = 100, 138 x 138) instead of writing and re-reading N*h*w*4 (121 MB).
+struct PlainSrc {
+  const float *m;
+  int w;
+  struct Col { int x; };
+  __device__ __forceinline__ void prepare(uint32_t *, int) {}
+  __device__ __forceinline__ Col col(int x) const { return {x}; }
+  __device__ __forceinline__ int bit(Col &c, int y) const { return m[(size_t)y * w + c.x] != 0.f; }
+};
+
+struct UpSrc {
+  const float *lo;
+  int ph, pw;
+  float sh, sw, thresh;
+  const uint32_t *ytab;       // LDS: per output row {y0, y1, bits of ly}: the row coordinates are the same for every column
+  // the column context caches the two source rows it last touched: walking down a column, a source row serves ~h/ph
+  // consecutive output rows
+  struct Col { int x0, x1; float lx; int cy0, cy1; float v00, v01, v10, v11; };
+  __device__ __forceinline__ void prepare(uint32_t *extra, int h) {
+    for (int y = threadIdx.x; y < h; y += blockDim.x) {
+      int y0, y1; float ly;
+      up_coord(y, sh, ph, y0, y1, ly);
+      extra[3 * y] = (uint32_t)y0; extra[3 * y + 1] = (uint32_t)y1; extra[3 * y + 2] = __float_as_uint(ly);
+    }
+    ytab = extra;
+    __syncthreads();
+  }
+  __device__ __forceinline__ Col col(int x) const {
+    Col c;
+    up_coord(x, sw, pw, c.x0, c.x1, c.lx);
+    c.cy0 = c.cy1 = -1;
+    c.v00 = c.v01 = c.v10 = c.v11 = 0.f;
+    return c;
+  }
+  __device__ __forceinline__ int bit(Col &c, int y) const {
+    const int y0 = (int)ytab[3 * y], y1 = (int)ytab[3 * y + 1];
+    const float ly = __uint_as_float(ytab[3 * y + 2]);
+    if (y0 != c.cy0) { c.cy0 = y0; c.v00 = lo[y0 * pw + c.x0]; c.v01 = lo[y0 * pw + c.x1]; }
+    if (y1 != c.cy1) { c.cy1 = y1; c.v10 = lo[y1 * pw + c.x0]; c.v11 = lo[y1 * pw + c.x1]; }
+    return up_lerp2(c.v00, c.v01, c.v10, c.v11, c.lx, ly) > thresh;
+  }
+};
 
 constexpr int RB = 4;          // row bands per column
 constexpr int NT = 1024;       // threads per block (16 waves)
@@ -32,9 +84,10 @@ __device__ __forceinline__ SegRange seg_of(int q, int h, int w, int hb) {
   return {x, y0, y1};
 }
 
-__device__ __forceinline__ int seg_prev(const float *m, int x, int y0, int h, int w) {
-  if (y0 > 0) return m[(size_t)(y0 - 1) * w + x] != 0.f;
-  if (x > 0) return m[(size_t)(h - 1) * w + (x - 1)] != 0.f;
+template <typename Src>
+__device__ __forceinline__ int seg_prev(const Src &src, int x, int y0, int h) {
+  if (y0 > 0) { auto c = src.col(x); return src.bit(c, y0 - 1); }
+  if (x > 0) { auto c = src.col(x - 1); return src.bit(c, h - 1); }
   return 0;                                        // rleEncode starts with p = 0
 }
 
@@ -63,7 +116,9 @@ __device__ __forceinline__ void block_scan(uint32_t &sum, int &mx, uint32_t *ws_
   __syncthreads();
 }
 
-__global__ __launch_bounds__(NT) void rle_counts_k(const float *__restrict__ masks, int h, int w, uint32_t *__restrict__ counts,
+// SrcOf(mask index) -> the source of that mask
+template <typename SrcOf>
+__global__ __launch_bounds__(NT) void rle_counts_k(const SrcOf src_of, int h, int w, uint32_t *__restrict__ counts,
                                                   int32_t *__restrict__ nruns, int cap) {
   extern __shared__ uint32_t lds[];
   const int nseg = w * RB;
@@ -73,27 +128,29 @@ __global__ __launch_bounds__(NT) void rle_counts_k(const float *__restrict__ mas
   __shared__ int ws_max[NT / 64];
   __shared__ uint32_t total_s;
   __shared__ int lastpos_s;
-  const float *m = masks + (size_t)blockIdx.x * h * w;
+  auto src = src_of(blockIdx.x);
+  src.prepare(lds + 2 * nseg, h);                   // (the fused source tabulates its row coordinates behind the tables)
   const int hb = (h + RB - 1) / RB;
 
   for (int q = threadIdx.x; q < nseg; q += NT) {
     const SegRange sg = seg_of(q, h, w, hb);
-    int prev = sg.y1 > sg.y0 ? seg_prev(m, sg.x, sg.y0, h, w) : 0;
+    int prev = sg.y1 > sg.y0 ? seg_prev(src, sg.x, sg.y0, h) : 0;
+    auto col = src.col(sg.x);
     uint32_t c = 0;
     int lp = -1;
     int y = sg.y0;
     for (; y + UNR <= sg.y1; y += UNR) {
-      float v[UNR];
+      int v[UNR];
 #pragma unroll
-      for (int u = 0; u < UNR; ++u) v[u] = m[(size_t)(y + u) * w + sg.x];
+      for (int u = 0; u < UNR; ++u) v[u] = src.bit(col, y + u);
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
-        const int b = v[u] != 0.f;
+        const int b = v[u];
         if (b != prev) { ++c; lp = sg.x * h + y + u; prev = b; }
       }
     }
     for (; y < sg.y1; ++y) {
-      const int b = m[(size_t)y * w + sg.x] != 0.f;
+      const int b = src.bit(col, y);
       if (b != prev) { ++c; lp = sg.x * h + y; prev = b; }
     }
     const int r = q / w;
@@ -131,15 +188,16 @@ __global__ __launch_bounds__(NT) void rle_counts_k(const float *__restrict__ mas
     uint32_t k = cnt[sg.x * RB + r];
     int pp = last[sg.x * RB + r];                  // position of the previous transition (-1: none => run starts at 0)
     if (pp < 0) pp = 0;
-    int prev = seg_prev(m, sg.x, sg.y0, h, w);
+    int prev = seg_prev(src, sg.x, sg.y0, h);
+    auto col = src.col(sg.x);
     int y = sg.y0;
     for (; y + UNR <= sg.y1; y += UNR) {
-      float v[UNR];
+      int v[UNR];
 #pragma unroll
-      for (int u = 0; u < UNR; ++u) v[u] = m[(size_t)(y + u) * w + sg.x];
+      for (int u = 0; u < UNR; ++u) v[u] = src.bit(col, y + u);
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
-        const int b = v[u] != 0.f;
+        const int b = v[u];
         if (b != prev) {
           const int p = sg.x * h + y + u;
           if (k < (uint32_t)cap) out[k] = (uint32_t)(p - pp);
@@ -148,7 +206,7 @@ __global__ __launch_bounds__(NT) void rle_counts_k(const float *__restrict__ mas
       }
     }
     for (; y < sg.y1; ++y) {
-      const int b = m[(size_t)y * w + sg.x] != 0.f;
+      const int b = src.bit(col, y);
       if (b != prev) {
         const int p = sg.x * h + y;
         if (k < (uint32_t)cap) out[k] = (uint32_t)(p - pp);
@@ -211,6 +269,18 @@ __global__ __launch_bounds__(256) void rle_string_k(const uint32_t *__restrict__
   if (threadIdx.x == 0) nchars[blockIdx.x] = (int32_t)carry_s;
 }
 
+struct PlainOf {
+  const float *masks;
+  int h, w;
+  __device__ __forceinline__ PlainSrc operator()(int n) const { return {masks + (size_t)n * h * w, w}; }
+};
+struct UpOf {
+  const float *lo;
+  int ph, pw;
+  float sh, sw, thresh;
+  __device__ __forceinline__ UpSrc operator()(int n) const { return {lo + (size_t)n * ph * pw, ph, pw, sh, sw, thresh, nullptr}; }
+};
+
 }  // namespace
 
 extern "C" int ymi_mask_rle_f32(const float *masks, int N, int h, int w, uint32_t *counts, int32_t *nruns, int cap,
@@ -219,7 +289,20 @@ extern "C" int ymi_mask_rle_f32(const float *masks, int N, int h, int w, uint32_
   if (N == 0) return YMI_OK;
   if (!masks || !counts || !nruns) return YMI_ENULL;
   if ((long)h * w >= (1L << 31) || w * RB * 8 > 65536) return YMI_ESHAPE;      // segment tables live in LDS: w <= 2048
-  hipLaunchKernelGGL(rle_counts_k, dim3(N), dim3(NT), (size_t)w * RB * 8, (hipStream_t)stream, masks, h, w, counts, nruns, cap);
+  const PlainOf of{masks, h, w};
+  hipLaunchKernelGGL(rle_counts_k<PlainOf>, dim3(N), dim3(NT), (size_t)w * RB * 8, (hipStream_t)stream, of, h, w, counts, nruns, cap);
+  return ymi_launch_status();
+}
+
+extern "C" int ymi_mask_rle_upsampled_f32(const float *masks_lo, int N, int ph, int pw, int h, int w, float thresh,
+                                          uint32_t *counts, int32_t *nruns, int cap, void *stream) {
+  if (N < 0 || ph <= 0 || pw <= 0 || h <= 0 || w <= 0 || cap <= 0) return YMI_EARG;
+  if (N == 0) return YMI_OK;
+  if (!masks_lo || !counts || !nruns) return YMI_ENULL;
+  if ((long)h * w >= (1L << 31) || (long)w * RB * 8 + (long)h * 12 > 65536 || (long)ph * pw >= (1L << 31)) return YMI_ESHAPE;
+  const UpOf of{masks_lo, ph, pw, (float)ph / (float)h, (float)pw / (float)w, thresh};    // scales as mask_upsample computes them
+  hipLaunchKernelGGL(rle_counts_k<UpOf>, dim3(N), dim3(NT), (size_t)w * RB * 8 + (size_t)h * 12, (hipStream_t)stream, of, h, w, counts,
+                     nruns, cap);
   return ymi_launch_status();
 }
 
