@@ -203,3 +203,24 @@ def test_data_parallel_gather_world2_gloo():
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+@pytest.mark.parametrize('config,anchors', [('yolact_resnet50_config', 3), ('yolact_plus_resnet50_config', 9)])
+def test_head_gemm_is_padded_for_vector_stores_but_accounted_algorithmically(config, anchors):
+    """Class rows are stored with a stride of 84 floats (81 logits + 3 zero-filter columns per anchor) so that every segment
+    of the head GEMM starts 16-byte aligned; the descriptor's cout_alg keeps the FLOP accounting on the real columns and
+    Detect is handed the stride."""
+    from yolact_amd.engine import Plan
+    net = _make_net(config)
+    plan = Plan(net, 2, 550, 550, torch.device('cpu'))
+    assert plan.Ccls == 81 and plan.conf_ld == 84 and tuple(plan.conf.shape) == (2, plan.P, 84)
+    heads = [d for n, d in plan.conv_meta if n.endswith('.out')]
+    assert len(heads) == 5
+    for d in heads:
+        assert d.Cout == anchors * (4 + 32 + 84) and d.cout_alg == anchors * (4 + 32 + 81)
+        assert d.nseg == 3
+        segs = [d.seg[i] for i in range(3)]
+        assert [s.n0 for s in segs] == [0, anchors * 4, anchors * (4 + 84)] or \
+               [s.n1 - s.n0 for s in segs].count(anchors * 84) == 1            # loc | conf (padded) | coef in some order
+        for s in segs:
+            assert s.n0 % 4 == 0 and (s.n1 - s.n0) % 4 == 0, 'segments must start and end on float4 boundaries'
