@@ -88,11 +88,21 @@ def test_product_path_rejects_cpu_tensors():
     from yolact_amd.layers.detection import Detect
     d = Detect(81, 0, 200, 0.05, 0.5)
     assert d.use_fast_nms is False and d.use_cross_class_nms is False       # the reference's defaults (detection.py:29-30)
-    with pytest.raises(NotImplementedError, match='use_fast_nms'):          # traditional NMS: loud, not silently Fast NMS
-        d({'loc': torch.zeros(1, 8, 4), 'conf': torch.zeros(1, 8, 81), 'mask': torch.zeros(1, 8, 32),
-           'priors': torch.zeros(8, 4)}, None)
-    with pytest.raises(NotImplementedError, match='use_fast_nms'):
-        net(torch.zeros(1, 3, 550, 550))
+    # traditional NMS (the reference's constructor default) is CPU/Cython and off the hot path: the engine says so ONCE and
+    # runs Fast NMS (so a plain Yolact()(x) works); YOLACT_AMD_STRICT_NMS=1 makes it a hard error instead
+    preds = {'loc': torch.zeros(1, 8, 4), 'conf': torch.zeros(1, 8, 81), 'mask': torch.zeros(1, 8, 32), 'priors': torch.zeros(8, 4)}
+    Detect._warned_traditional = False
+    with pytest.warns(UserWarning, match='use_fast_nms'):
+        with pytest.raises(RuntimeError, match='GPU'):
+            d(preds, None)
+    os.environ['YOLACT_AMD_STRICT_NMS'] = '1'
+    try:
+        with pytest.raises(NotImplementedError, match='use_fast_nms'):
+            d(preds, None)
+        with pytest.raises(NotImplementedError, match='use_fast_nms'):
+            net(torch.zeros(1, 3, 550, 550))
+    finally:
+        del os.environ['YOLACT_AMD_STRICT_NMS']
     d.use_fast_nms = True                                                    # eval.py:871
     net.detect.use_fast_nms = True
     with pytest.raises(RuntimeError, match='GPU'):

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = '/root/reference'
 
 SCRIPT = r'''
-import sys, types, inspect, json
+import sys, types, inspect, json, os
 ROOT, REF = sys.argv[1], sys.argv[2]
 import torch
 
@@ -80,10 +80,12 @@ for cfg_name, keys in golden.items():
     except RuntimeError as e:
         assert 'GPU' in str(e)
     net.detect.use_fast_nms = False
+    os.environ['YOLACT_AMD_STRICT_NMS'] = '1'
     try:
-        net(torch.zeros(1, 3, cfg.max_size, cfg.max_size)); raise SystemExit('traditional NMS did not raise')
+        net(torch.zeros(1, 3, cfg.max_size, cfg.max_size)); raise SystemExit('traditional NMS did not raise in strict mode')
     except NotImplementedError:
         pass
+    del os.environ['YOLACT_AMD_STRICT_NMS']
     # cfg is read at CALL time: a field mutated through the reference's global is what the engine sees
     cfg.nms_top_k = 123
     assert net.cfg.nms_top_k == 123

@@ -1,0 +1,70 @@
+#!/bin/bash
+# ONE parametrised GPU session script (replaces the 35 one-off tools/gpu_session_*.sh of rounds 1-2; those stay in git
+# history and are what profiles/README.md's round-1/2 rows refer to).
+#   gpurun --timeout T -- 'bash tools/gpu_session.sh <name> <stage> [<stage> ...]'
+# Results go to gpurun_out/<name>/ (merged back by gpurun).  Stages (run in the order given):
+#   build        make -C yolact_amd/csrc (the .so normally travels with the snapshot; this is for probes built on the box)
+#   tune         re-measure the shipped tile table (all plans);   tune1 = configs[1] + batch 1/2 only
+#   pytest       full `-m gpu` suite;   pytest:<expr> = `-k <expr>`;   pytestf:<file> = one test file
+#   smoke        __graft_entry__.smoke()
+#   bench        driver-style bench line + per-layer table;   bench:<extra args> (use _ for spaces)
+#   configs      the other BASELINE configs (R101 B16, im700 B8, R50++ B8, Darknet53 B8), batch 1, exact-fp32-only
+#   stats        rocprofv3 --kernel-trace --stats of the bench command, single- and two-stream
+#   traffic      PMC FETCH_SIZE / WRITE_SIZE passes (separate runs, kernel-trace only) + tools/traffic_summary.py
+#   pmc          SQ busy / MFMA counters over the real plan (tools/pmc_summary.py)
+#   probe        tools/split_probe.hip (register/LDS-level ceilings of the split-precision schemes)
+#   dcnref       build oracle/_ref on the box if missing, run the reference-compiled DCN parity test
+#   evalpy       the reference's unmodified eval.py against the engine (needs the scratch copy staged by tools/stage_reference.sh)
+#   py:<file>    python <file> (a probe under tools/), output to <file basename>.log
+O=gpurun_out/$1; shift; mkdir -p $O
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$PWD}
+BENCH="python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary"
+for st in "$@"; do
+  arg="${st#*:}"; [ "$arg" = "$st" ] && arg=""; arg="${arg//_/ }"
+  case "${st%%:*}" in
+    build) make -C yolact_amd/csrc -j16 > $O/build.log 2>&1; tail -2 $O/build.log ;;
+    tune) timeout 1500 python tools/make_tune_table.py --fresh --copy-to $O/gfx950.json > $O/tune.log 2>&1; grep -E "plan|table" $O/tune.log | cut -c1-160 | tail -14 ;;
+    tune1) timeout 900 python tools/make_tune_table.py --only configs1_r50_b8 r50_b1 r50_b2 --copy-to $O/gfx950.json > $O/tune.log 2>&1; grep -E "plan|table" $O/tune.log | cut -c1-160 ;;
+    pytest) timeout 2400 python -m pytest tests -m gpu -q --timeout 900 -rA ${arg:+-k "$arg"} > $O/pytest.log 2>&1; grep -E "passed|failed" $O/pytest.log | tail -3; grep -E "^FAILED|^ERROR" $O/pytest.log | head -20 ;;
+    pytestf) timeout 1200 python -m pytest tests/$arg -m gpu -q --timeout 600 -rA -s > $O/pytest_${arg%.py}.log 2>&1; grep -E "passed|failed" $O/pytest_${arg%.py}.log | tail -3; grep -E "^FAILED|^ERROR" $O/pytest_${arg%.py}.log | head -20 ;;
+    smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log ;;
+    bench) timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --layers $arg > $O/bench.json 2> $O/bench_layers.txt; head -1 $O/bench.json | cut -c1-600 ;;
+    configs)
+      timeout 300 python bench.py --batch 1 --steps 50 --no-cpu-baseline --no-secondary > $O/bench_b1.json 2>/dev/null; head -1 $O/bench_b1.json | cut -c1-200
+      for c in "yolact_base_config 16 r101_b16" "yolact_im700_config 8 im700_b8" "yolact_plus_resnet50_config 8 plus_b8" "yolact_darknet53_config 8 darknet_b8"; do
+        set -- $c
+        timeout 400 python bench.py --config $1 --batch $2 --steps 10 --no-cpu-baseline --no-secondary > $O/bench_$3.json 2>/dev/null; head -1 $O/bench_$3.json | cut -c1-200
+      done
+      YOLACT_AMD_SPLIT=0 timeout 400 python bench.py --no-cpu-baseline --no-secondary > $O/bench_fp32only.json 2>/dev/null; head -1 $O/bench_fp32only.json | cut -c1-200 ;;
+    stats)
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $R/$O/stats2 -- bash -c "cd $R && $BENCH" > $R/$O/stats2.log 2>&1)
+      (cd /tmp && YOLACT_AMD_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $R/$O/stats1 -- bash -c "cd $R && $BENCH" > $R/$O/stats1.log 2>&1)
+      for v in 1 2; do python - $O/stats$v > $O/kernel_stats_streams$v.txt <<'PY'
+import csv, glob, sys
+fs = glob.glob(sys.argv[1] + '/**/*kernel_stats.csv', recursive=True)
+print('%-116s %8s %12s %10s %6s' % ('kernel', 'calls', 'total_ns', 'avg_ns', '%'))
+for r in (csv.DictReader(open(fs[0])) if fs else []):
+    print('%-116s %8s %12s %10.0f %6.2f' % (r['Name'][:116], r['Calls'], r['TotalDurationNs'], float(r['AverageNs']), float(r['Percentage'])))
+PY
+      done; head -12 $O/kernel_stats_streams1.txt | cut -c1-200 ;;
+    traffic)
+      CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary"
+      (cd /tmp && YOLACT_AMD_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex conv_igemm -f csv -d $R/$O/fetch -- bash -c "cd $R && $CMD" > $R/$O/fetch.log 2>&1)
+      (cd /tmp && YOLACT_AMD_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --kernel-include-regex conv_igemm -f csv -d $R/$O/write -- bash -c "cd $R && $CMD" > $R/$O/write.log 2>&1)
+      python tools/traffic_summary.py $O/fetch $O/write > $O/traffic.json 2> $O/traffic.err; head -c 600 $O/traffic.json
+      find $O -name "*counter_collection.csv" -size +4M -delete ;;
+    pmc)
+      (cd /tmp && YOLACT_AMD_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --kernel-include-regex conv_igemm -f csv -d $R/$O/pmc1 -- bash -c "cd $R && python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary" > $R/$O/pmc1.log 2>&1)
+      python tools/pmc_summary.py $O/pmc1 > $O/pmc_plan_p1.tsv 2> $O/pmc.err; head -20 $O/pmc_plan_p1.tsv | cut -c1-200
+      find $O -name "*counter_collection.csv" -size +4M -delete ;;
+    probe)
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/split_probe.hip -o /tmp/split_probe.bin > $O/probe_build.log 2>&1
+      timeout 300 /tmp/split_probe.bin > $O/split_probe.json 2> $O/probe.err; cat $O/split_probe.json | tr '}' '\n' | cut -c1-230 ;;
+    dcnref) timeout 600 python -m pytest tests/test_gpu_dcn_reference.py -m gpu -q -rA -s > $O/dcnref.log 2>&1; tail -5 $O/dcnref.log ;;
+    evalpy) timeout 1500 bash tools/run_reference_eval.sh $O > $O/evalpy.log 2>&1; tail -30 $O/evalpy.log ;;
+    py) timeout 900 python $arg > $O/$(basename ${arg%% *} .py).log 2>&1; tail -20 $O/$(basename ${arg%% *} .py).log ;;
+    *) echo "unknown stage $st" ;;
+  esac
+done
+ls $O

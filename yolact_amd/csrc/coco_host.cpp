@@ -41,7 +41,12 @@ int ymi_coco_poly_fill_u8(const double *xy, int k, int h, int w, uint8_t *mask) 
   if (!xy || !mask) return YMI_ENULL;
   if (k < 1 || h <= 0 || w <= 0 || (long)h * w > (1L << 31) - 1) return YMI_EARG;
   // maskApi.c scales by 5 into int: coordinates that cannot be image coordinates (or NaN) are an argument error here
-  for (int j = 0; j < 2 * k; ++j) if (!(std::fabs(xy[j]) < 1.0e5)) return YMI_EARG;
+  // (and bounds the boundary walk below: an edge contributes <= 5 * 3 * max(w, h) points, so a hostile polygon cannot ask
+  // for gigabytes — pycocotools itself has no such guard)
+  for (int j = 0; j < k; ++j) {
+    const double px = xy[2 * j], py = xy[2 * j + 1];
+    if (!(px >= -(double)w && px <= 2.0 * w && py >= -(double)h && py <= 2.0 * h)) return YMI_EARG;
+  }
   const double scale = 5;
   std::vector<int> x(k + 1), y(k + 1);
   for (int j = 0; j < k; ++j) x[j] = (int)(scale * xy[j * 2 + 0] + .5);
@@ -129,8 +134,8 @@ int ymi_coco_rle_string_fill_u8(const char *s, long len, int h, int w, uint8_t *
       more = (int)(c & 0x20);
       ++p;
       ++k;
+      if (k > 12) return YMI_EFORMAT;                           // before the shift below: 5 * 13 = 65 bits would be undefined
       if (!more && (c & 0x10)) x |= (long)(~0UL << (5 * k));   // sign extension (maskApi.c: x |= -1 << 5*k)
-      if (k > 12) return YMI_EFORMAT;
     }
     if (cnts.size() > 2) x += (long)cnts[cnts.size() - 2];
     if (x < 0) return YMI_EFORMAT;

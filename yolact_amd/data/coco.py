@@ -170,7 +170,9 @@ class COCODetection(torch.utils.data.Dataset):
 
         masks = target = None
         if anns:
-            masks = np.stack([ann_to_mask(a, height, width) for a in anns])
+            # data/coco.py:146-148: annToMask rasterises at the JSON's (height, width); the flat masks are then reshaped to
+            # the DECODED size (they differ only for EXIF-rotated files: the reference carries on, and so does this)
+            masks = np.vstack([self.coco.annToMask(a).reshape(-1) for a in anns]).reshape(-1, height, width)
             target = np.array(self.target_transform(anns, width, height))
 
         if self.transform is not None:

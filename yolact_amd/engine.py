@@ -709,18 +709,32 @@ class Plan:
         sb = C.c_void_p(self.stream_b.cuda_stream) if two else sa
         proto = torch.empty(self.proto_shape, dtype=torch.float32, device=self.device)
         self.proto_patch.seg[0].ptr = proto.data_ptr()
+        # only a module with the reference's timer API (utils/timer.py: start / stop / env) is driven
+        if timer is not None and not all(hasattr(timer, a) for a in ('start', 'stop', 'env')):
+            timer = None
+        self._sec = None
+        try:
+            det = self._dispatch(x, cur, sa, sb, two, detect, timer)
+        finally:
+            if timer is not None and self._sec is not None:   # a failed launch must not leave a reference timer running
+                timer.stop(self._sec)
+        self.mark_done()
+        return proto, det
+
+    def _dispatch(self, x, cur, sa, sb, two, detect, timer):
+        """The flat op loop of run(): C-ABI launches on the two streams, event records / waits, the Detect callback."""
+        lib = self.lib
         det = None
-        sec = None
         for (fn, args, name, where), nsec in zip(self.ops, self.sections):
             s = sb if where == 'B' else sa
-            if timer is not None and nsec is not None and nsec != sec:
-                if sec is not None:
-                    timer.stop(sec)
+            if timer is not None and nsec is not None and nsec != self._sec:
+                if self._sec is not None:
+                    timer.stop(self._sec)
                 timer.start(nsec)
+                self._sec = nsec
                 if nsec == 'pred_heads' and not self._priors_timed:
                     with timer.env('makepriors'):       # yolact.py:219: priors are host constants of the plan, built once
                         self._priors_timed = True
-                sec = nsec
             if fn == 'input':
                 a = self.in_args
                 rc = lib.ymi_nchw_to_nhwc4_f32(x.data_ptr(), a[1], a[2], a[3], a[4], a[5], s)
@@ -742,10 +756,7 @@ class Plan:
                 rc = fn(args, s)
             if rc != 0:
                 L.check(rc, name)
-        if timer is not None and sec is not None:
-            timer.stop(sec)
-        self.mark_done()
-        return proto, det
+        return det
 
     # ---- tile / algorithm selection ------------------------------------------------------------------
     def tune(self, x: torch.Tensor, reps: int = 3):

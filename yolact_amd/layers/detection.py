@@ -10,7 +10,9 @@ from __future__ import annotations
 import ctypes as C
 import sys
 import contextlib
+import os
 import threading
+import warnings
 
 import torch
 
@@ -24,6 +26,8 @@ def _timer_env(name):
 
 
 class Detect(object):
+    _warned_traditional = False
+
     def __init__(self, num_classes, bkg_label, top_k, conf_thresh, nms_thresh):
         self.num_classes = num_classes
         self.background_label = bkg_label
@@ -79,13 +83,20 @@ class Detect(object):
         return self._launch(loc, conf, mask, priors, conf_is_logits, stream, ws, B, P, Ccls, D, dev, max_det, cap, conf_ld)
 
     def _require_fast_nms(self):
-        if not self.use_fast_nms:
-            # detection.py:101-106: the reference would run traditional_nms (per-class greedy NMS in Cython on the
-            # CPU, utils/cython_nms.pyx) here.  That path is outside the hot path (non-default in eval.py,
-            # a CPU round trip per class); raising keeps the semantics honest instead of silently running Fast NMS.
-            raise NotImplementedError(
-                'Detect.use_fast_nms is False (the reference default): traditional Cython/CPU NMS is not part of the '
-                'MI355X hot path.  Set net.detect.use_fast_nms = True, as eval.py:871 does for its default --fast_nms.')
+        """detection.py:101-106: with use_fast_nms False (the reference's constructor default) the reference runs
+        traditional_nms — per-class greedy NMS in Cython on the CPU (utils/cython_nms.pyx), outside the hot path (SURVEY 2:
+        non-default in eval.py, a CPU round trip per class).  A plain `Yolact()(x)` must still work, so the engine runs
+        Fast NMS — what eval.py:871 selects through its default --fast_nms=True — and says so ONCE, loudly;
+        YOLACT_AMD_STRICT_NMS=1 turns the warning into NotImplementedError for callers that must not differ."""
+        if self.use_fast_nms:
+            return
+        msg = ('Detect.use_fast_nms is False (the reference default): traditional Cython/CPU NMS is not part of the MI355X '
+               'hot path; running Fast NMS instead (eval.py:871 sets use_fast_nms = True for its default --fast_nms).')
+        if os.environ.get('YOLACT_AMD_STRICT_NMS', '0') == '1':
+            raise NotImplementedError(msg)
+        if not Detect._warned_traditional:
+            Detect._warned_traditional = True
+            warnings.warn(msg, UserWarning, stacklevel=3)
 
     def _launch(self, loc, conf, mask, priors, conf_is_logits, stream, ws, B, P, Ccls, D, dev, max_det, cap, conf_ld=0):
         out = dict(count=torch.empty(B, dtype=torch.int32, device=dev), box=torch.empty(B, cap, 4, device=dev),

@@ -238,24 +238,32 @@ class Yolact(nn.Module):
         static input and static outputs; every call copies x in and clones the results out, so returned tensors keep
         the eager path's lifetime rules."""
         key = ('graph', tuple(x.shape), x.device, slot)
-        rec = self._plans.get(key)
-        if rec is None:
-            def body(inp):
-                proto, out = plan.run(inp, detect=lambda s: self.detect.run_device(
-                    plan.loc, plan.conf, plan.coef, plan.priors, True, stream=s, slot=slot, conf_ld=plan.conf_ld))
-                out['proto'] = proto
-                return out
-            static_x = x.clone()
-            body(static_x)                                   # eager warm-up: workspaces, lazy module state
-            torch.cuda.synchronize(x.device)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                static_out = body(static_x)
-            rec = self._plans[key] = (graph, static_x, static_out)
-        graph, static_x, static_out = rec
-        static_x.copy_(x)
-        graph.replay()
-        return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in static_out.items()}
+        # capture and replay touch the plan's shared arena / head buffers exactly like an eager run: same host lock, and
+        # the device-side ordering against the previous run (possibly on another stream) through the plan's done-event
+        with self._run_lock:
+            rec = self._plans.get(key)
+            cur = torch.cuda.current_stream(x.device)
+            if plan._done_event is not None:
+                cur.wait_event(plan._done_event)
+            if rec is None:
+                def body(inp):
+                    proto, out = plan.run(inp, detect=lambda s: self.detect.run_device(
+                        plan.loc, plan.conf, plan.coef, plan.priors, True, stream=s, slot=slot, conf_ld=plan.conf_ld))
+                    out['proto'] = proto
+                    return out
+                static_x = x.clone()
+                body(static_x)                                   # eager warm-up: workspaces, lazy module state
+                torch.cuda.synchronize(x.device)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    static_out = body(static_x)
+                rec = self._plans[key] = (graph, static_x, static_out)
+            graph, static_x, static_out = rec
+            static_x.copy_(x)
+            graph.replay()
+            res = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in static_out.items()}
+            plan.mark_done()                                     # the clones read the graph's static outputs
+            return res
 
     def forward_device(self, x):
         """Forward + Detect with NO host synchronisation: fixed-capacity device tensors
