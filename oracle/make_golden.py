@@ -84,10 +84,16 @@ CASES = [
     ('darknet53', 'yolact_darknet53_config', 1, 550, 4, 0.04, (80, 60)),
     ('im700', 'yolact_im700_config', 1, 700, 5, 0.04, (80, 60)),
     ('plus_r50', 'yolact_plus_resnet50_config', 1, 550, 6, 0.04, (80, 60)),
+    # cross-class Fast NMS (detection.py:111-135; eval.py --cross_class_nms): the reference's own cc_fast_nms output
+    ('r50_cc', 'yolact_resnet50_config', 2, 550, 7, 0.04, (80, 60), dict(cross_class=True)),
+    # the "pretrained-like" sparse regime of SURVEY 8(d): ~1 % of the priors over the candidate threshold, a handful of
+    # confident detections; postprocess runs with the display threshold (eval.py --score_threshold 0.15)
+    ('r50_few', 'yolact_resnet50_config', 2, 550, 8, 0.2, (160, 120), dict(bg_bias=19.5, score_threshold=0.15)),
 ]
 
 
-def run_case(name, config, B, size, seed, gain, post, outdir):
+def run_case(name, config, B, size, seed, gain, post, outdir, extra=None):
+    extra = extra or {}
     from data import cfg, set_cfg
     set_cfg(config)
     cfg.mask_proto_debug = False
@@ -97,8 +103,9 @@ def run_case(name, config, B, size, seed, gain, post, outdir):
     net = Yolact()
     net.eval()          # the reference's train() override returns None, so no chaining
     net.detect.use_fast_nms = True
+    net.detect.use_cross_class_nms = bool(extra.get('cross_class', False))      # eval.py:872
     shapes = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
-    sd = synth_state_dict(shapes, seed=seed, conf_gain=gain)
+    sd = synth_state_dict(shapes, seed=seed, conf_gain=gain, bg_bias=extra.get('bg_bias', 0.0))
     net.load_state_dict(sd)
     x = synth_images(B, size, size, seed=1000 + seed)
     rec = {}
@@ -128,7 +135,8 @@ def run_case(name, config, B, size, seed, gain, post, outdir):
             rec[k] = digest(captured[k])
     arrays = {}
     meta = dict(name=name, config=config, B=B, size=size, seed=seed, conf_gain=gain, post=list(post),
-                keys=[[k, list(s)] for k, s in shapes], n=[], torch=torch.__version__)
+                keys=[[k, list(s)] for k, s in shapes], n=[], torch=torch.__version__, **extra)
+    meta['n_post'] = []
     for k, d in rec.items():
         arrays['dg_%s_idx' % k] = d['idx']
         arrays['dg_%s_val' % k] = d['val']
@@ -138,13 +146,17 @@ def run_case(name, config, B, size, seed, gain, post, outdir):
         det = d['detection']
         if det is None:
             meta['n'].append(0)
+            meta['n_post'].append(0)
             continue
         meta['n'].append(int(det['score'].shape[0]))
         for k in ('box', 'mask', 'class', 'score'):
             arrays['det%d_%s' % (b, k)] = det[k].numpy()
         with torch.no_grad():
             det_copy = [{'detection': {k: (v.clone() if torch.is_tensor(v) else v) for k, v in det.items()}, 'net': net}]
-            classes, scores, boxes, masks = postprocess(det_copy, w, h)
+            classes, scores, boxes, masks = postprocess(det_copy, w, h, score_threshold=extra.get('score_threshold', 0))
+        meta['n_post'].append(int(classes.shape[0]))
+        if classes.shape[0] == 0:
+            continue
         arrays['post%d_class' % b] = classes.numpy()
         if isinstance(scores, list):
             arrays['post%d_score' % b] = scores[0].numpy()
@@ -167,7 +179,7 @@ def main():
     for c in CASES:
         if only and c[0] not in only:
             continue
-        run_case(*c, outdir)
+        run_case(*c[:7], outdir, c[7] if len(c) > 7 else None)
 
 
 if __name__ == '__main__':

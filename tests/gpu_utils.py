@@ -76,6 +76,7 @@ def build_net(meta, device=DEV):
     net = Yolact()
     net.load_state_dict_compat(case_state_dict(meta))
     net.detect.use_fast_nms = True          # what eval.py:871 does (the class default is the reference's False)
+    net.detect.use_cross_class_nms = bool(meta.get('cross_class', False))     # eval.py:872 (--cross_class_nms)
     return net.to(device)
 
 

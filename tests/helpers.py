@@ -12,7 +12,7 @@ from yolact_amd.config import CONFIGS
 from yolact_amd.utils.synth import synth_images, synth_state_dict
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-ALL_CASES = ['r50_dense', 'r50_sparse', 'r50_empty', 'r101_base', 'darknet53', 'im700', 'plus_r50']
+ALL_CASES = ['r50_dense', 'r50_sparse', 'r50_empty', 'r101_base', 'darknet53', 'im700', 'plus_r50', 'r50_cc', 'r50_few']
 
 
 @functools.lru_cache(maxsize=None)
@@ -29,7 +29,7 @@ def case_cfg(meta):
 
 def case_state_dict(meta):
     shapes = [(k, tuple(s)) for k, s in meta['keys']]
-    return synth_state_dict(shapes, seed=meta['seed'], conf_gain=meta['conf_gain'])
+    return synth_state_dict(shapes, seed=meta['seed'], conf_gain=meta['conf_gain'], bg_bias=meta.get('bg_bias', 0.0))
 
 
 def case_images(meta):
@@ -45,7 +45,7 @@ def oracle_run(name):
     sd = case_state_dict(meta)
     with torch.no_grad():
         raw = O.forward_raw(case_images(meta), sd, cfg)
-        dets = O.detect(raw, cfg)
+        dets = O.detect(raw, cfg, cross_class=bool(meta.get('cross_class', False)))
     return meta, arrays, cfg, sd, raw, dets
 
 

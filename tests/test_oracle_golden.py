@@ -33,11 +33,14 @@ def test_postprocess_matches_reference(name):
     from oracle import yolact_oracle as O
     meta, arrays, cfg, sd, raw, dets = oracle_run(name)
     w, h = meta['post']
+    thr = meta.get('score_threshold', 0.0)          # r50_few: the display threshold (output_utils.py:42-50)
     for b in range(meta['B']):
-        if meta['n'][b] == 0:
-            assert O.postprocess(dets[b], w, h, cfg, sd) is None
+        n_post = meta.get('n_post', meta['n'])[b]
+        if n_post == 0:
+            assert O.postprocess(dets[b], w, h, cfg, sd, score_threshold=thr) is None
             continue
-        classes, scores, boxes, masks, soft = O.postprocess(dets[b], w, h, cfg, sd, return_soft=True)
+        classes, scores, boxes, masks, soft = O.postprocess(dets[b], w, h, cfg, sd, score_threshold=thr, return_soft=True)
+        assert classes.shape[0] == n_post
         assert torch.equal(classes, torch.from_numpy(arrays['post%d_class' % b]))
         assert torch.equal(boxes, torch.from_numpy(arrays['post%d_box' % b]))
         if isinstance(scores, list):
@@ -45,8 +48,30 @@ def test_postprocess_matches_reference(name):
             assert torch.allclose(scores[1], torch.from_numpy(arrays['post%d_score2' % b]), atol=1e-5)
         else:
             assert torch.allclose(scores, torch.from_numpy(arrays['post%d_score' % b]), atol=1e-6)
-        ref = unpack_masks(arrays, b, meta['n'][b], h, w)
+        ref = unpack_masks(arrays, b, n_post, h, w)
         bad = (masks != ref)
         # a binarised pixel may only flip where the soft value sits on the 0.5 threshold
         assert (soft[bad] - 0.5).abs().max().item() < 1e-5 if bad.any() else True
         assert bad.float().mean().item() < 1e-5
+
+
+def test_sparse_case_is_sparse():
+    """r50_few is the 'pretrained-like' regime SURVEY 8(d) asks for: ~1 % of the priors pass the candidate threshold and only
+    a handful of detections clear the display threshold (the reference's own postprocess count is in the fixture)."""
+    meta, arrays, cfg, sd, raw, dets = oracle_run('r50_few')
+    for b in range(meta['B']):
+        k = int((raw['conf'][b][:, 1:].max(1)[0] > cfg.nms_conf_thresh).sum())
+        assert 0.003 * raw['conf'].shape[1] < k < 0.02 * raw['conf'].shape[1], k
+        assert 1 <= meta['n_post'][b] <= 20, meta['n_post']
+        assert int((dets[b]['score'] > meta['score_threshold']).sum()) == meta['n_post'][b]
+
+
+def test_cross_class_case_is_the_references_cc_fast_nms():
+    """r50_cc was produced by the reference with detect.use_cross_class_nms = True (eval.py:872): more than max_num_detections
+    rows come back (cc_fast_nms does not truncate beyond top_k, detection.py:111-135) and the class column is not sorted by
+    class-major order."""
+    meta, arrays, cfg, sd, raw, dets = oracle_run('r50_cc')
+    assert meta['cross_class'] is True
+    for b in range(meta['B']):
+        assert cfg.max_num_detections < meta['n'][b] <= cfg.nms_top_k
+        assert dets[b]['score'].shape[0] == meta['n'][b]

@@ -21,7 +21,10 @@ def _gen(key: str, seed: int) -> torch.Generator:
 
 
 def synth_state_dict(shapes: Iterable[Tuple[str, Tuple[int, ...]]], seed: int = 0, conf_gain: float = 0.04,
-                     ) -> Dict[str, torch.Tensor]:
+                     bg_bias: float = 0.0) -> Dict[str, torch.Tensor]:
+    """`bg_bias` is added to the background logit's bias of every anchor (conf_layer.bias[a * C + 0]): with a large gain it
+    gives the "pretrained-like" sparse regime of SURVEY 8(d) — about 1 % of the priors over the 0.05 candidate threshold and a
+    handful of confident, well separated detections."""
     shapes = [(k, tuple(s)) for k, s in shapes]
     keys = {k for k, _ in shapes}
     out = {}
@@ -59,6 +62,9 @@ def synth_state_dict(shapes: Iterable[Tuple[str, Tuple[int, ...]]], seed: int = 
         elif len(shp) == 1:
             std = 0.3 if 'conv_offset_mask' in k else 0.02
             out[k] = torch.randn(shp, generator=g) * std
+            if bg_bias and k.endswith('conf_layer.bias'):
+                ncls = 81 if shp[0] % 81 == 0 else shp[0]
+                out[k][0::ncls] += bg_bias
         else:
             out[k] = torch.randn(shp, generator=g) * 0.02
     return out
