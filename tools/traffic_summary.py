@@ -50,7 +50,7 @@ def collect(root, counter):
             if not m:
                 continue
             v = tuple(int(x) for x in m.groups())
-            tile = TILES.get(v[:6], str(v[:6])) + ('x3' if v[7] else '')
+            tile = TILES.get(v[:6], str(v[:6])) + ('x3' if v[7] in (1, 2) else 'h2' if v[7] >= 3 else '')
             key = ('conv_igemm_f32<%s,winograd grouped GEMM>' % tile) if (v[6] == 3 and r['Dispatch_Id'] in grouped) else \
                 'conv_igemm_f32<%s,loader%d>' % (tile, v[6])
             a = acc[key]
@@ -67,6 +67,10 @@ def main(fdir, wdir):
         out[k] = {'hbm_read_bytes_per_launch': round(f), 'hbm_write_bytes_per_launch': round(w),
                   'bytes_per_launch': round(f + w), 'launches_sampled': fe[k][1],
                   'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2'}
+    # bench.py reports these figures only while it runs the tile table they were measured with
+    import hashlib
+    tp = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'yolact_amd', 'tune', 'gfx950.json')
+    out['tune_sha'] = hashlib.sha256(open(tp, 'rb').read()).hexdigest()[:16] if os.path.exists(tp) else None
     json.dump(out, sys.stdout, indent=1)
 
 
