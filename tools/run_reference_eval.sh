@@ -6,9 +6,10 @@
 O=$1; N=${2:-24}
 export GPU_MAX_HW_QUEUES=8
 PY="python tools/run_reference_eval.py --out $O --images $N"
-$PY --who reference --mode gt        || { echo "reference on GPU failed: falling back to the reference on the host CPU"; REFCPU="--cuda 0"; $PY --who reference --mode gt $REFCPU; }
-$PY --who reference --mode map $REFCPU
-$PY --who reference --mode benchmark $REFCPU
+export MIOPEN_FIND_MODE=FAST MIOPEN_USER_DB_PATH=/tmp/miopen_db MIOPEN_CUSTOM_CACHE_DIR=/tmp/miopen_cache
+timeout 420 $PY --who reference --mode gt || { echo "reference on GPU failed or too slow: falling back to the reference on the host CPU"; REFCPU="--cuda 0"; timeout 600 $PY --who reference --mode gt $REFCPU; }
+timeout 600 $PY --who reference --mode map $REFCPU
+timeout 600 $PY --who reference --mode benchmark $REFCPU
 $PY --who engine --mode map
 $PY --who engine --mode benchmark
 $PY --who engine --mode coco

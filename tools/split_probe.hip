@@ -9,6 +9,12 @@
 //   MODE 1  A and B split on the fly after the ds_read (no change to the LDS image / the LDS-DMA staging)
 //   MODE 2  A split on the fly, B (weights) pre-split on the host into three bf16 planes in LDS
 //   MODE 3  both pre-split (upper bound: no VALU at all; would need producers to write split activations)
+//   MODE 4  "fp16x2": x*s = h + l, two fp16 pieces by round-to-nearest (11 + 11 significant bits + signs: 3/4 of all fp32
+//           values exactly, the rest off by one fp32 ulp), s = a power-of-two scale that maps the tensor's amax below
+//           65504; 3 of the 4 piece products (hl, lh, hh) on v_mfma_f32_32x32x16_f16, fp32 accumulate, ONE accumulator;
+//           the dropped l*l term is <= 2^-22 |a b|.  A split on the fly (3 VALU per element, no v_perm), B pre-split
+//           into two fp16 planes in LDS (same bytes as the fp32 tile)
+//   MODE 5  fp16x2, both operands pre-split (no VALU in the loop)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -20,6 +26,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
@@ -51,6 +58,22 @@ __device__ __forceinline__ Split3 split8(const f32x4 x0, const f32x4 x1) {
   return s;
 }
 
+struct Split2 { f16x8 h, l; };
+
+// 8 fp32 -> two fp16x8 by round-to-nearest: t = x * s (exact), h = f16(t), l = f16(t - h)  (t - h is exact in fp32)
+__device__ __forceinline__ Split2 split8h(const f32x4 x0, const f32x4 x1, const float s) {
+  const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+  Split2 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float t = x[e] * s;
+    const _Float16 h = (_Float16)t;
+    o.h[e] = h;
+    o.l[e] = (_Float16)(t - (float)h);
+  }
+  return o;
+}
+
 __device__ __forceinline__ f32x16 mma6(const Split3 &a, const Split3 &b, f32x16 c) {
   // small terms first, the dominant product last
   c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, c, 0, 0, 0);
@@ -68,11 +91,11 @@ __device__ __forceinline__ f32x16 mma6(const Split3 &a, const Split3 &b, f32x16 
 template <int MODE, int TM, int TN, int ORDER>
 __global__ __launch_bounds__(256) void probe_k(const float *__restrict__ A, const float *__restrict__ B,
                                                const unsigned short *__restrict__ Ap, const unsigned short *__restrict__ Bp,
-                                               float *__restrict__ Cout, int iters, int write_c) {
+                                               float *__restrict__ Cout, int iters, int write_c, float sA = 1.f, float sB = 1.f) {
   constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
   __shared__ __attribute__((aligned(16))) float As[BM * BK];
   __shared__ __attribute__((aligned(16))) float Bs[BN * BK];
-  __shared__ __attribute__((aligned(16))) unsigned short Aps[(MODE == 3) ? 3 * BM * BK : 8];
+  __shared__ __attribute__((aligned(16))) unsigned short Aps[(MODE == 3 || MODE == 5) ? 3 * BM * BK : 8];
   __shared__ __attribute__((aligned(16))) unsigned short Bps[(MODE >= 2) ? 3 * BN * BK : 8];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
   for (int i = t; i < BM * 8; i += 256) {                       // 16-byte slots
@@ -83,7 +106,7 @@ __global__ __launch_bounds__(256) void probe_k(const float *__restrict__ A, cons
     const int row = i >> 3, sl = i & 7;
     *reinterpret_cast<f32x4 *>(Bs + row * BK + 4 * (sl ^ ((row >> 1) & 7))) = *reinterpret_cast<const f32x4 *>(B + row * BK + 4 * sl);
   }
-  if (MODE == 3)
+  if (MODE == 3 || MODE == 5)
     for (int i = t; i < 3 * BM * 4; i += 256) {
       const int p = i / (BM * 4), rem = i - p * BM * 4, row = rem >> 2, sl = rem & 3;
       *reinterpret_cast<u32x4 *>(Aps + (p * BM + row) * BK + 8 * (sl ^ ((row >> 2) & 3))) =
@@ -125,6 +148,42 @@ __global__ __launch_bounds__(256) void probe_k(const float *__restrict__ A, cons
 #pragma unroll
             for (int j = 0; j < TN; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+      }
+    } else if (MODE >= 4) {
+      const int fsw = (l31 >> 1) & 7, psw = (l31 >> 2) & 3;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        Split2 a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int row = (wm * TM + i) * 32 + l31;
+          if (MODE == 5) {
+            const int o = row * BK + 8 * ((2 * s + hh) ^ psw);
+            a[i].h = *reinterpret_cast<const f16x8 *>(Aps + 0 * BM * BK + o);
+            a[i].l = *reinterpret_cast<const f16x8 *>(Aps + 1 * BM * BK + o);
+          } else {
+            const float *p = As + row * BK;
+            a[i] = split8h(*reinterpret_cast<const f32x4 *>(p + 4 * ((4 * s + 2 * hh) ^ fsw)),
+                           *reinterpret_cast<const f32x4 *>(p + 4 * ((4 * s + 2 * hh + 1) ^ fsw)), sA);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int row = (wn * TN + j) * 32 + l31;
+          const int o = row * BK + 8 * ((2 * s + hh) ^ psw);
+          b[j].h = *reinterpret_cast<const f16x8 *>(Bps + 0 * BN * BK + o);
+          b[j].l = *reinterpret_cast<const f16x8 *>(Bps + 1 * BN * BK + o);
+        }
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              const f16x8 fa_ = pr == 0 ? a[i].h : pr == 1 ? a[i].l : a[i].h;
+              const f16x8 fb_ = pr == 0 ? b[j].l : pr == 1 ? b[j].h : b[j].h;
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_, fb_, acc[i][j], 0, 0, 0);
+            }
       }
     } else {
       const int fsw = (l31 >> 1) & 7, psw = (l31 >> 2) & 3;
@@ -187,7 +246,7 @@ __global__ __launch_bounds__(256) void probe_k(const float *__restrict__ A, cons
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh, n = (wn * TN + j) * 32 + l31;
-          Cout[(size_t)blockIdx.x * BM * BN + m * BN + n] = acc[i][j][r];
+          Cout[(size_t)blockIdx.x * BM * BN + m * BN + n] = (MODE >= 4) ? acc[i][j][r] * (1.f / (sA * sB)) : acc[i][j][r];
         }
   } else {
     float sum = 0.f;
@@ -216,6 +275,22 @@ static void make_planes(const std::vector<float> &X, int rows, std::vector<unsig
   }
 }
 
+static float pow2_scale(const std::vector<float> &X) {     // largest power of two s with amax * s <= 32768 (< 65504)
+  float amax = 0.f;
+  for (float v : X) amax = fmaxf(amax, fabsf(v));
+  int e; frexpf(amax, &e);                                   // amax = m * 2^e, 0.5 <= m < 1
+  return ldexpf(1.f, 15 - e);
+}
+static void make_planes_f16(const std::vector<float> &X, int rows, float s, std::vector<unsigned short> &P) {
+  P.assign((size_t)3 * rows * BK, 0);
+  for (int i = 0; i < rows * BK; ++i) {
+    const float t = X[i] * s;
+    const _Float16 h = (_Float16)t;
+    const _Float16 l = (_Float16)(t - (float)h);
+    memcpy(&P[i], &h, 2); memcpy(&P[(size_t)rows * BK + i], &l, 2);
+  }
+}
+
 template <int MODE, int TM, int TN, int ORDER = 0>
 void run(const char *name, int cus, bool first) {
   constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
@@ -227,7 +302,9 @@ void run(const char *name, int cus, bool first) {
   // a few tiny / large magnitudes to exercise the exponent range of the pieces
   if (!zeros) { A[3] = 1e-20f; A[40] = 3.0e4f; B[5] = -2.5e-12f; B[77] = 17.f; }
   std::vector<unsigned short> Ap, Bp;
-  make_planes(A, BM, Ap); make_planes(B, BN, Bp);
+  float sA = 1.f, sB = 1.f;
+  if (MODE >= 4) { sA = pow2_scale(A); sB = pow2_scale(B); make_planes_f16(A, BM, sA, Ap); make_planes_f16(B, BN, sB, Bp); }
+  else { make_planes(A, BM, Ap); make_planes(B, BN, Bp); }
   float *dA, *dB, *dC; unsigned short *dAp, *dBp;
   const int max_blocks = cus * 4;
   CK(hipMalloc(&dA, A.size() * 4)); CK(hipMalloc(&dB, B.size() * 4)); CK(hipMalloc(&dC, (size_t)max_blocks * BM * BN * 4));
@@ -235,7 +312,7 @@ void run(const char *name, int cus, bool first) {
   CK(hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(dAp, Ap.data(), Ap.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dBp, Bp.data(), Bp.size() * 2, hipMemcpyHostToDevice));
   // numerics: one K chunk, compare with fp64
-  hipLaunchKernelGGL((probe_k<MODE, TM, TN, ORDER>), dim3(1), dim3(256), 0, 0, dA, dB, dAp, dBp, dC, 1, 1);
+  hipLaunchKernelGGL((probe_k<MODE, TM, TN, ORDER>), dim3(1), dim3(256), 0, 0, dA, dB, dAp, dBp, dC, 1, 1, sA, sB);
   CK(hipDeviceSynchronize());
   std::vector<float> C(BM * BN);
   CK(hipMemcpy(C.data(), dC, C.size() * 4, hipMemcpyDeviceToHost));
@@ -252,10 +329,10 @@ void run(const char *name, int cus, bool first) {
   const int iters = 4000;
   for (int bpc = 1; bpc <= 3; ++bpc) {
     const int blocks = cus * bpc;
-    hipLaunchKernelGGL((probe_k<MODE, TM, TN, ORDER>), dim3(blocks), dim3(256), 0, 0, dA, dB, dAp, dBp, dC, 200, 0);
+    hipLaunchKernelGGL((probe_k<MODE, TM, TN, ORDER>), dim3(blocks), dim3(256), 0, 0, dA, dB, dAp, dBp, dC, 200, 0, sA, sB);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL((probe_k<MODE, TM, TN, ORDER>), dim3(blocks), dim3(256), 0, 0, dA, dB, dAp, dBp, dC, iters, 0);
+    hipLaunchKernelGGL((probe_k<MODE, TM, TN, ORDER>), dim3(blocks), dim3(256), 0, 0, dA, dB, dAp, dBp, dC, iters, 0, sA, sB);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double fl = 2.0 * BM * BN * BK * (double)iters * blocks;     // fp32-equivalent FLOPs
@@ -280,6 +357,11 @@ int main() {
   run<1, 2, 2, 1>("bf16x3_fly_128x128_prodmajor", cus, false);
   run<1, 1, 2, 1>("bf16x3_fly_64x128_prodmajor", cus, false);
   run<3, 2, 2, 1>("bf16x3_ABplanes_128x128_prodmajor", cus, false);
+  run<4, 2, 2>("fp16x2_Bplanes_128x128", cus, false);
+  run<4, 1, 2>("fp16x2_Bplanes_64x128", cus, false);
+  run<4, 1, 1>("fp16x2_Bplanes_64x64", cus, false);
+  run<5, 2, 2>("fp16x2_ABplanes_128x128", cus, false);
+  run<5, 1, 2>("fp16x2_ABplanes_64x128", cus, false);
   printf("}\n");
   return 0;
 }

@@ -41,12 +41,11 @@ int ymi_coco_poly_fill_u8(const double *xy, int k, int h, int w, uint8_t *mask) 
   if (!xy || !mask) return YMI_ENULL;
   if (k < 1 || h <= 0 || w <= 0 || (long)h * w > (1L << 31) - 1) return YMI_EARG;
   // maskApi.c scales by 5 into int: coordinates that cannot be image coordinates (or NaN) are an argument error here
-  // (and bounds the boundary walk below: an edge contributes <= 5 * 3 * max(w, h) points, so a hostile polygon cannot ask
-  // for gigabytes — pycocotools itself has no such guard)
-  for (int j = 0; j < k; ++j) {
-    const double px = xy[2 * j], py = xy[2 * j + 1];
-    if (!(px >= -(double)w && px <= 2.0 * w && py >= -(double)h && py <= 2.0 * h)) return YMI_EARG;
-  }
+  // (and bounds the boundary walk below: with |coordinate| <= 3 * max(w, h) + 1024 an edge contributes at most
+  // 5 * (6 * max(w, h) + 2048) points, so memory stays proportional to the input — coordinates up to 1e5 used to let one
+  // hostile polygon ask for gigabytes; pycocotools itself has no such guard)
+  const double lim = 3.0 * (w > h ? w : h) + 1024.0;
+  for (int j = 0; j < 2 * k; ++j) if (!(std::fabs(xy[j]) <= lim)) return YMI_EARG;
   const double scale = 5;
   std::vector<int> x(k + 1), y(k + 1);
   for (int j = 0; j < k; ++j) x[j] = (int)(scale * xy[j * 2 + 0] + .5);
