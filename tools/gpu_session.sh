@@ -21,7 +21,8 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
 BENCH="python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary"
 for st in "$@"; do
-  arg="${st#*:}"; [ "$arg" = "$st" ] && arg=""; arg="${arg//_/ }"
+  arg="${st#*:}"; [ "$arg" = "$st" ] && arg=""
+  case "${st%%:*}" in pytestf|py) ;; *) arg="${arg//_/ }" ;; esac      # (_ stands for a space except in file names)
   case "${st%%:*}" in
     build) make -C yolact_amd/csrc -j16 > $O/build.log 2>&1; tail -2 $O/build.log ;;
     tune) timeout 1500 python tools/make_tune_table.py --fresh --copy-to $O/gfx950.json > $O/tune.log 2>&1; grep -E "plan|table" $O/tune.log | cut -c1-160 | tail -14 ;;

@@ -158,6 +158,7 @@ def main():
             torch.set_default_tensor_type('torch.cuda.FloatTensor')
         else:
             torch.set_default_tensor_type('torch.FloatTensor')
+            torch.set_num_threads(min(16, torch.get_num_threads()))      # one thread per logical CPU oversubscribes big hosts
         net = E.Yolact()
         sd = synth_state_dict([(k, tuple(v.shape)) for k, v in net.state_dict().items()], seed=a.seed, conf_gain=a.conf_gain)
         net.load_state_dict(sd)                      # stands in for net.load_weights(args.trained_model) (eval.py:1097)

@@ -25,31 +25,33 @@ def synth_state_dict(shapes: Iterable[Tuple[str, Tuple[int, ...]]], seed: int = 
     """`bg_bias` is added to the background logit's bias of every anchor (conf_layer.bias[a * C + 0]): with a large gain it
     gives the "pretrained-like" sparse regime of SURVEY 8(d) — about 1 % of the priors over the 0.05 candidate threshold and a
     handful of confident, well separated detections."""
+    # every factory call names device='cpu': eval.py / train.py run under torch.set_default_tensor_type('torch.cuda.FloatTensor')
+    # (eval.py:1077-1081), where a device-less torch.rand(generator=<cpu generator>) raises
     shapes = [(k, tuple(s)) for k, s in shapes]
     keys = {k for k, _ in shapes}
     out = {}
     for k, shp in shapes:
         g = _gen(k, seed)
         if k.endswith('num_batches_tracked'):
-            out[k] = torch.zeros(shp, dtype=torch.long)
+            out[k] = torch.zeros(shp, dtype=torch.long, device='cpu')
         elif k.endswith('running_var'):
-            out[k] = torch.rand(shp, generator=g) + 0.5
+            out[k] = torch.rand(shp, generator=g, device='cpu') + 0.5
         elif k.endswith('running_mean'):
-            out[k] = torch.randn(shp, generator=g) * 0.1
+            out[k] = torch.randn(shp, generator=g, device='cpu') * 0.1
         elif len(shp) == 1 and k.endswith('.weight') and (k[:-len('weight')] + 'running_mean') in keys:
             if k.endswith('bn3.weight') or k.endswith('conv2.1.weight'):
                 # last BN of a residual branch: small gamma keeps activations O(1) through 16-33 blocks
-                out[k] = torch.rand(shp, generator=g) * 0.2 + 0.1
+                out[k] = torch.rand(shp, generator=g, device='cpu') * 0.2 + 0.1
             else:
-                out[k] = torch.rand(shp, generator=g) + 0.5      # BN gamma
+                out[k] = torch.rand(shp, generator=g, device='cpu') + 0.5      # BN gamma
         elif len(shp) == 1 and k.endswith('.bias') and (k[:-len('bias')] + 'running_mean') in keys:
-            out[k] = torch.randn(shp, generator=g) * 0.1          # BN beta
+            out[k] = torch.randn(shp, generator=g, device='cpu') * 0.1          # BN beta
         elif len(shp) == 4:
             fan_in = shp[1] * shp[2] * shp[3]
             bound = (6.0 / fan_in) ** 0.5
-            w = (torch.rand(shp, generator=g) * 2 - 1) * bound
+            w = (torch.rand(shp, generator=g, device='cpu') * 2 - 1) * bound
             if 'conv_offset_mask' in k:
-                w = torch.randn(shp, generator=g) * 0.02
+                w = torch.randn(shp, generator=g, device='cpu') * 0.02
             if 'conf_layer' in k:
                 w = w * conf_gain
             elif 'bbox_layer' in k:
@@ -61,12 +63,12 @@ def synth_state_dict(shapes: Iterable[Tuple[str, Tuple[int, ...]]], seed: int = 
             out[k] = w
         elif len(shp) == 1:
             std = 0.3 if 'conv_offset_mask' in k else 0.02
-            out[k] = torch.randn(shp, generator=g) * std
+            out[k] = torch.randn(shp, generator=g, device='cpu') * std
             if bg_bias and k.endswith('conf_layer.bias'):
                 ncls = 81 if shp[0] % 81 == 0 else shp[0]
                 out[k][0::ncls] += bg_bias
         else:
-            out[k] = torch.randn(shp, generator=g) * 0.02
+            out[k] = torch.randn(shp, generator=g, device='cpu') * 0.02
     return out
 
 
@@ -74,4 +76,4 @@ def synth_images(B: int, H: int, W: int, seed: int = 1234) -> torch.Tensor:
     """Zero-mean unit-variance RGB planes = the post-BaseTransform distribution."""
     g = torch.Generator(device='cpu')
     g.manual_seed(int(seed))
-    return torch.randn(B, 3, H, W, generator=g)
+    return torch.randn(B, 3, H, W, generator=g, device='cpu')
