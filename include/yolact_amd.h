@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define YMI_ABI_VERSION 2
+#define YMI_ABI_VERSION 3
 
 /* negative return codes (ymi_strerror) */
 #define YMI_EFORMAT (-4)       /* corrupt or truncated input stream (ymi_jpeg_*) */
@@ -46,7 +46,8 @@ typedef struct {
  *   backbone.py:37-57 (Bottleneck), :126-139 (stem), :222-236 (darknet unit), yolact.py:319-361 (FPN),
  *   utils/functions.py:163-213 (make_net convs), yolact.py:146-193 (prediction heads).
  * y[b,oy,ox,n] = act( scale[n] * sum_{ky,kx,c} x[b, oy*s-p+ky, ox*s-p+kx, c] * w[n,ky,kx,c] + bias[n]  (+ res) )
- * computed with v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate). */
+ * fp32 in, fp32 accumulate, fp32 out.  The products are formed by the tile `tile` selects: plain ids = v_mfma_f32_32x32x2_f32
+ * (exact fp32 products); `| YMI_TILE_X3` = three-piece bf16 split; `| YMI_TILE_H2` = two-piece fp16 split (see the enum). */
 typedef struct {
   const float *x;       /* [B,H,W,ldx] NHWC; channels [0,Cin) of each pixel are used; 16-byte aligned, < 2 GiB */
   const float *w;       /* packed [CoutPad][Kpad], k = (ky*kw+kx)*Cin + c; CoutPad % 128 == 0, Kpad % 32 == 0, zero padded */
@@ -77,6 +78,21 @@ typedef struct {
   float *split_ws;      /* split_k > 1: workspace of split_k * B*Ho*Wo * Cout floats, 16-byte aligned */
   int32_t cout_alg;     /* real output channels for FLOP accounting when Cout carries zero-filter padding columns; 0 = Cout */
   int32_t _pad2;
+  /* -- fp16x2 tiles (tile | YMI_TILE_H2) ------------------------------------------------------------------------------
+   * w_h2: the SAME filters as two fp16 planes [2][CoutPad][Kpad] (uint16 bit patterns): row n is scaled by the power of two
+   * sW[n] that maps max|w[n,:]| into [2^13, 2^14); plane 0 = fp16(w * sW) (round to nearest), plane 1 = fp16(w * sW - plane 0).
+   * scale_h2[n] = scale[n] / sW[n]  (or 1 / sW[n] without a scale): the epilogue's per-channel factor with the filter scale
+   * folded in (exact: a power of two).  winv_h2[n] = 1 / sW[n] alone (partial sums of split-K launches).
+   * x_amax: DEVICE scalar holding an upper bound on |x| over the whole input tensor — written by the launch that produced x
+   * (its y_amax) or by ymi_amax_f32; the kernel scales x by the power of two sA that maps x_amax * x_amax_mul into
+   * [2^13, 2^14) before the fp16 split and divides the accumulators by sA.  A bound that is too small can overflow fp16. */
+  const void *w_h2;
+  const float *scale_h2;
+  const float *winv_h2;
+  const float *x_amax;
+  float *y_amax;        /* any tile: DEVICE scalar (or NULL) raised atomically to max|y| over everything this launch writes */
+  float x_amax_mul;     /* static factor on *x_amax; 0 = 1 */
+  int32_t _pad3;
 } ymi_conv_desc;
 
 /* block tile BMxBN; _Kn = the block's 4 waves also split K n ways (partial sums reduced in LDS in a fixed order:
@@ -92,10 +108,19 @@ enum { YMI_TILE_AUTO = 0, YMI_TILE_128x128 = 1, YMI_TILE_128x64 = 2, YMI_TILE_64
         * step is too short to hide a DMA round trip behind one or two co-resident blocks */
        YMI_TILE_128x128_S3 = 19, YMI_TILE_128x128_W8_S3 = 20, YMI_TILE_256x128_W8_S3 = 21, YMI_TILE_128x128_W8_S4 = 22,
        /* tile | YMI_TILE_X3: the same block tile computed as "bf16x3" — every fp32 operand split exactly into three bf16
-        * pieces (24 mantissa bits), 6 of the 9 piece products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the
-        * dropped terms are <= 3 * 2^-24 |a b| (one fp32 rounding of the product).  Cin % 32 == 0 layers; available for
-        * tiles 1, 2, 3, 5, 6, 7, 8, 9, 11, 12, 16, 17, 19 - 22. */
-       YMI_TILE_X3 = 32 };
+        * pieces BY TRUNCATION (24 mantissa bits), 6 of the 9 piece products on v_mfma_f32_32x32x16_bf16 with fp32
+        * accumulation; the dropped terms (m*l, l*m, l*l) are < 2^-21 |a b| in the worst case (|m| < 2^-7 |a|, |l| < 2^-15 |a|;
+        * simulated maximum 6.4 * 2^-24) and, because truncated pieces carry the sign of their operand, always of the sign of
+        * a*b: a one-sided error of +0.63 * 2^-24 |a b| on average.  Cin % 32 == 0
+        * layers; available for tiles 1, 2, 3, 5, 6, 7, 8, 9, 11, 12, 16, 17, 19 - 22. */
+       YMI_TILE_X3 = 32,
+       /* tile | YMI_TILE_H2: the same block tile computed as "fp16x2" — x * s = h + l with two fp16 pieces taken by ROUND TO
+        * NEAREST (11 + 11 significant bits + two signs: about two thirds of all fp32 values are represented exactly, the rest
+        * with an error of one fp32 ulp; unbiased), s a power of two per tensor (activations, from x_amax) or per filter row;
+        * 3 of the 4 piece products (h*l, l*h, h*h) on v_mfma_f32_32x32x16_f16 with fp32 accumulation; the dropped l*l term is
+        * <= 2^-22 |a b|, unbiased.  Half the matrix-pipe work of X3 and no byte permutes in the split.  Needs w_h2, scale_h2,
+        * x_amax.  Same base tiles as X3. */
+       YMI_TILE_H2 = 64 };
 
 int ymi_abi_version(void);
 const char *ymi_strerror(int code);
@@ -132,9 +157,21 @@ typedef struct {
   ymi_conv_seg seg[3];
   const void *u_x3;     /* optional, for tile | YMI_TILE_X3: u pre-split into bf16 planes [G][3][CoutPad][C] (see ymi_conv_desc.w_x3) */
   int32_t cout_alg;     /* real output channels for FLOP accounting (see ymi_conv_desc.cout_alg); 0 = Cout */
-  int32_t _pad2;
+  int32_t v_planes;     /* tile | YMI_TILE_H2 only.  1: the input transform writes V directly as two fp16 planes [G][2][T][C]
+                         * (scaled by the power of two derived from x_amax * the transform's gain bound; same bytes as fp32 V) and
+                         * the grouped GEMM runs with NO operand split in its loop; 0: V stays fp32 and is split on the fly */
+  /* tile | YMI_TILE_H2: u as fp16x2 planes [G][2][CoutPad][C] with one scale per (component, filter row);
+   * uinv_h2 [G][CoutPad] = 1 / that scale; x_amax / y_amax as in ymi_conv_desc (y_amax may be NULL) */
+  const void *u_h2;
+  const float *uinv_h2;
+  const float *x_amax;
+  float *y_amax;
 } ymi_wino_desc;
 int ymi_conv3x3_winograd_f32(const ymi_wino_desc *d, void *stream);
+
+/* *out = max(*out, max_i |x[i]|) over n floats (n % 4 == 0, x 16-byte aligned): the magnitude bound of a tensor that no
+ * ymi_conv launch produced (the network input), for ymi_conv_desc.x_amax.  The caller zeroes *out beforehand. */
+int ymi_amax_f32(const float *x, long n, float *out, void *stream);
 
 /* -- layout / pooling / resize ---------------------------------------------------------- */
 /* x [B,C,H,W] (C<=4) -> y [B,H,W,4], zero-filled channels C..3.  Entry of Yolact.forward (yolact.py:564). */

@@ -104,6 +104,8 @@ def test_conv_stem_7x7_c4_loader():
         for planes in (True, False):
             yx = run_conv(x, w, None, None, 2, 3, act=L.ACT_RELU, cin_pad=4, tile=tile | L.TILE_X3, planes=planes)
             assert rel_err(yx, ref) < 2e-5
+        yh = run_conv(x, w, None, None, 2, 3, act=L.ACT_RELU, cin_pad=4, tile=tile | L.TILE_H2)      # ... and on fp16x2
+        assert rel_err(yh, ref) < 2e-5
     # darknet pre-conv: 3x3 / s1 / p1 on 3 channels
     w3 = torch.randn(32, 3, 3, 3, generator=g) / 5
     y3 = run_conv(x, w3, None, None, 1, 1, cin_pad=4)
@@ -331,7 +333,8 @@ def test_conv_bf16x3_is_fp32_class(base):
 
 
 @pytest.mark.parametrize('tile', [L.TILE_128x128, L.TILE_64x128 | L.TILE_X3, L.TILE_128x128 | L.TILE_X3, L.TILE_256x128_W8 | L.TILE_X3,
-                                  L.TILE_64x64 | L.TILE_X3])
+                                  L.TILE_64x64 | L.TILE_X3, L.TILE_64x128 | L.TILE_H2, L.TILE_128x128 | L.TILE_H2,
+                                  L.TILE_256x128_W8 | L.TILE_H2, L.TILE_64x64 | L.TILE_H2])
 @pytest.mark.parametrize('S', [2, 4])
 def test_conv_1x1_split_k(tile, S):
     """split_k: the K reduction of a 1x1 convolution cut into S ranges (S x the blocks), partial sums added in a fixed
@@ -423,3 +426,74 @@ def test_merged_two_output_conv(mode):
     r1, r2 = F.relu(F.conv2d(x, w1, b1, 1, 1)), F.relu(F.conv2d(x, w2, b2, 1, 1))
     from gpu_utils import rel_err
     assert rel_err(nchw(y1.cpu()), r1) < tol and rel_err(nchw(y2.cpu()), r2) < tol
+
+
+@pytest.mark.parametrize('base', [3, 5, 1, 8, 6, 16, 17, 19, 21])
+def test_conv_fp16x2_is_fp32_class(base):
+    """tile | TILE_H2: x * s = h + l, two fp16 pieces by round to nearest (s: a power of two per tensor from the magnitude bound
+    the producer recorded, per filter row for the weights), 3 piece products on the fp16 matrix pipe, fp32 accumulate.  Same bar
+    as the bf16x3 tiles: the error against an fp64 reference over a K = 2304 reduction with operands of mixed magnitude (values
+    far below / far above the fp16 range before scaling: 1e-30, 3e4, a weight of 40 next to weights of 1e-2) must be of the
+    exact-fp32 kernel's own class, and the launch must report max|y| exactly."""
+    from gpu_utils import run_conv
+    g = _g(90 + base)
+    B, Cin, H, W, Cout, k = 2, 256, 13, 11, 192, 3
+    x = torch.randn(B, Cin, H, W, generator=g) * torch.exp(torch.randn(B, Cin, 1, 1, generator=g) * 2.0)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    x[0, 0, 0, 0], x[0, 1, 2, 3], w[0, 0, 0, 0], w[5, 7, 1, 1] = 1e-30, 3.0e4, -2.5e-22, 40.0
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    mag = F.conv2d(x.double().abs(), w.double().abs(), None, 1, 1)
+    y32 = run_conv(x, w, None, None, 1, 1, tile=base).double()
+    e32 = ((y32 - ref).abs() / mag).max().item()
+    yh = run_conv(x, w, None, None, 1, 1, tile=base | L.TILE_H2)
+    amax = run_conv.last_amax
+    eh = ((yh.double() - ref).abs() / mag).max().item()
+    print('tile %s: fp32 MFMA err %.2e, fp16x2 err %.2e (of sum|ab|)' % (L.TILE_NAMES[base], e32, eh))
+    assert e32 < 1e-5 and eh < 1e-5
+    assert eh < 2 * e32 + 1e-7
+    assert amax[0] == x.abs().max().item() and amax[1] == yh.abs().max().item()
+
+
+def test_conv_fp16x2_scale_follows_the_magnitude_bound():
+    """The activation scale is derived on the device from x_amax: tensors far outside the fp16 range (1e6, 1e-9) go through
+    unchanged in accuracy, an all-zero tensor is handled (bound 0 -> scale 1), and a bound that is LARGER than the true maximum
+    (what a max-pool / interpolation consumer hands on) only costs headroom, not correctness."""
+    from gpu_utils import run_conv, rel_err
+    g = _g(321)
+    x = torch.randn(2, 64, 9, 7, generator=g)
+    w = torch.randn(96, 64, 3, 3, generator=g) / 24
+    b = torch.randn(96, generator=g)
+    ref = F.conv2d(x, w, b, 1, 1)
+    for gain in (1e6, 1e-9, 1.0):
+        y = run_conv(x * gain, w, b * gain, None, 1, 1, tile=L.TILE_64x64 | L.TILE_H2)
+        assert rel_err(y / gain, ref) < 2e-5, gain
+    y0 = run_conv(torch.zeros_like(x), w, b, None, 1, 1, tile=L.TILE_64x64 | L.TILE_H2)
+    assert torch.equal(y0, b.view(1, -1, 1, 1).expand_as(y0))
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 9, 11, 96), (1, 256, 18, 18, 256), (1, 32, 37, 35, 64)])
+@pytest.mark.parametrize('tile', [L.TILE_64x64, L.TILE_128x128, L.TILE_64x128, L.TILE_256x128_W8, L.TILE_32x64_K2, L.TILE_128x128_S3])
+@pytest.mark.parametrize('m', [2, 4])
+@pytest.mark.parametrize('v_planes', [False, True])
+def test_winograd_fp16x2(shape, tile, m, v_planes):
+    """The Winograd path on fp16x2 GEMM tiles: U as fp16 planes with a scale per (component, filter row); V either fp32 and split
+    on the fly (scale from the input's magnitude bound times the transform's gain bound 4 / 100) or written by the input
+    transform directly as two fp16 planes (`v_planes`: no operand split in the GEMM loop at all)."""
+    from gpu_utils import run_wino, rel_err
+    import torch.nn as nn
+    B, Cin, H, W, Cout = shape
+    g = _g(B * 100 + Cin + Cout + H + m)
+    x = torch.randn(B, Cin, H, W, generator=g) * torch.exp(torch.randn(B, Cin, 1, 1, generator=g))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    bn = nn.BatchNorm2d(Cout).eval()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(Cout, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(Cout, generator=g) * 0.1)
+        bn.running_mean.copy_(torch.randn(Cout, generator=g) * 0.1)
+        bn.running_var.copy_(torch.rand(Cout, generator=g) + 0.5)
+        ref = F.relu(bn(F.conv2d(x, w, None, 1, 1)))
+    y = run_wino(x, w, None, bn, L.ACT_RELU, tile | L.TILE_H2, m, v_planes=v_planes)
+    y_fp32 = run_wino(x, w, None, bn, L.ACT_RELU, tile, m)
+    assert rel_err(y, ref) < (2e-5 if m == 2 else 5e-5)
+    assert rel_err(y, y_fp32) < (1e-5 if m == 2 else 3e-5)          # same algorithm, exact-fp32 MFMA GEMM
+    assert run_wino.last_amax[1] == y_fp32.abs().max().item() or abs(run_wino.last_amax[1] - y_fp32.abs().max().item()) < 1e-3

@@ -77,7 +77,7 @@ def test_struct_sizes_match_header():
     """ctypes mirrors have the C layout (checked against sizes computed from the header's field lists)."""
     from yolact_amd import _lib as L
     assert ctypes.sizeof(L.ConvSeg) == 32
-    assert ctypes.sizeof(L.ConvDesc) == 5 * 8 + 22 * 4 + 3 * 32 + 16 + 8
+    assert ctypes.sizeof(L.ConvDesc) == 5 * 8 + 22 * 4 + 3 * 32 + 16 + 8 + 5 * 8 + 8      # + fp16x2 planes / scales / amax slots
     assert ctypes.sizeof(L.DcnDesc) == ctypes.sizeof(L.ConvDesc) + 16
     assert ctypes.sizeof(L.DetectDesc) == 4 * 8 + 7 * 4 + 2 * 4 + 4 + 2 * 4 + 13 * 8
 

@@ -9,7 +9,7 @@
 //   MODE 1  A and B split on the fly after the ds_read (no change to the LDS image / the LDS-DMA staging)
 //   MODE 2  A split on the fly, B (weights) pre-split on the host into three bf16 planes in LDS
 //   MODE 3  both pre-split (upper bound: no VALU at all; would need producers to write split activations)
-//   MODE 4  "fp16x2": x*s = h + l, two fp16 pieces by round-to-nearest (11 + 11 significant bits + signs: 3/4 of all fp32
+//   MODE 4  "fp16x2": x*s = h + l, two fp16 pieces by round-to-nearest (11 + 11 significant bits + signs: ~2/3 of all fp32
 //           values exactly, the rest off by one fp32 ulp), s = a power-of-two scale that maps the tensor's amax below
 //           65504; 3 of the 4 piece products (hl, lh, hh) on v_mfma_f32_32x32x16_f16, fp32 accumulate, ONE accumulator;
 //           the dropped l*l term is <= 2^-22 |a b|.  A split on the fly (3 VALU per element, no v_perm), B pre-split

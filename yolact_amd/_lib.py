@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libyolact_amd.so')
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 ACT_NONE, ACT_RELU, ACT_LEAKY01, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 RES_NONE, RES_ADD, RES_BILINEAR = 0, 1, 2
@@ -28,7 +28,11 @@ X3_BASE_TILES = (1, 2, 3, 5, 6, 7, 8, 9, 11, 12, 16, 17, 19, 20, 21, 22)
 for _t in X3_BASE_TILES:
     TILE_NAMES[_t | TILE_X3] = TILE_NAMES[_t] + 'x3'
 BASIC_TILES = (1, 2, 3, 4, 5)      # available for every loader (stem, DCN)
-KSPLIT_TILES = (6, 7, 8, 13, 14, 15, 6 | 32, 7 | 32, 8 | 32)   # different (still deterministic) fp32 summation order than the unsplit tiles
+TILE_H2 = 64                        # tile | TILE_H2: fp16x2 split-precision variant (two fp16 pieces, 3 MFMAs per product)
+for _t in X3_BASE_TILES:
+    TILE_NAMES[_t | TILE_H2] = TILE_NAMES[_t] + 'h2'
+WINO_PLANES = 1024                  # tune-table flag on a Winograd GEMM tile id: V written as fp16x2 planes (ymi_wino_desc.v_planes)
+KSPLIT_TILES = (6, 7, 8, 13, 14, 15, 6 | 32, 7 | 32, 8 | 32, 6 | 64, 7 | 64, 8 | 64)   # different (still deterministic) fp32 summation order than the unsplit tiles
 
 
 class ConvSeg(C.Structure):
@@ -46,7 +50,9 @@ class ConvDesc(C.Structure):
                 ('res_H', C.c_int32), ('res_W', C.c_int32), ('res_after_act', C.c_int32),
                 ('nseg', C.c_int32), ('tile', C.c_int32), ('cin_alg', C.c_int32), ('split_k', C.c_int32),
                 ('seg', ConvSeg * 3), ('w_x3', C.c_void_p), ('split_ws', C.c_void_p), ('cout_alg', C.c_int32),
-                ('_pad2', C.c_int32)]
+                ('_pad2', C.c_int32),
+                ('w_h2', C.c_void_p), ('scale_h2', C.c_void_p), ('winv_h2', C.c_void_p), ('x_amax', C.c_void_p),
+                ('y_amax', C.c_void_p), ('x_amax_mul', C.c_float), ('_pad3', C.c_int32)]
 
 
 class WinoDesc(C.Structure):
@@ -54,7 +60,8 @@ class WinoDesc(C.Structure):
                 ('V', C.c_void_p), ('M', C.c_void_p),
                 ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('C', C.c_int32), ('Cout', C.c_int32),
                 ('act', C.c_int32), ('tile', C.c_int32), ('nseg', C.c_int32), ('m', C.c_int32), ('_pad0', C.c_int32),
-                ('seg', ConvSeg * 3), ('u_x3', C.c_void_p), ('cout_alg', C.c_int32), ('_pad2', C.c_int32)]
+                ('seg', ConvSeg * 3), ('u_x3', C.c_void_p), ('cout_alg', C.c_int32), ('v_planes', C.c_int32),
+                ('u_h2', C.c_void_p), ('uinv_h2', C.c_void_p), ('x_amax', C.c_void_p), ('y_amax', C.c_void_p)]
 
 
 class DcnDesc(C.Structure):
@@ -93,6 +100,7 @@ SYMBOLS = [
     ('ymi_conv3x3_winograd_f32', C.c_int, [C.POINTER(WinoDesc), _P]),
     ('ymi_conv_flops', C.c_double, [C.POINTER(ConvDesc)]),
     ('ymi_conv_pick_tile', C.c_int, [C.POINTER(ConvDesc)]),
+    ('ymi_amax_f32', C.c_int, [_P, C.c_long, _P, _P]),
     ('ymi_nchw_to_nhwc4_f32', C.c_int, [_P, _P, _I, _I, _I, _I, _P]),
     ('ymi_nhwc_to_nchw_f32', C.c_int, [_P, _P, _I, _I, _I, _I, _P]),
     ('ymi_maxpool3x3s2_nhwc_f32', C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),

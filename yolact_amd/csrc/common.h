@@ -26,3 +26,29 @@ __device__ __forceinline__ int ymi_xcd_remap(int bid, int nwg) {
   const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + local;
 }
+
+// ---- fp16x2 ("h2") operand scaling ----------------------------------------------------------------------------------------
+// An activation tensor is carried through the fp16 matrix pipe as  x * s = h + l  (two fp16 pieces, round to nearest);  s is
+// the power of two that maps the tensor's magnitude bound `amax` (written by its producer, csrc/conv_igemm.hip epilogue) into
+// [2^13, 2^14): far below the fp16 maximum 65504 and with 27 binades of normal range below it for h.  Producer-side
+// pre-splitting (Winograd input transform) and consumer-side un-scaling MUST derive s from the same slot with the same
+// formula, hence one helper.  amax == 0 (an all-zero tensor), inf or NaN: s = 1.
+__host__ __device__ __forceinline__ void ymi_h2_scale(float amax, float &s, float &inv) {
+  const unsigned u = __builtin_bit_cast(unsigned, amax);
+  const int eb = (int)((u >> 23) & 0xff);            // amax in [2^(eb-127), 2^(eb-126))
+  int es = 267 - eb;                                 // s = 2^(14 - (eb - 126))  ->  amax * s in [2^13, 2^14)
+  if (eb == 0 || eb == 255) es = 127;
+  es = es < 2 ? 2 : (es > 252 ? 252 : es);           // s and 1/s both stay normal fp32 numbers
+  s = __builtin_bit_cast(float, (unsigned)es << 23);
+  inv = __builtin_bit_cast(float, (unsigned)(254 - es) << 23);
+}
+
+// Non-negative floats order like their bit patterns: a device-wide running maximum is one integer atomic.
+__device__ __forceinline__ void ymi_amax_commit(float m, float *slot) {
+#pragma unroll
+  for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned *>(slot), __builtin_bit_cast(unsigned, m));
+}
+__device__ __forceinline__ float ymi_absmax4(const f32x4 v) {
+  return fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+}

@@ -74,6 +74,30 @@ __device__ __forceinline__ Split3 split8(const f32x4 x0, const f32x4 x1) {
 }
 
 
+// ---- PREC = 3 / 4: fp32-class products on the fp16 matrix pipe ("fp16x2") ----------------------------------------------
+// x * s = h + l, two fp16 pieces by ROUND TO NEAREST (v_cvt_pk_f16_f32): h = fp16(x s), l = fp16(x s - h) with x s - h exact
+// in fp32.  11 + 11 significant bits + two signs represent about two thirds of all fp32 values exactly and the rest to one fp32 ulp,
+// unbiased.  s = a power of two per tensor (ymi_h2_scale: the producer's magnitude bound -> [2^13, 2^14)), so h never
+// overflows and stays a normal fp16 for 27 binades below the tensor's maximum.  a*b = hh + hl + lh (+ ll dropped,
+// <= 2^-22 |ab|): 3 MFMAs (v_mfma_f32_32x32x16_f16, exact products, fp32 accumulate) instead of bf16x3's 6, and the split
+// is 3 VALU per element with no byte permutes.  tools/split_probe.hip: 574 TFLOP/s fp32-equivalent on random data (bf16x3
+// 313, exact fp32 154), error against fp64 2.6e-7 of sum|ab| (bf16x3 3.3e-7, fp32 MFMA 5.2e-7).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+struct Split2 { f16x8 h, l; };
+
+__device__ __forceinline__ Split2 split8h(const f32x4 x0, const f32x4 x1, const float s) {
+  const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+  Split2 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float t = x[e] * s;
+    const _Float16 h = (_Float16)t;
+    o.h[e] = h;
+    o.l[e] = (_Float16)(t - (float)h);
+  }
+  return o;
+}
+
 struct KParams {
   ymi_conv_desc d;
   int M, HoWo, tiles_n, nk;
@@ -84,6 +108,11 @@ struct KParams {
   const void *w3;                 // PREC == 2: filters pre-split into three bf16 planes [groups][3][CoutPad][Kpad]
   unsigned w3_plane;              // PREC == 2: bytes between planes (CoutPad * Kpad * 2)
   unsigned w3_gs;                 // PREC == 2: bytes between groups (3 planes for a Winograd component, K range * 2 for split-K)
+                                  // (PREC >= 3: the same three fields describe the TWO fp16 planes of ymi_conv_desc.w_h2)
+  const void *a2;                 // PREC == 4: the A operand pre-split into two fp16 planes [groups][2][rows][ldx] (Winograd V)
+  unsigned a2_plane;              // PREC == 4: bytes between the two planes
+  long a2_gs;                     // PREC == 4: bytes between groups
+  unsigned sc_gs;                 // PREC >= 3: floats between the groups' scale_h2 arrays (0: shared)
   unsigned long long *trace;      // diagnostics only (ymi_debug_set_trace): per block {hw id, t0, t_loop, t_epi, t1, t_transposed}
   int abl;                        // diagnostics only (env YMI_ABLATE): bit0 skip the staging of chunks > 0,
                                   // bit2 skip barriers in the K loop — wrong results, used to attribute stall time;
@@ -116,10 +145,13 @@ __device__ __forceinline__ void bilin_coord(int dst, float scale, int in_size, i
 // call would impose the callee's register budget and a scratch stack on the whole kernel (occupancy 5 -> 2).
 template <int BM, int BN, int WK, int RPT, int RSTEP, bool RES_PREFETCH>
 __device__ __forceinline__ void epilogue_general(const KParams &p, const float *es, f32x4 sc, f32x4 bi, const f32x4 *rpre,
-                                              int m0, int n, int c4, int rbase, bool vec_res) {
+                                              int m0, int n, int c4, int rbase, bool vec_res, float invA) {
   constexpr int ELD = BN + 4;
   const ymi_conv_desc &d = p.d;
-  if (n >= d.Cout) return;
+  if (n >= d.Cout) {                    // (the commit is wave-collective: lanes past Cout still take part, with 0)
+    if (d.y_amax) ymi_amax_commit(0.f, d.y_amax);
+    return;
+  }
   // The segment table lives in the kernel arguments; resolve it with compile-time indices + selects (indexing
   // d.seg[] with a per-lane value turns into dependent per-lane global loads).
   struct SegR { float *ptr; int64_t bs; int rs, act, n0; };
@@ -137,6 +169,7 @@ __device__ __forceinline__ void epilogue_general(const KParams &p, const float *
   // vector store only if all 4 channels live in one aligned segment
   const bool vec_out = se[0].ptr != nullptr && se[0].ptr == se[3].ptr && ((n - se[0].n0) & 3) == 0 && (se[0].rs & 3) == 0 &&
                        (se[0].bs & 3) == 0 && (((uintptr_t)se[0].ptr) & 15) == 0;
+  float amax = 0.f;                     // magnitude bound of what this thread writes (ymi_conv_desc.y_amax)
   float rscale_h = 0.f, rscale_w = 0.f;
   if (d.res_mode == YMI_RES_BILINEAR) {
     rscale_h = (float)d.res_H / (float)d.Ho;
@@ -151,7 +184,7 @@ __device__ __forceinline__ void epilogue_general(const KParams &p, const float *
     f32x4 v = *reinterpret_cast<const f32x4 *>(es + row * ELD + 4 * c4);
 #pragma unroll
     for (int q = 1; q < WK; ++q) v += *reinterpret_cast<const f32x4 *>(es + q * (BM * ELD) + row * ELD + 4 * c4);
-    v = v * sc + bi;
+    v = (v * invA) * sc + bi;           // invA: fp16x2 activation scale (a power of two: exact), 1 otherwise
     f32x4 rv = {0.f, 0.f, 0.f, 0.f};
     if (d.res_mode == YMI_RES_ADD) {
       const float *rp = d.res + (size_t)m * d.res_ld + n;
@@ -183,6 +216,8 @@ __device__ __forceinline__ void epilogue_general(const KParams &p, const float *
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = act_apply(o[e], se[e].act);
     if (d.res_after_act) o += rv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (se[e].ptr != nullptr) amax = fmaxf(amax, fabsf(o[e]));
     if (vec_out) {
       *reinterpret_cast<f32x4 *>(se[0].ptr + (size_t)b * se[0].bs + (size_t)pix * se[0].rs + (n - se[0].n0)) = o;
     } else {
@@ -191,6 +226,7 @@ __device__ __forceinline__ void epilogue_general(const KParams &p, const float *
         if (se[e].ptr != nullptr) se[e].ptr[(size_t)b * se[e].bs + (size_t)pix * se[e].rs + (n + e - se[e].n0)] = o[e];
     }
   }
+  if (d.y_amax) ymi_amax_commit(amax, d.y_amax);
 }
 
 // LOADER: 0 = Cin % 32 == 0 (a K chunk lies inside one filter tap; tap is block-uniform)
@@ -215,7 +251,7 @@ __device__ __forceinline__ void epilogue_general(const KParams &p, const float *
 // compiler, so that the epilogue's prefetch registers never cost a resident block
 // floats of LDS per K chunk: A tile [BM][32] fp32 + B tile [BN][32] fp32, or (PREC == 2) B as three bf16 planes [3][BN][32]
 template <int BM, int BN, int PREC>
-constexpr int conv_sub_floats() { return BM * BK + (PREC == 2 ? BN * BK * 3 / 2 : BN * BK); }
+constexpr int conv_sub_floats() { return BM * BK + (PREC == 2 ? BN * BK * 3 / 2 : BN * BK); }   // (fp16x2: 2 planes = BN * BK)
 
 template <int WM, int WN, int WK, int TM, int TN, int NSTAGE, int LOADER, int PREC>
 constexpr int conv_occupancy() {
@@ -241,9 +277,14 @@ void conv_igemm_f32(const KParams p) {
   constexpr int RPP = NTHR / 8;               // tile rows staged by one pass of the block (8 lanes per row)
   // DMA pieces per wave per chunk: A tile 8 rows x 128 bytes each; B tile likewise, or (PREC == 2, three bf16 planes of
   // 64-byte rows) 16 rows x 64 bytes of one plane each
-  constexpr int RA = BM / RPP, RB = (PREC == 2) ? (3 * BN) / (16 * NWAVE) : BN / RPP;
-  static_assert(BM % RPP == 0 && (PREC == 2 ? (3 * BN) % (16 * NWAVE) == 0 : BN % RPP == 0),
+  constexpr int NPL = (PREC == 2) ? 3 : 2;      // planes of a pre-split operand: bf16x3 three, fp16x2 two
+  constexpr bool BPL = PREC >= 2;               // B (filters) staged as 16-bit planes
+  constexpr bool APL = PREC == 4;               // A staged as fp16 planes too (no operand split in the loop at all)
+  constexpr bool H2 = PREC >= 3;                // fp16x2 arithmetic
+  constexpr int RA = APL ? (2 * BM) / (16 * NWAVE) : BM / RPP, RB = BPL ? (NPL * BN) / (16 * NWAVE) : BN / RPP;
+  static_assert((APL ? (2 * BM) % (16 * NWAVE) == 0 : BM % RPP == 0) && (BPL ? (NPL * BN) % (16 * NWAVE) == 0 : BN % RPP == 0),
                 "tile rows must be a multiple of the rows per staging pass");
+  static_assert(!APL || LOADER == 3, "pre-split A planes: pointwise loader only");
   constexpr int SUB = conv_sub_floats<BM, BN, PREC>();        // floats per chunk image
   constexpr int STAGE = SUB * WK;            // floats per pipeline stage
   constexpr int NS = (LOADER == 2) ? 2 : NSTAGE;   // the register-staged DCN gather keeps the simple 2-stage drain
@@ -254,7 +295,7 @@ void conv_igemm_f32(const KParams p) {
   static_assert(WM * WN * WK == 4 || WM * WN * WK == 8, "4 or 8 waves per block");
   static_assert(LOADER != 2 || WK == 1, "DCN gather runs without the K split");
   static_assert(PREC == 0 || LOADER != 2, "the bf16x3 path exists for the LDS-DMA loaders only");
-  static_assert(PREC != 2 || BN % 16 == 0, "bf16 planes: 16-row DMA pieces");
+  static_assert(!BPL || BN % 16 == 0, "16-bit planes: 16-row DMA pieces");
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
   const ymi_conv_desc &d = p.d;
@@ -272,11 +313,19 @@ void conv_igemm_f32(const KParams p) {
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const int grp = blockIdx.y;    // group of a grouped GEMM (the 16 Winograd components); 0 otherwise
-  const __amdgpu_buffer_rsrc_t xrs =
-      __builtin_amdgcn_make_buffer_rsrc((void *)(d.x + (size_t)grp * p.x_gs), 0, (int)p.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t wrs = (PREC == 2)
-      ? __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.w3 + (size_t)grp * p.w3_gs), 0, (int)(3 * p.w3_plane), 0x00020000)
+  const __amdgpu_buffer_rsrc_t xrs = APL
+      ? __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.a2 + (size_t)grp * p.a2_gs), 0, (int)(2 * p.a2_plane), 0x00020000)
+      : __builtin_amdgcn_make_buffer_rsrc((void *)(d.x + (size_t)grp * p.x_gs), 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = BPL
+      ? __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.w3 + (size_t)grp * p.w3_gs), 0, (int)(NPL * p.w3_plane), 0x00020000)
       : __builtin_amdgcn_make_buffer_rsrc((void *)(d.w + (size_t)grp * p.w_gs), 0, (int)p.w_bytes, 0x00020000);
+  // fp16x2: the power-of-two scale of the activation operand, from the producer's magnitude bound (ymi_h2_scale)
+  float sA = 1.f, invA = 1.f;
+  if (H2) {
+    float xam = d.x_amax ? *d.x_amax : 0.f;
+    if (d.x_amax_mul != 0.f) xam *= d.x_amax_mul;
+    ymi_h2_scale(xam, sA, invA);
+  }
 
   // ---- epilogue thread mapping + residual prefetch -----------------------------------------------
   // Each thread owns 4 consecutive output channels of RPT rows.  A plain residual (bottleneck shortcut) is fetched
@@ -301,15 +350,17 @@ void conv_igemm_f32(const KParams p) {
 
   // Folded-BN scale / bias are fetched NOW as well: epilogue loads sit behind the other blocks' DMA traffic in the
   // CU's memory queue.
+  // (fp16x2 tiles: scale_h2 = scale / the filter row's power-of-two scale, one array per group of a grouped launch)
+  const float *scp = H2 ? d.scale_h2 + (size_t)grp * p.sc_gs : d.scale;
   f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
-  if (n + 3 < d.Cout && (((uintptr_t)d.scale | (uintptr_t)d.bias) & 15) == 0) {
-    if (d.scale) sc = *reinterpret_cast<const f32x4 *>(d.scale + n);
+  if (n + 3 < d.Cout && (((uintptr_t)scp | (uintptr_t)d.bias) & 15) == 0) {
+    if (scp) sc = *reinterpret_cast<const f32x4 *>(scp + n);
     if (d.bias) bi = *reinterpret_cast<const f32x4 *>(d.bias + n);
   } else {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       if (n + e < d.Cout) {
-        if (d.scale) sc[e] = d.scale[n + e];
+        if (scp) sc[e] = scp[n + e];
         if (d.bias) bi[e] = d.bias[n + e];
       }
     }
@@ -318,13 +369,18 @@ void conv_igemm_f32(const KParams p) {
   int a_iy0[RA], a_ix0[RA], a_base[RA];        // a_base: byte offset of (pixel, channel 4*sl) for tap (0,0)
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
-    const int m = m0 + r0 + RPP * i;
+    // pre-split A planes (PREC 4): piece i of this wave = unit u = wave + NWAVE * i of the 2 * BM / 16 (plane, 16-row group)
+    // units; lane l fills row l >> 2, physical 16-byte slot l & 3 of a 64-byte row; a_base = byte offset of (plane, pixel,
+    // logical slot) for K chunk 0
+    const int au = wave + NWAVE * i, apl = APL ? au / (BM / 16) : 0, arow = APL ? (au - apl * (BM / 16)) * 16 + (lane >> 2) : 0;
+    const int m = APL ? m0 + arow : m0 + r0 + RPP * i;
     if (m < p.M) {
       const int b = m / p.HoWo, pix = m - b * p.HoWo;
       const int oy = pix / d.Wo, ox = pix - oy * d.Wo;
       a_iy0[i] = oy * d.stride - d.pad;
       a_ix0[i] = ox * d.stride - d.pad;
       a_base[i] = (((b * d.H + a_iy0[i]) * d.W + a_ix0[i]) * d.ldx + 4 * sl) * 4;
+      if (APL) a_base[i] = (int)(apl * p.a2_plane) + (((b * d.H + a_iy0[i]) * d.W + a_ix0[i]) * d.ldx + 8 * ((lane & 3) ^ ((arow >> 2) & 3))) * 2;
       if (LOADER == 2) a_base[i] = m;  // DCN: remember the output pixel, geometry recomputed per tap
     } else {
       a_iy0[i] = -(1 << 28);  // never valid
@@ -338,8 +394,8 @@ void conv_igemm_f32(const KParams p) {
     for (int i = 0; i < RA; ++i) a_voff[i] = (a_iy0[i] > -(1 << 27)) ? (unsigned)a_base[i] : OOB;
   }
   unsigned b_off[RB];                           // byte offset of (filter row, k-slot sl) for chunk 0
-  if (PREC == 2) {
-    // piece i of this wave = unit u = wave + NWAVE * i of the 3 * BN / 16 (plane, 16-row group) units; lane l fills row
+  if (BPL) {
+    // piece i of this wave = unit u = wave + NWAVE * i of the NPL * BN / 16 (plane, 16-row group) units; lane l fills row
     // l >> 2, physical 16-byte slot l & 3 (64-byte rows); logical slot = physical ^ ((row >> 2) & 3)
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
@@ -352,14 +408,22 @@ void conv_igemm_f32(const KParams p) {
     for (int i = 0; i < RB; ++i) b_off[i] = (unsigned)(((n0 + r0 + RPP * i) * d.Kpad + 4 * sl) * 4);
   }
   // LDS destination (floats from the chunk's B base) and per-chunk byte advance of a B piece
+  auto a_lds = [&](int i) -> int {              // LDS destination (floats from the chunk's A base) of A piece i
+    if (APL) {
+      const int u = wave + NWAVE * i, plane = u / (BM / 16), rg = u - plane * (BM / 16);
+      return plane * (BM * 16) + rg * 256;
+    }
+    return (wave * 8 + RPP * i) * BK;
+  };
+  constexpr int A_CHUNK_BYTES = APL ? BK * 2 : BK * 4;
   auto b_lds = [&](int i) -> int {
-    if (PREC == 2) {
+    if (BPL) {
       const int u = wave + NWAVE * i, plane = u / (BN / 16), rg = u - plane * (BN / 16);
       return plane * (BN * 16) + rg * 256;
     }
     return (wave * 8 + RPP * i) * BK;
   };
-  constexpr int B_CHUNK_BYTES = (PREC == 2) ? BK * 2 : BK * 4;
+  constexpr int B_CHUNK_BYTES = BPL ? BK * 2 : BK * 4;
 
   // incremental (tap, channel-chunk) state of the next chunk to stage for each of the WK chunk slots (LOADER 0 / 2)
   int nx_c[WK], nx_ky[WK], nx_kx[WK];
@@ -389,8 +453,8 @@ void conv_igemm_f32(const KParams p) {
       if (LOADER == 3) {
 #pragma unroll
         for (int i = 0; i < RA; ++i)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(As + (wave * 8 + RPP * i) * BK), 16,
-                                                   live ? a_voff[i] : OOB, live ? kc * (BK * 4) : 0, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(As + a_lds(i)), 16,
+                                                   live ? a_voff[i] : OOB, live ? kc * A_CHUNK_BYTES : 0, 0, 0);
       } else if (LOADER == 0) {
         const int koff = ((nx_ky[j] * d.W + nx_kx[j]) * d.ldx + nx_c[j]) * 4;
 #pragma unroll
@@ -488,8 +552,8 @@ void conv_igemm_f32(const KParams p) {
     float *As = lds + buf * STAGE + j * SUB;
     float *Bs = As + BM * BK;
     if (r < RA && LOADER == 3) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(As + (wave * 8 + RPP * r) * BK), 16,
-                                               live ? a_voff[r] : OOB, live ? kc * (BK * 4) : 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(As + a_lds(r)), 16,
+                                               live ? a_voff[r] : OOB, live ? kc * A_CHUNK_BYTES : 0, 0, 0);
     } else if (r < RA) {
       const int i = r;
       bool ok;
@@ -581,6 +645,7 @@ void conv_igemm_f32(const KParams p) {
   // raw fp32 fragments / filter-plane fragments, one set per step of the chunk (compile-time indexed: no register copies)
   f32x4 rwa[2][TM][2], rwb[2][TN][2];     // (dead, hence register-free, when PREC == 0)
   Split3 pbn[2][TN];                      // PREC == 2: the B pieces, read straight from the LDS planes
+  Split2 pbh[2][TN], pah[2][TM];          // PREC >= 3: fp16x2 B pieces (and, PREC == 4, A pieces) from the LDS planes
   int fo2[2][2];
 #pragma unroll
   for (int s2 = 0; s2 < 2; ++s2)
@@ -590,12 +655,28 @@ void conv_igemm_f32(const KParams p) {
   auto load_raw = [&](int buf, auto s2c) {
     constexpr int s2 = decltype(s2c)::value;
     const float *As = lds + buf * STAGE + wk * SUB + (wm * TM * 32) * BK;
+    if constexpr (APL) {       // plane image: 64-byte rows (16 floats), plane stride BM * 16 floats
+      const float *Ap = lds + buf * STAGE + wk * SUB + ((wm * TM * 32 + (lane & 31)) * 16 + 4 * ((2 * s2 + hh_) ^ psw));
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      rwa[s2][i][0] = *reinterpret_cast<const f32x4 *>(As + i * 32 * BK + fo2[s2][0]);
-      rwa[s2][i][1] = *reinterpret_cast<const f32x4 *>(As + i * 32 * BK + fo2[s2][1]);
+      for (int i = 0; i < TM; ++i) {
+        pah[s2][i].h = *reinterpret_cast<const f16x8 *>(Ap + i * 32 * 16);
+        pah[s2][i].l = *reinterpret_cast<const f16x8 *>(Ap + i * 32 * 16 + BM * 16);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        rwa[s2][i][0] = *reinterpret_cast<const f32x4 *>(As + i * 32 * BK + fo2[s2][0]);
+        rwa[s2][i][1] = *reinterpret_cast<const f32x4 *>(As + i * 32 * BK + fo2[s2][1]);
+      }
     }
-    if constexpr (PREC == 2) {
+    if constexpr (H2) {
+      const float *Bp = lds + buf * STAGE + wk * SUB + BM * BK + ((wn * TN * 32 + (lane & 31)) * 16 + 4 * ((2 * s2 + hh_) ^ psw));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        pbh[s2][j].h = *reinterpret_cast<const f16x8 *>(Bp + j * 32 * 16);
+        pbh[s2][j].l = *reinterpret_cast<const f16x8 *>(Bp + j * 32 * 16 + BN * 16);
+      }
+    } else if constexpr (PREC == 2) {
       const float *Bp = lds + buf * STAGE + wk * SUB + BM * BK + ((wn * TN * 32 + (lane & 31)) * 16 + 4 * ((2 * s2 + hh_) ^ psw));
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
@@ -653,6 +734,47 @@ void conv_igemm_f32(const KParams p) {
           }
     }
   };
+  // fp16x2: the same chunk structure with 3 products per (A, B) fragment pair — h*l, l*h first, the dominant h*h last
+  auto compute_h2 = [&](int buf, auto stage_c, int nst, int nbuf) {
+    constexpr bool STAGE_NEXT = decltype(stage_c)::value;
+    constexpr int NPOS = 6 * TM * TN;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      Split2 xa[TM];
+      if constexpr (!APL) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) xa[i] = split8h(rwa[s2][i][0], rwa[s2][i][1], sA);
+      }
+      if (s2 == 0) load_raw(buf, std::integral_constant<int, 1>{});
+#pragma unroll
+      for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const Split2 &a_ = APL ? pah[s2][i] : xa[i];
+            const f16x8 fa_ = pr == 1 ? a_.l : a_.h;
+            const f16x8 fb_ = pr == 0 ? pbh[s2][j].l : pbh[s2][j].h;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_, fb_, acc[i][j], 0, 0, 0);
+            if constexpr (STAGE_NEXT) {
+              const int pos = ((s2 * 3 + pr) * TM + i) * TN + j;
+#pragma unroll
+              for (int q = 0; q < NP; ++q) {
+                if ((NPOS * q) / NP == pos) {
+                  __builtin_amdgcn_sched_barrier(0);
+                  issue_piece(nst, nbuf, q);
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+              }
+            }
+          }
+    }
+  };
+  // split-precision chunk, bf16x3 or fp16x2 by the template's PREC
+  auto compute_sp = [&](int buf, auto stage_c, int nst, int nbuf) {
+    if constexpr (H2) compute_h2(buf, stage_c, nst, nbuf);
+    else compute_x3(buf, stage_c, nst, nbuf);
+  };
   // precision-independent entry points of the main loop
   auto prefetch_frags = [&](int buf) {
     if constexpr (PREC >= 1) {
@@ -664,8 +786,8 @@ void conv_igemm_f32(const KParams p) {
   };
   auto compute_chunk = [&](int buf, bool stage_next, int nst, int nbuf) {
     if constexpr (PREC >= 1) {
-      if (stage_next) compute_x3(buf, std::true_type{}, nst, nbuf);
-      else compute_x3(buf, std::false_type{}, nst, nbuf);
+      if (stage_next) compute_sp(buf, std::true_type{}, nst, nbuf);
+      else compute_sp(buf, std::false_type{}, nst, nbuf);
     } else {
       compute(buf, stage_next, nst, nbuf);
     }
@@ -704,23 +826,23 @@ void conv_igemm_f32(const KParams p) {
       for (; UNROLL2 && st + 2 < nsteps; st += 2) {
         prefetch_frags(0);
         __builtin_amdgcn_sched_barrier(0);
-        compute_x3(0, std::true_type{}, st + 1, 1);
+        compute_sp(0, std::true_type{}, st + 1, 1);
         __syncthreads();
         prefetch_frags(1);
         __builtin_amdgcn_sched_barrier(0);
-        compute_x3(1, std::true_type{}, st + 2, 0);
+        compute_sp(1, std::true_type{}, st + 2, 0);
         __syncthreads();
       }
       for (; st + 1 < nsteps; ++st) {              // remaining staged steps (all of them without UNROLL2)
         const int cur = st & 1;
         prefetch_frags(cur);
         __builtin_amdgcn_sched_barrier(0);
-        compute_x3(cur, std::true_type{}, st + 1, cur ^ 1);
+        compute_sp(cur, std::true_type{}, st + 1, cur ^ 1);
         __syncthreads();
       }
       prefetch_frags(st & 1);
       __builtin_amdgcn_sched_barrier(0);
-      compute_x3(st & 1, std::false_type{}, 0, 0);
+      compute_sp(st & 1, std::false_type{}, 0, 0);
       __syncthreads();
     } else {
 #pragma unroll
@@ -737,7 +859,7 @@ void conv_igemm_f32(const KParams p) {
       for (; st + NS - 1 < nsteps; ++st) {          // steady state: NS - 2 later steps stay in flight behind step st + 1
         prefetch_frags(cur);
         __builtin_amdgcn_sched_barrier(0);
-        compute_x3(cur, std::true_type{}, st + NS - 1, nxt);
+        compute_sp(cur, std::true_type{}, st + NS - 1, nxt);
         if (NS >= 4) YMI_WAIT_VM(2 * DMA_PER_STEP); else YMI_WAIT_VM(DMA_PER_STEP);
         YMI_BARRIER();
         cur = (cur + 1 == NS) ? 0 : cur + 1;
@@ -746,7 +868,7 @@ void conv_igemm_f32(const KParams p) {
       for (; st < nsteps; ++st) {                   // drain: nothing left to stage
         prefetch_frags(cur);
         __builtin_amdgcn_sched_barrier(0);
-        compute_x3(cur, std::false_type{}, 0, 0);
+        compute_sp(cur, std::false_type{}, 0, 0);
         if (st + 1 < nsteps) {
           const int rem = nsteps - 2 - st;
           if (NS >= 4 && rem >= 2) YMI_WAIT_VM(2 * DMA_PER_STEP);
@@ -864,6 +986,7 @@ void conv_igemm_f32(const KParams p) {
         f32x4 v = *reinterpret_cast<const f32x4 *>(es + row * ELD + 4 * c4);
 #pragma unroll
         for (int q = 1; q < WK; ++q) v += *reinterpret_cast<const f32x4 *>(es + q * (BM * ELD) + row * ELD + 4 * c4);
+        if (H2) v = v * invA;             // fp16x2 activation scale: a power of two, exact
         v = v * sc + bi;
         f32x4 rv = {0.f, 0.f, 0.f, 0.f};
         if (RES_PREFETCH && has_res) rv = rpre[i];
@@ -879,8 +1002,17 @@ void conv_igemm_f32(const KParams p) {
         for (int i = 0; i < RPT; ++i)
           if (m0 + rbase + RSTEP * i < p.M) *reinterpret_cast<f32x4 *>(base + (size_t)(RSTEP * i) * g0.row_stride) = o[i];
       }
+      if (d.y_amax) {                     // block-uniform: every lane takes part in the wave reduction
+        float am = 0.f;
+        if (n < d.Cout) {
+#pragma unroll
+          for (int i = 0; i < RPT; ++i)
+            if (m0 + rbase + RSTEP * i < p.M) am = fmaxf(am, ymi_absmax4(o[i]));
+        }
+        ymi_amax_commit(am, d.y_amax);
+      }
     } else {
-      epilogue_general<BM, BN, WK, RPT, RSTEP, RES_PREFETCH>(p, es, sc, bi, rpre, m0, n, c4, rbase, vec_res);
+      epilogue_general<BM, BN, WK, RPT, RSTEP, RES_PREFETCH>(p, es, sc, bi, rpre, m0, n, c4, rbase, vec_res, invA);
     }
   }
   if (p.trace && t == 0) {
@@ -934,6 +1066,11 @@ int launch_cfg(const KParams &kp, int loader, hipStream_t s, int groups) {
     }
   }
   const bool pointwise = p.d.kh == 1 && p.d.kw == 1 && p.d.pad == 0;
+  if constexpr (PREC == 4) {             // pre-split A planes exist for the pointwise loader only (the grouped Winograd GEMMs)
+    if (loader != 0 || !pointwise) return YMI_EARG;
+    hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, NS, 3, 4>), dim3(grid, groups), dim3(64 * WM * WN * WK), dyn, s, p);
+    return ymi_launch_status();
+  } else
   if (loader == 0 && (groups > 1 || pointwise)) {
     hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, NS, 3, PREC>), dim3(grid, groups), dim3(64 * WM * WN * WK), dyn, s, p);
   } else if (loader == 0) {
@@ -949,8 +1086,20 @@ int launch_cfg(const KParams &kp, int loader, hipStream_t s, int groups) {
 }
 
 // bf16x3 tiles: with pre-split filter planes (d->w_x3) only the activations are split on the fly (PREC 2), else both (PREC 1)
+// fp16x2 tiles (table PREC 3): filter planes always; with pre-split activation planes (kp.a2) nothing is split in the loop (PREC 4)
 template <int WM, int WN, int WK, int TM, int TN, int NS, bool ALL_LOADERS, int PREC>
 int launch_prec(const KParams &kp, int loader, hipStream_t s, int groups) {
+  if constexpr (PREC == 3) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NWAVE = WM * WN * WK;
+    if constexpr ((2 * BN) % (16 * NWAVE) != 0) return YMI_EARG;
+    else {
+      if (kp.a2 != nullptr) {
+        if constexpr ((2 * BM) % (16 * NWAVE) == 0) return launch_cfg<WM, WN, WK, TM, TN, NS, ALL_LOADERS, 4>(kp, loader, s, groups);
+        else return YMI_EARG;
+      }
+      return launch_cfg<WM, WN, WK, TM, TN, NS, ALL_LOADERS, 3>(kp, loader, s, groups);
+    }
+  } else
   if constexpr (PREC == 1) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NWAVE = WM * WN * WK;
     if constexpr (BN % 16 == 0 && (3 * BN) % (16 * NWAVE) == 0 && NS * conv_sub_floats<BM, BN, 2>() * WK * 4 <= 160 * 1024) {
@@ -1000,7 +1149,23 @@ int launch_prec(const KParams &kp, int loader, hipStream_t s, int groups) {
   X(YMI_TILE_X3 | YMI_TILE_128x128_S3, 2, 2, 1, 2, 2, 3, false, 1)  \
   X(YMI_TILE_X3 | YMI_TILE_128x128_W8_S3, 4, 2, 1, 1, 2, 3, false, 1) \
   X(YMI_TILE_X3 | YMI_TILE_256x128_W8_S3, 4, 2, 1, 2, 2, 3, false, 1) \
-  X(YMI_TILE_X3 | YMI_TILE_128x128_W8_S4, 4, 2, 1, 1, 2, 4, false, 1)
+  X(YMI_TILE_X3 | YMI_TILE_128x128_W8_S4, 4, 2, 1, 1, 2, 4, false, 1) \
+  X(YMI_TILE_H2 | YMI_TILE_128x128, 2, 2, 1, 2, 2, 2, true, 3)      \
+  X(YMI_TILE_H2 | YMI_TILE_128x64, 2, 2, 1, 2, 1, 2, true, 3)       \
+  X(YMI_TILE_H2 | YMI_TILE_64x64, 2, 2, 1, 1, 1, 2, true, 3)        \
+  X(YMI_TILE_H2 | YMI_TILE_64x128, 2, 2, 1, 1, 2, 2, true, 3)       \
+  X(YMI_TILE_H2 | YMI_TILE_32x32_K4, 1, 1, 4, 1, 1, 2, false, 3)    \
+  X(YMI_TILE_H2 | YMI_TILE_64x32_K2, 2, 1, 2, 1, 1, 2, false, 3)    \
+  X(YMI_TILE_H2 | YMI_TILE_32x64_K2, 1, 2, 2, 1, 1, 2, false, 3)    \
+  X(YMI_TILE_H2 | YMI_TILE_64x64_S3, 2, 2, 1, 1, 1, 3, false, 3)    \
+  X(YMI_TILE_H2 | YMI_TILE_64x128_S3, 2, 2, 1, 1, 2, 3, false, 3)   \
+  X(YMI_TILE_H2 | YMI_TILE_128x64_S3, 2, 2, 1, 2, 1, 3, false, 3)   \
+  X(YMI_TILE_H2 | YMI_TILE_128x128_W8, 4, 2, 1, 1, 2, 2, false, 3)  \
+  X(YMI_TILE_H2 | YMI_TILE_256x128_W8, 4, 2, 1, 2, 2, 2, false, 3)  \
+  X(YMI_TILE_H2 | YMI_TILE_128x128_S3, 2, 2, 1, 2, 2, 3, false, 3)  \
+  X(YMI_TILE_H2 | YMI_TILE_128x128_W8_S3, 4, 2, 1, 1, 2, 3, false, 3) \
+  X(YMI_TILE_H2 | YMI_TILE_256x128_W8_S3, 4, 2, 1, 2, 2, 3, false, 3) \
+  X(YMI_TILE_H2 | YMI_TILE_128x128_W8_S4, 4, 2, 1, 1, 2, 4, false, 3)
 
 int tile_dims(int tile, int &bm, int &bn) {
   switch (tile) {
@@ -1086,8 +1251,11 @@ int validate(const ymi_conv_desc *d, int loader) {
 // split_k > 1 (internal, ymi_conv2d_nhwc_f32 with desc->split_k): the `groups` of the launch are K ranges of ONE pointwise
 // GEMM — group g multiplies channels [g*K/S, (g+1)*K/S) and writes its raw partial sums to ws + g*M*Cout (fast-path
 // epilogue, no scale / bias / activation); splitk_fixup_k then adds the partials in a fixed order and applies the epilogue.
+struct H2Group { const void *a2 = nullptr; unsigned a2_plane = 0; long a2_gs = 0; unsigned sc_gs = 0; };
+
 int run_conv(const ymi_conv_desc *d, int loader, const float *offmask, int ldo, hipStream_t s, int groups = 1, long x_gs = 0,
-             long w_gs = 0, long y_gs = 0, double prof_flops = -1.0, int prof_kind = -1, int split_k = 1) {
+             long w_gs = 0, long y_gs = 0, double prof_flops = -1.0, int prof_kind = -1, int split_k = 1,
+             const H2Group &h2g = H2Group()) {
   int rc = validate(d, loader);
   // grouped launches take the fast-path epilogue only (it applies the group's output offset)
   if (rc == YMI_OK && groups > 1 &&
@@ -1110,17 +1278,23 @@ int run_conv(const ymi_conv_desc *d, int loader, const float *offmask, int ldo, 
   kp.offmask = offmask;
   kp.ldo = ldo;
   kp.x_gs = x_gs; kp.w_gs = w_gs; kp.y_gs = y_gs;
-  kp.w3 = d->w_x3;
+  const bool h2 = (d->tile & YMI_TILE_H2) != 0;
+  if (h2 && (d->tile & YMI_TILE_X3)) return YMI_EARG;
+  // fp16x2 needs the filter planes, the folded per-row scales and a magnitude bound for the activations (or pre-split ones)
+  if (h2 && (!d->w_h2 || !d->scale_h2 || (!d->x_amax && !h2g.a2))) return YMI_ENULL;
+  kp.w3 = h2 ? d->w_h2 : d->w_x3;
   kp.w3_plane = (unsigned)((((long)d->Cout + 127) / 128 * 128) * d->Kpad * 2L);
-  kp.w3_gs = split_k > 1 ? (unsigned)(d->Kpad / split_k * 2) : 3u * kp.w3_plane;
+  kp.w3_gs = split_k > 1 ? (unsigned)(d->Kpad / split_k * 2) : (h2 ? 2u : 3u) * kp.w3_plane;
   if (kp.w3 && (((uintptr_t)kp.w3) & 15)) return YMI_ESHAPE;
+  kp.a2 = h2 ? h2g.a2 : nullptr; kp.a2_plane = h2g.a2_plane; kp.a2_gs = h2g.a2_gs; kp.sc_gs = h2g.sc_gs;
+  if (kp.a2 && ((((uintptr_t)kp.a2) & 15) || (d->ldx & 7))) return YMI_ESHAPE;
   kp.abl = 0;
 #ifdef YMI_DIAGNOSTICS   // `make DIAG=1`: ablation switches for tools/conv_probe.py — they produce WRONG results by design
   { const char *e = getenv("YMI_ABLATE"); kp.abl = e ? atoi(e) : 0; }
 #endif
   kp.trace = g_trace;
   int tile = d->tile ? d->tile : pick_tile(d);
-  if (loader != 0 && (!tile_all_loaders(tile) || (loader == 2 && (tile & YMI_TILE_X3)))) {
+  if (loader != 0 && (!tile_all_loaders(tile) || (loader == 2 && (tile & (YMI_TILE_X3 | YMI_TILE_H2))))) {
     if (d->tile) return YMI_EARG;   // explicit request the stem / DCN loaders cannot honour
     tile = YMI_TILE_64x64;
   }
@@ -1153,8 +1327,9 @@ int run_conv(const ymi_conv_desc *d, int loader, const float *offmask, int ldo, 
 __global__ __launch_bounds__(256) void splitk_fixup_k(const float *__restrict__ part, long gstride, int S, long M, int N4, int ldy,
                                                       float *__restrict__ y, const float *__restrict__ scale,
                                                       const float *__restrict__ bias, const float *__restrict__ res, int res_ld,
-                                                      int act, int res_after_act) {
+                                                      int act, int res_after_act, float *__restrict__ y_amax) {
   const long total = M * N4;
+  float am = 0.f;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
     const long m = i / N4;
     const int n = (int)(i - m * N4) * 4;
@@ -1170,8 +1345,10 @@ __global__ __launch_bounds__(256) void splitk_fixup_k(const float *__restrict__ 
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], slope * v[e]);
     if (res_after_act) v += rv;
+    am = fmaxf(am, ymi_absmax4(v));
     *reinterpret_cast<f32x4 *>(y + m * ldy + n) = v;
   }
+  if (y_amax) ymi_amax_commit(am, y_amax);
 }
 
 int ymi_internal_prof_begin_fwd(double flops, int tile, int kind, hipStream_t s);
@@ -1195,6 +1372,9 @@ int run_splitk(const ymi_conv_desc *d, hipStream_t s) {
   ymi_conv_desc pd = *d;
   pd.split_k = 0;
   pd.scale = nullptr; pd.bias = nullptr; pd.res = nullptr; pd.res_mode = YMI_RES_NONE; pd.res_after_act = 0;
+  pd.scale_h2 = d->winv_h2;            // fp16x2: the partial launches undo the operand scales only -> true partial sums
+  pd.y_amax = nullptr;                 // (the second pass reports the magnitude of the finished tensor)
+  if ((d->tile & YMI_TILE_H2) && !d->winv_h2) return YMI_ENULL;
   pd.seg[0].n0 = 0; pd.seg[0].n1 = d->Cout; pd.seg[0].act = YMI_ACT_NONE; pd.seg[0].row_stride = d->Cout;
   pd.seg[0].batch_stride = HoWo * d->Cout; pd.seg[0].ptr = d->split_ws;
   const int outer = ymi_internal_prof_begin_fwd(ymi_conv_flops(d), d->tile ? d->tile : pick_tile(d), 7, s);
@@ -1206,7 +1386,7 @@ int run_splitk(const ymi_conv_desc *d, hipStream_t s) {
   const long cap = 256L * 32;
   hipLaunchKernelGGL(splitk_fixup_k, dim3((unsigned)(gsz > cap ? cap : gsz)), dim3(256), 0, s, d->split_ws, M * (long)d->Cout, S, M,
                      d->Cout / 4, g0.row_stride, g0.ptr, d->scale, d->bias, d->res_mode == YMI_RES_ADD ? d->res : nullptr,
-                     d->res_ld, g0.act, d->res_after_act);
+                     d->res_ld, g0.act, d->res_after_act, d->y_amax);
   rc = ymi_launch_status();
   ymi_internal_prof_end_fwd(outer, s);
   return rc;
@@ -1237,8 +1417,10 @@ void ymi_internal_prof_end_fwd(int idx, hipStream_t s) { ymi_internal_prof_end(i
 // internal (not part of the C ABI): grouped GEMM for csrc/winograd.hip — `groups` independent 1x1 GEMMs that share the
 // descriptor's shape; group g reads x + g*x_gs, w + g*w_gs and writes seg[0].ptr + g*y_gs.
 int ymi_internal_grouped_gemm(const ymi_conv_desc *d, int groups, long x_gs, long w_gs, long y_gs, double prof_flops,
-                              int prof_kind, hipStream_t s) {
-  return run_conv(d, 0, nullptr, 0, s, groups, x_gs, w_gs, y_gs, prof_flops, prof_kind);
+                              int prof_kind, hipStream_t s, const void *a2, unsigned a2_plane, long a2_gs, unsigned sc_gs) {
+  H2Group g;
+  g.a2 = a2; g.a2_plane = a2_plane; g.a2_gs = a2_gs; g.sc_gs = sc_gs;
+  return run_conv(d, 0, nullptr, 0, s, groups, x_gs, w_gs, y_gs, prof_flops, prof_kind, 1, g);
 }
 
 extern "C" {

@@ -110,7 +110,26 @@ inline int grid_for(long total) {
 
 }  // namespace
 
+namespace {
+// *out = max(*out, max |x|): one float4 per thread and trip, a wave reduction and one integer atomic per wave (non-negative
+// floats order like their bit patterns).  Feeds ymi_conv_desc.x_amax for tensors no conv launch produced (the network input).
+__global__ __launch_bounds__(256) void amax_k(const float *__restrict__ x, long n4, float *__restrict__ out) {
+  float am = 0.f;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256L)
+    am = fmaxf(am, ymi_absmax4(*reinterpret_cast<const f32x4 *>(x + 4 * i)));
+  ymi_amax_commit(am, out);
+}
+}  // namespace
+
 extern "C" {
+
+int ymi_amax_f32(const float *x, long n, float *out, void *stream) {
+  if (!x || !out) return YMI_ENULL;
+  if (n <= 0 || (n & 3) || (((uintptr_t)x) & 15)) return YMI_ESHAPE;
+  long g = (n / 4 + 255) / 256;
+  hipLaunchKernelGGL(amax_k, dim3((unsigned)(g > 2048 ? 2048 : g)), dim3(256), 0, (hipStream_t)stream, x, n / 4, out);
+  return ymi_launch_status();
+}
 
 int ymi_nchw_to_nhwc4_f32(const float *x, float *y, int B, int C, int H, int W, void *stream) {
   if (!x || !y) return YMI_ENULL;

@@ -13,20 +13,42 @@
 #include "../../include/yolact_amd.h"
 
 int ymi_internal_grouped_gemm(const ymi_conv_desc *d, int groups, long x_gs, long w_gs, long y_gs, double prof_flops,
-                              int prof_kind, hipStream_t s);
+                              int prof_kind, hipStream_t s, const void *a2 = nullptr, unsigned a2_plane = 0, long a2_gs = 0,
+                              unsigned sc_gs = 0);
 int ymi_internal_prof_begin(double flops, int tile, int kind, hipStream_t s);
 void ymi_internal_prof_end(int idx, hipStream_t s);
 
 namespace {
+
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// fp16x2 planes of V (ymi_wino_desc.v_planes): component e of (tile t, channels c .. c+3) as  v * s = h + l  (round to nearest),
+// layout [G][2][T][C] fp16 — the same bytes as the fp32 V it replaces; the grouped GEMM then stages both operands as planes and
+// its K loop contains no operand split at all (csrc/conv_igemm.hip PREC 4).  `o` points at plane 0 of component 0.
+__device__ __forceinline__ void store_v_planes(_Float16 *o, long e, long stride_e2, long plane, const f32x4 v, float s) {
+  f16x4 h, l;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float t = v[k] * s;
+    h[k] = (_Float16)t;
+    l[k] = (_Float16)(t - (float)h[k]);
+  }
+  *reinterpret_cast<f16x4 *>(o + e * stride_e2) = h;
+  *reinterpret_cast<f16x4 *>(o + e * stride_e2 + plane) = l;
+}
 
 __device__ __forceinline__ f32x4 ld4(const float *p, bool ok) {
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
   return ok ? *reinterpret_cast<const f32x4 *>(p) : z;
 }
 
-// one thread = one tile x 4 channels.  x [B,H,W,C] NHWC, V [16][T][C]
+// one thread = one tile x 4 channels.  x [B,H,W,C] NHWC, V [16][T][C]  (PLANES: fp16x2 planes [16][2][T][C], scaled by the power
+// of two derived from *x_amax * 4 — |B^T d B| <= 4 max|d| for F(2x2,3x3))
+template <bool PLANES>
 __global__ __launch_bounds__(256) void wino_in_k(const float *__restrict__ x, float *__restrict__ V, int H, int W, int C4,
-                                                 int th, int tw, long T, long total) {
+                                                 int th, int tw, long T, long total, const float *__restrict__ x_amax) {
+  float vs = 1.f, vinv = 1.f;
+  if (PLANES) ymi_h2_scale(*x_amax * 4.f, vs, vinv);
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
     const int c4 = (int)(i % C4);
     const long t = i / C4;
@@ -59,13 +81,21 @@ __global__ __launch_bounds__(256) void wino_in_k(const float *__restrict__ x, fl
     }
     const long stride_e = T * (C4 * 4L);
     float *o = V + t * (C4 * 4L) + c4 * 4;
+    _Float16 *o2 = reinterpret_cast<_Float16 *>(V) + t * (C4 * 4L) + c4 * 4;
 #pragma unroll
     for (int iy = 0; iy < 4; ++iy) {       // columns: v = u B
       const f32x4 v0 = u[iy][0] - u[iy][2], v1 = u[iy][1] + u[iy][2], v2 = u[iy][2] - u[iy][1], v3 = u[iy][1] - u[iy][3];
-      *reinterpret_cast<f32x4 *>(o + (iy * 4 + 0) * stride_e) = v0;
-      *reinterpret_cast<f32x4 *>(o + (iy * 4 + 1) * stride_e) = v1;
-      *reinterpret_cast<f32x4 *>(o + (iy * 4 + 2) * stride_e) = v2;
-      *reinterpret_cast<f32x4 *>(o + (iy * 4 + 3) * stride_e) = v3;
+      if (PLANES) {
+        store_v_planes(o2, iy * 4 + 0, 2 * stride_e, stride_e, v0, vs);
+        store_v_planes(o2, iy * 4 + 1, 2 * stride_e, stride_e, v1, vs);
+        store_v_planes(o2, iy * 4 + 2, 2 * stride_e, stride_e, v2, vs);
+        store_v_planes(o2, iy * 4 + 3, 2 * stride_e, stride_e, v3, vs);
+      } else {
+        *reinterpret_cast<f32x4 *>(o + (iy * 4 + 0) * stride_e) = v0;
+        *reinterpret_cast<f32x4 *>(o + (iy * 4 + 1) * stride_e) = v1;
+        *reinterpret_cast<f32x4 *>(o + (iy * 4 + 2) * stride_e) = v2;
+        *reinterpret_cast<f32x4 *>(o + (iy * 4 + 3) * stride_e) = v3;
+      }
     }
   }
 }
@@ -73,7 +103,9 @@ __global__ __launch_bounds__(256) void wino_in_k(const float *__restrict__ x, fl
 // one thread = one tile x 4 output channels.  M [16][T][N], y [B,Ho,Wo,N]
 __global__ __launch_bounds__(256) void wino_out_k(const float *__restrict__ Mm, float *__restrict__ y,
                                                   const float *__restrict__ scale, const float *__restrict__ bias, int Ho,
-                                                  int Wo, int N4, int th, int tw, long T, int act, long total) {
+                                                  int Wo, int N4, int th, int tw, long T, int act, long total,
+                                                  float *__restrict__ y_amax) {
+  float am = 0.f;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
     const int n4 = (int)(i % N4);
     const long t = i / N4;
@@ -109,10 +141,12 @@ __global__ __launch_bounds__(256) void wino_out_k(const float *__restrict__ Mm, 
         f32x4 v = (ix == 0 ? o0 : o1) * sc + bi;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], slope * v[e]);
+        am = fmaxf(am, ymi_absmax4(v));
         *reinterpret_cast<f32x4 *>(y + ((b * Ho + oy) * (long)Wo + ox) * (N4 * 4L) + n4 * 4) = v;
       }
     }
   }
+  if (y_amax) ymi_amax_commit(am, y_amax);
 }
 
 // Same output transform, scattering to up to 3 output segments with their own strides / activations (the shared
@@ -159,7 +193,7 @@ __device__ __forceinline__ SegVec seg_vec_setup(const SegTab &st, int k, const f
   for (int e = 0; e < 4; ++e) { v.sc[e] = scale ? scale[n + e] : 1.f; v.bi[e] = bias ? bias[n + e] : 0.f; }
   return v;
 }
-__device__ __forceinline__ void seg_vec_store(const SegVec &sv, f32x4 v, long b, long pix) {
+__device__ __forceinline__ float seg_vec_store(const SegVec &sv, f32x4 v, long b, long pix) {
   v = v * sv.sc + sv.bi;
   if (sv.act <= YMI_ACT_LEAKY01) {      // none / ReLU / LeakyReLU: max(x, slope x)
     const float slope = sv.act == YMI_ACT_RELU ? 0.f : (sv.act == YMI_ACT_LEAKY01 ? 0.1f : 1.f);
@@ -170,11 +204,13 @@ __device__ __forceinline__ void seg_vec_store(const SegVec &sv, f32x4 v, long b,
     for (int e = 0; e < 4; ++e) v[e] = wino_act(v[e], sv.act);
   }
   *reinterpret_cast<f32x4 *>(sv.ptr + b * sv.bs + pix * sv.rs) = v;
+  return ymi_absmax4(v);
 }
 
 __global__ __launch_bounds__(256) void wino_out_seg_k(const float *__restrict__ Mm, const SegTab st,
                                                       const float *__restrict__ scale, const float *__restrict__ bias,
-                                                      int Ho, int Wo, int N4, int Cout, int th, int tw, long T, long total) {
+                                                      int Ho, int Wo, int N4, int Cout, int th, int tw, long T, long total, float *__restrict__ y_amax) {
+  float am = 0.f;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
     const int n4 = (int)(i % N4);
     const long t = i / N4;
@@ -207,7 +243,7 @@ __global__ __launch_bounds__(256) void wino_out_seg_k(const float *__restrict__ 
 #pragma unroll
         for (int ix = 0; ix < 2; ++ix) {
           const int oy = 2 * ty + iy, ox = 2 * tx + ix;
-          if (oy < Ho && ox < Wo) seg_vec_store(sv, o[iy][ix], b, (long)oy * Wo + ox);
+          if (oy < Ho && ox < Wo) am = fmaxf(am, seg_vec_store(sv, o[iy][ix], b, (long)oy * Wo + ox));
         }
       continue;
     }
@@ -232,11 +268,14 @@ __global__ __launch_bounds__(256) void wino_out_seg_k(const float *__restrict__ 
         for (int ix = 0; ix < 2; ++ix) {
           const int ox = 2 * tx + ix;
           if (ox >= Wo) continue;
-          ptr[b * bs + ((long)oy * Wo + ox) * rs + (n - n0)] = wino_act(o[iy][ix][e] * sc + bi, act);
+          const float val = wino_act(o[iy][ix][e] * sc + bi, act);
+          am = fmaxf(am, fabsf(val));
+          ptr[b * bs + ((long)oy * Wo + ox) * rs + (n - n0)] = val;
         }
       }
     }
   }
+  if (y_amax) ymi_amax_commit(am, y_amax);
 }
 
 // ---- F(4x4, 3x3): 36 multiplications per 4x4 output tile instead of 144 (4x fewer MFMA FLOPs than direct, 1.78x fewer
@@ -259,9 +298,13 @@ __device__ __forceinline__ void bt6(const f32x4 v0, const f32x4 v1, const f32x4 
   t5 = (v1 * 4.f - v3 * 5.f) + v5;
 }
 
-// one thread = one 6x6 input patch (tile) x 4 channels.  x [B,H,W,C] NHWC, V [36][T][C]
+// one thread = one 6x6 input patch (tile) x 4 channels.  x [B,H,W,C] NHWC, V [36][T][C]  (PLANES: fp16x2 planes [36][2][T][C];
+// |B^T d B| <= 100 max|d|: every row of B^T has an absolute sum of at most 10)
+template <bool PLANES>
 __global__ __launch_bounds__(256) void wino43_in_k(const float *__restrict__ x, float *__restrict__ V, int H, int W, int C4,
-                                                   int th, int tw, long T, long total) {
+                                                   int th, int tw, long T, long total, const float *__restrict__ x_amax) {
+  float vs = 1.f, vinv = 1.f;
+  if (PLANES) ymi_h2_scale(*x_amax * 100.f, vs, vinv);
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
     const int c4 = (int)(i % C4);
     const long t = i / C4;
@@ -287,12 +330,16 @@ __global__ __launch_bounds__(256) void wino43_in_k(const float *__restrict__ x, 
     }
     const long stride_e = T * (C4 * 4L);
     float *o = V + t * (C4 * 4L) + c4 * 4;
+    _Float16 *o2 = reinterpret_cast<_Float16 *>(V) + t * (C4 * 4L) + c4 * 4;
 #pragma unroll
     for (int iy = 0; iy < 6; ++iy) {       // rows: v = u B
       f32x4 v[6];
       bt6(u[iy][0], u[iy][1], u[iy][2], u[iy][3], u[iy][4], u[iy][5], v[0], v[1], v[2], v[3], v[4], v[5]);
 #pragma unroll
-      for (int l = 0; l < 6; ++l) *reinterpret_cast<f32x4 *>(o + (iy * 6 + l) * stride_e) = v[l];
+      for (int l = 0; l < 6; ++l) {
+        if (PLANES) store_v_planes(o2, iy * 6 + l, 2 * stride_e, stride_e, v[l], vs);
+        else *reinterpret_cast<f32x4 *>(o + (iy * 6 + l) * stride_e) = v[l];
+      }
     }
   }
 }
@@ -323,7 +370,9 @@ __device__ __forceinline__ void wino43_out_tile(const float *__restrict__ src, l
 
 __global__ __launch_bounds__(256) void wino43_out_k(const float *__restrict__ Mm, float *__restrict__ y,
                                                     const float *__restrict__ scale, const float *__restrict__ bias, int Ho,
-                                                    int Wo, int N4, int th, int tw, long T, int act, long total) {
+                                                    int Wo, int N4, int th, int tw, long T, int act, long total,
+                                                    float *__restrict__ y_amax) {
+  float am = 0.f;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
     const int n4 = (int)(i % N4);
     const long t = i / N4;
@@ -348,15 +397,18 @@ __global__ __launch_bounds__(256) void wino43_out_k(const float *__restrict__ Mm
         f32x4 v = o[iy][ix] * sc + bi;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], slope * v[e]);
+        am = fmaxf(am, ymi_absmax4(v));
         *reinterpret_cast<f32x4 *>(y + ((b * Ho + oy) * (long)Wo + ox) * (N4 * 4L) + n4 * 4) = v;
       }
     }
   }
+  if (y_amax) ymi_amax_commit(am, y_amax);
 }
 
 __global__ __launch_bounds__(256) void wino43_out_seg_k(const float *__restrict__ Mm, const SegTab st,
                                                         const float *__restrict__ scale, const float *__restrict__ bias,
-                                                        int Ho, int Wo, int N4, int Cout, int th, int tw, long T, long total) {
+                                                        int Ho, int Wo, int N4, int Cout, int th, int tw, long T, long total, float *__restrict__ y_amax) {
+  float am = 0.f;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
     const int n4 = (int)(i % N4);
     const long t = i / N4;
@@ -374,7 +426,7 @@ __global__ __launch_bounds__(256) void wino43_out_seg_k(const float *__restrict_
 #pragma unroll
         for (int ix = 0; ix < 4; ++ix) {
           const int oy = 4 * ty + iy, ox = 4 * tx + ix;
-          if (oy < Ho && ox < Wo) seg_vec_store(sv, o[iy][ix], b, (long)oy * Wo + ox);
+          if (oy < Ho && ox < Wo) am = fmaxf(am, seg_vec_store(sv, o[iy][ix], b, (long)oy * Wo + ox));
         }
       continue;
     }
@@ -398,11 +450,14 @@ __global__ __launch_bounds__(256) void wino43_out_seg_k(const float *__restrict_
         for (int ix = 0; ix < 4; ++ix) {
           const int ox = 4 * tx + ix;
           if (ox >= Wo) continue;
-          ptr[b * bs + ((long)oy * Wo + ox) * rs + (n - n0)] = wino_act(o[iy][ix][e] * sc + bi, act);
+          const float val = wino_act(o[iy][ix][e] * sc + bi, act);
+          am = fmaxf(am, fabsf(val));
+          ptr[b * bs + ((long)oy * Wo + ox) * rs + (n - n0)] = val;
         }
       }
     }
   }
+  if (y_amax) ymi_amax_commit(am, y_amax);
 }
 
 unsigned grid_for(long total) {
@@ -434,10 +489,16 @@ extern "C" int ymi_conv3x3_winograd_f32(const ymi_wino_desc *d, void *stream) {
   const double alg = 2.0 * d->B * d->H * d->W * (double)(d->cout_alg > 0 ? d->cout_alg : d->Cout) * 9.0 * d->C;
   const double exe = 2.0 * ng * (double)T * d->C * Ng;
   const int outer = ymi_internal_prof_begin(alg, d->tile ? d->tile : YMI_TILE_64x64, mt == 4 ? 4 : 3, s);
-  if (mt == 4)
-    hipLaunchKernelGGL(wino43_in_k, dim3(grid_for(T * C4)), dim3(256), 0, s, d->x, d->V, d->H, d->W, C4, th, tw, T, T * C4);
-  else
-    hipLaunchKernelGGL(wino_in_k, dim3(grid_for(T * C4)), dim3(256), 0, s, d->x, d->V, d->H, d->W, C4, th, tw, T, T * C4);
+  const bool h2 = (d->tile & YMI_TILE_H2) != 0;
+  if (h2 && (!d->u_h2 || !d->uinv_h2 || !d->x_amax)) return YMI_ENULL;
+  const bool planes = h2 && d->v_planes != 0;
+  if (mt == 4) {
+    if (planes) hipLaunchKernelGGL(wino43_in_k<true>, dim3(grid_for(T * C4)), dim3(256), 0, s, d->x, d->V, d->H, d->W, C4, th, tw, T, T * C4, d->x_amax);
+    else hipLaunchKernelGGL(wino43_in_k<false>, dim3(grid_for(T * C4)), dim3(256), 0, s, d->x, d->V, d->H, d->W, C4, th, tw, T, T * C4, d->x_amax);
+  } else {
+    if (planes) hipLaunchKernelGGL(wino_in_k<true>, dim3(grid_for(T * C4)), dim3(256), 0, s, d->x, d->V, d->H, d->W, C4, th, tw, T, T * C4, d->x_amax);
+    else hipLaunchKernelGGL(wino_in_k<false>, dim3(grid_for(T * C4)), dim3(256), 0, s, d->x, d->V, d->H, d->W, C4, th, tw, T, T * C4, d->x_amax);
+  }
   int rc = ymi_launch_status();
   if (rc) return rc;
   ymi_conv_desc g = {};
@@ -447,10 +508,19 @@ extern "C" int ymi_conv3x3_winograd_f32(const ymi_wino_desc *d, void *stream) {
   g.kh = g.kw = 1; g.stride = 1; g.pad = 0; g.Kpad = d->C;
   g.nseg = 1; g.tile = d->tile;
   g.w_x3 = d->u_x3;                    // [G][3][CoutPad][C] bf16 planes (optional)
+  // fp16x2: U as [G][2][CoutPad][C] fp16 planes with a scale per (component, filter row); V scaled by the power of two derived
+  // from the input tensor's magnitude bound times the transform's gain bound (|B^T d B| <= 4 resp. 100 max|d|)
+  g.w_h2 = d->u_h2; g.scale_h2 = d->uinv_h2; g.winv_h2 = d->uinv_h2;
+  g.x_amax = d->x_amax; g.x_amax_mul = mt == 4 ? 100.f : 4.f;
   g.seg[0].n0 = 0; g.seg[0].n1 = Ng; g.seg[0].act = YMI_ACT_NONE; g.seg[0].row_stride = Ng;
   g.seg[0].batch_stride = T * Ng; g.seg[0].ptr = d->M;
   const long cout_pad = ((long)d->Cout + 127) / 128 * 128;
-  rc = ymi_internal_grouped_gemm(&g, ng, T * d->C, cout_pad * d->C, T * Ng, exe, mt == 4 ? 6 : 5 /* kind: winograd GEMM */, s);
+  if (planes)      // V = [G][2][T][C] fp16: both GEMM operands arrive pre-split (conv_igemm PREC 4)
+    rc = ymi_internal_grouped_gemm(&g, ng, T * d->C, cout_pad * d->C, T * Ng, exe, mt == 4 ? 6 : 5, s, d->V,
+                                   (unsigned)(T * d->C * 2), 2L * T * d->C * 2, (unsigned)cout_pad);
+  else
+    rc = ymi_internal_grouped_gemm(&g, ng, T * d->C, cout_pad * d->C, T * Ng, exe, mt == 4 ? 6 : 5 /* kind: winograd GEMM */, s,
+                                   nullptr, 0, 0, (unsigned)cout_pad);
   if (rc) return rc;
   if (d->nseg > 0) {
     SegTab st;
@@ -458,20 +528,20 @@ extern "C" int ymi_conv3x3_winograd_f32(const ymi_wino_desc *d, void *stream) {
     for (int k = 0; k < 3; ++k) st.seg[k] = d->seg[k];
     if (mt == 4)
       hipLaunchKernelGGL(wino43_out_seg_k, dim3(grid_for(T * N4)), dim3(256), 0, s, d->M, st, d->scale, d->bias, d->H, d->W,
-                         N4, d->Cout, th, tw, T, T * N4);
+                         N4, d->Cout, th, tw, T, T * N4, d->y_amax);
     else
       hipLaunchKernelGGL(wino_out_seg_k, dim3(grid_for(T * N4)), dim3(256), 0, s, d->M, st, d->scale, d->bias, d->H, d->W, N4,
-                         d->Cout, th, tw, T, T * N4);
+                         d->Cout, th, tw, T, T * N4, d->y_amax);
     rc = ymi_launch_status();
     ymi_internal_prof_end(outer, s);
     return rc;
   }
   if (mt == 4)
     hipLaunchKernelGGL(wino43_out_k, dim3(grid_for(T * N4)), dim3(256), 0, s, d->M, d->y, d->scale, d->bias, d->H, d->W, N4, th,
-                       tw, T, d->act, T * N4);
+                       tw, T, d->act, T * N4, d->y_amax);
   else
     hipLaunchKernelGGL(wino_out_k, dim3(grid_for(T * N4)), dim3(256), 0, s, d->M, d->y, d->scale, d->bias, d->H, d->W, N4, th,
-                       tw, T, d->act, T * N4);
+                       tw, T, d->act, T * N4, d->y_amax);
   rc = ymi_launch_status();
   ymi_internal_prof_end(outer, s);
   return rc;

@@ -25,8 +25,8 @@ def _ceil(a, b):
 
 
 # ---- shipped tile / algorithm table ------------------------------------------------------------------------------
-SPLIT_DEFAULT = '1'   # default of YOLACT_AMD_SPLIT (see Plan.__init__)
-TUNE_GEN = 3          # bump whenever tile ids or kernel variants change meaning: older tables are ignored
+SPLIT_DEFAULT = '2'   # default of YOLACT_AMD_SPLIT (see Plan.__init__): 0 exact-fp32 MFMA, 1 bf16x3, 2 fp16x2
+TUNE_GEN = 4          # bump whenever tile ids or kernel variants change meaning: older tables are ignored
 TUNE_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tune')
 _table_cache = {}
 
@@ -85,6 +85,26 @@ def split3_planes(w: torch.Tensor) -> torch.Tensor:
     return torch.stack([hb, mb, lb], dim=-3).contiguous()
 
 
+def split2_planes_f16(w: torch.Tensor):
+    """fp32 [..., R, K] -> (fp16 bit patterns int16 [..., 2, R, K], inverse row scales fp32 [..., R]) for the fp16x2 tiles
+    (csrc/conv_igemm.hip split8h does the same to the activations on the fly): row r is scaled by the power of two s_r that maps
+    max|w[r, :]| into [2^13, 2^14) (all-zero rows: 1); plane 0 = fp16(w s) by round to nearest, plane 1 = fp16(w s - plane 0)
+    (the difference is exact in fp32).  11 + 11 significant bits + two signs: about two thirds of all fp32 values are represented
+    exactly, the rest to one fp32 ulp, unbiased.  The second result is 1 / s_r (exact), folded into the epilogue's per-channel
+    scale by the callers."""
+    w = w.detach().to(torch.float32).contiguous()
+    amax = w.abs().amax(dim=-1)
+    _, e = torch.frexp(amax)                                   # amax = m * 2^e with 0.5 <= m < 1, i.e. amax < 2^e
+    s = torch.ldexp(torch.ones_like(amax), 14 - e)
+    s = torch.where(amax > 0, s, torch.ones_like(s))
+    t = w * s.unsqueeze(-1)                                    # exact: a power-of-two scale
+    h = t.to(torch.float16)
+    l = (t - h.to(torch.float32)).to(torch.float16)
+    assert bool(torch.isfinite(h.float()).all()), 'fp16x2 filter planes overflowed'
+    planes = torch.stack([h, l], dim=-3).contiguous().view(torch.int16)
+    return planes, (1.0 / s).contiguous()
+
+
 class Packed:
     """A convolution's filters in the engine layout [CoutPad][Kpad] (k = (ky*kw+kx)*Cin + c) + folded epilogue."""
 
@@ -101,7 +121,7 @@ class Packed:
         wp = torch.zeros(self.CoutPad, self.Kpad, dtype=torch.float32, device=weight.device)
         wp[:Cout, :K] = w.reshape(Cout, K)
         self.w = wp.to(device).contiguous()
-        self._wp_host, self._w3 = wp, None
+        self._wp_host, self._w3, self._h2 = wp, None, None
         self.weight_oihw = weight if (kh == 3 and kw == 3) else None     # Winograd transform source
         self.Cin, self.Cout, self.kh, self.kw, self.stride, self.pad = cin_p, Cout, kh, kw, stride, pad
         self.cin_alg = Cin
@@ -126,6 +146,19 @@ class Packed:
         return self._w3
 
 
+    def h2(self):
+        """(planes [2][CoutPad][Kpad] fp16, scale_h2 [CoutPad] = folded-BN scale / the row's filter scale, winv_h2 [CoutPad] =
+        1 / the row's filter scale) for the fp16x2 tiles (ymi_conv_desc.w_h2 / scale_h2 / winv_h2); built on first use."""
+        if self._h2 is None:
+            planes, winv = split2_planes_f16(self._wp_host.cpu())
+            sc = torch.ones(self.CoutPad, dtype=torch.float32)
+            if self.scale is not None:
+                sc[:self.Cout] = self.scale.detach().float().cpu()
+            dev = self.w.device
+            self._h2 = (planes.to(dev), (sc * winv).contiguous().to(dev), winv.to(dev))
+        return self._h2
+
+
 class WinoPacked:
     """Winograd filters U = G g G^T in fp64 -> fp32, layout [(m+2)^2][CoutPad][C] (csrc/winograd.hip); m = 2: F(2x2,3x3),
     m = 4: F(4x4,3x3) (matrices of Lavin & Gray, interpolation points 0, +-1, +-2, inf)."""
@@ -145,13 +178,24 @@ class WinoPacked:
         up = torch.zeros(a * a, self.CoutPad, Cin, dtype=torch.float32)
         up[:, :Cout] = u.reshape(a * a, Cout, Cin).to(torch.float32)
         self.u = up.to(device).contiguous()
-        self._up_host, self._u3 = up, None
+        self._up_host, self._u3, self._uh2 = up, None, None
 
     def u3(self):
         """[G][3][CoutPad][C] bf16 planes of U for the bf16x3 GEMM tiles."""
         if self._u3 is None:
             self._u3 = split3_planes(self._up_host).to(self.u.device)
         return self._u3
+
+
+def _wino_h2(self):
+    """([G][2][CoutPad][C] fp16 planes of U, [G][CoutPad] inverse row scales) for the fp16x2 GEMM tiles."""
+    if self._uh2 is None:
+        planes, uinv = split2_planes_f16(self._up_host)
+        self._uh2 = (planes.to(self.u.device), uinv.to(self.u.device))
+    return self._uh2
+
+
+WinoPacked.h2 = _wino_h2
 
 
 def wino_eligible(pk, res, segs, act, x_C):
@@ -171,10 +215,11 @@ def pack_module(conv: nn.Conv2d, bn=None, device=None, cin_pad=None) -> Packed:
 
 class T:
     """An NHWC activation living in an arena buffer."""
-    __slots__ = ('buf', 'B', 'H', 'W', 'C')
+    __slots__ = ('buf', 'B', 'H', 'W', 'C', 'slot')
 
-    def __init__(self, buf, B, H, W, C):
+    def __init__(self, buf, B, H, W, C, slot=None):
         self.buf, self.B, self.H, self.W, self.C = buf, B, H, W, C
+        self.slot = slot          # index of the tensor's magnitude bound in Plan.amax (fp16x2 tiles), None: not tracked
 
     @property
     def ptr(self):
@@ -249,7 +294,16 @@ class Plan:
         # YOLACT_AMD_SPLIT=1: the bf16x3 variants of the GEMM tiles (fp32-class products on the bf16 matrix pipe, 6 bf16
         # MFMAs per product at 16x the fp32-MFMA rate, csrc/conv_igemm.hip split8) join the candidates of every Cin % 32
         # == 0 layer and of the Winograd GEMMs; the measurement decides per shape
-        self.split = os.environ.get('YOLACT_AMD_SPLIT', SPLIT_DEFAULT) == '1'
+        # YOLACT_AMD_SPLIT=2 (default): the fp16x2 variants instead — two fp16 pieces by round to nearest, 3 fp16 MFMAs per product
+        # (half the matrix-pipe work of bf16x3, no byte permutes in the split).  Activations are scaled per tensor by a power of
+        # two derived from a magnitude bound that every producing launch records on the device (`self.amax`, one float per
+        # tensor, zeroed at the start of a run and raised atomically by the epilogues: ymi_conv_desc.y_amax / x_amax)
+        smode = os.environ.get('YOLACT_AMD_SPLIT', SPLIT_DEFAULT)
+        self.split = smode == '1'
+        self.h2 = smode == '2'
+        self.mode_key = '|x3' if self.split else '|h2' if self.h2 else ''
+        self.amax = torch.zeros(2048, dtype=torch.float32, device=device)
+        self._nslots = 0
         # YOLACT_AMD_SPLITK=0 keeps every GEMM a single pass (no split-K candidates in the tuner)
         self.splitk = os.environ.get('YOLACT_AMD_SPLITK', '1') == '1'
         self._sk_ws = {}
@@ -273,8 +327,17 @@ class Plan:
             return self.arena_b
         return self.arena
 
-    def _new(self, B, H, W, C) -> T:
-        return T(self._arena().alloc(B * H * W * C), B, H, W, C)
+    def _new(self, B, H, W, C, slot=None) -> T:
+        return T(self._arena().alloc(B * H * W * C), B, H, W, C, slot)
+
+    def _slot(self):
+        """A fresh magnitude-bound slot (index into self.amax)."""
+        self._nslots += 1
+        assert self._nslots <= self.amax.numel()
+        return self._nslots - 1
+
+    def _slot_ptr(self, slot):
+        return self.amax.data_ptr() + 4 * slot
 
     def free(self, t):
         self._arena().free(t)
@@ -303,9 +366,19 @@ class Plan:
         d.cout_alg = pk.cout_alg
         if self.split and dcn_offmask is None:
             d.w_x3 = pk.w3().data_ptr()
+        yslot = self._slot()                    # every launch records the magnitude bound of what it writes (cheap: one atomic
+        d.y_amax = self._slot_ptr(yslot)        # per wave); consumers on fp16x2 tiles read it as x_amax
+        if x.slot is not None:
+            d.x_amax = self._slot_ptr(x.slot)
+        if self.h2 and dcn_offmask is None:
+            assert x.slot is not None, name
+            planes, sc2, winv = pk.h2()
+            d.w_h2, d.scale_h2, d.winv_h2 = planes.data_ptr(), sc2.data_ptr(), winv.data_ptr()
+        self.last_yslot = yslot
         y = None
         if segs is None:
             y = out if out is not None else self._new(x.B, Ho, Wo, pk.Cout)
+            y.slot = yslot
             d.nseg = 1
             d.seg[0] = L.ConvSeg(0, pk.Cout, act, pk.Cout, Ho * Wo * pk.Cout, y.ptr)
         else:
@@ -353,6 +426,12 @@ class Plan:
         d.x, d.u = x.ptr, wp.u.data_ptr()
         if self.split:
             d.u_x3 = wp.u3().data_ptr()
+        if self.h2:
+            planes, uinv = wp.h2()
+            d.u_h2, d.uinv_h2 = planes.data_ptr(), uinv.data_ptr()
+        if x.slot is not None:
+            d.x_amax = self._slot_ptr(x.slot)
+        d.y_amax = self._slot_ptr(self.last_yslot)        # same slot as the direct descriptor of this layer
         if segs is None:
             d.y = y.ptr
         else:
@@ -396,8 +475,9 @@ class Plan:
         ar = self.arena
 
         # input: NCHW fp32 -> NHWC with C padded to 4 (pointer patched per call)
-        x4 = self._new(B, H, W, 4)
+        x4 = self._new(B, H, W, 4, slot=self._slot())
         self.in_args = [None, x4.ptr, B, 3, H, W]
+        self.in_amax = (x4.ptr, B * H * W * 4, self._slot_ptr(x4.slot))    # the input's magnitude bound: ymi_amax_f32
         self.ops.append(('input', None, 'nchw_to_nhwc4', 'A'))
 
         bb = net.backbone
@@ -496,6 +576,7 @@ class Plan:
                     (0, cu.out_channels, L.ACT_RELU, cu.out_channels, hw * cu.out_channels, u.ptr),
                     (cu.out_channels, cu.out_channels + cp.out_channels, L.ACT_RELU, cp.out_channels, hw * cp.out_channels,
                      t0.ptr)])
+                u.slot = t0.slot = self.last_yslot      # one bound (the maximum over both halves) serves both consumers
                 self._merged_p3 = t0
             else:
                 for k, pk in enumerate(up_pk):
@@ -577,7 +658,7 @@ class Plan:
             elif isinstance(m, M.InterpolateModule):
                 s = int(m.scale_factor)
                 has_relu = (i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU))
-                y = self._new(t.B, t.H * s, t.W * s, t.C)
+                y = self._new(t.B, t.H * s, t.W * s, t.C, slot=t.slot)   # convex interpolation: the input's bound holds
                 self.call(lib.ymi_bilinear_nhwc_f32, t.ptr, y.ptr, t.B, t.H, t.W, t.C, y.H, y.W,
                           C.c_float(1.0 / s), C.c_float(1.0 / s), 1 if has_relu else 0, name='proto.interp')
                 self.free(t)
@@ -592,7 +673,7 @@ class Plan:
         stem = self.conv('stem', x4, pack_module(bb.conv1, bb.bn1, dev, cin_pad=4), act=L.ACT_RELU)
         ar.free(x4)
         Hp, Wp = out_size(stem.H, 3, 2, 1), out_size(stem.W, 3, 2, 1)
-        x = self._new(stem.B, Hp, Wp, stem.C)
+        x = self._new(stem.B, Hp, Wp, stem.C, slot=stem.slot)        # max-pooling cannot raise the magnitude bound
         self.call(lib.ymi_maxpool3x3s2_nhwc_f32, stem.ptr, x.ptr, stem.B, stem.H, stem.W, stem.C, Hp, Wp, name='maxpool')
         ar.free(stem)
         outs = []
@@ -709,6 +790,7 @@ class Plan:
         sb = C.c_void_p(self.stream_b.cuda_stream) if two else sa
         proto = torch.empty(self.proto_shape, dtype=torch.float32, device=self.device)
         self.proto_patch.seg[0].ptr = proto.data_ptr()
+        self.amax.zero_()            # magnitude bounds are re-derived by every run (on the caller's stream, ahead of every op)
         # only a module with the reference's timer API (utils/timer.py: start / stop / env) is driven
         if timer is not None and not all(hasattr(timer, a) for a in ('start', 'stop', 'env')):
             timer = None
@@ -738,6 +820,8 @@ class Plan:
             if fn == 'input':
                 a = self.in_args
                 rc = lib.ymi_nchw_to_nhwc4_f32(x.data_ptr(), a[1], a[2], a[3], a[4], a[5], s)
+                if rc == 0:
+                    rc = lib.ymi_amax_f32(self.in_amax[0], self.in_amax[1], self.in_amax[2], s)
             elif fn == 'record':
                 if two:
                     self.events[args].record(self.stream_b if where == 'B' else cur)
@@ -834,7 +918,7 @@ class Plan:
                 continue
             d = dptr.contents
             key = (d.B, d.H, d.W, d.Cin, d.Cout, d.kh, d.kw, d.stride, d.pad, d.res_mode, d.nseg, d.Kpad)
-            skey = str(key) + ('|x3' if self.split else '')
+            skey = str(key) + self.mode_key
             if key not in cache and skey in disk:
                 if self._apply_choice(fn, dptr, where, disk[skey], s) == 0:   # a stale / foreign entry must not make every forward raise
                     cache[key] = int(disk[skey])
@@ -854,15 +938,16 @@ class Plan:
                              L.TILE_32x32_K4, L.TILE_32x32_K4_S4, L.TILE_64x32_K2, L.TILE_64x32_K2_S3,
                              L.TILE_32x64_K2, L.TILE_32x64_K2_S3]
                 else:
-                    cands = [t for t in sorted(L.TILE_NAMES) if t != L.TILE_128x32 and not (t & L.TILE_X3)]
+                    cands = [t for t in sorted(L.TILE_NAMES) if t != L.TILE_128x32 and not (t & (L.TILE_X3 | L.TILE_H2))]
                     if d.Cout < 256:
                         cands = [t for t in cands if t != L.TILE_128x256_W8]
-                if self.split:      # (the Cin = 4 stem loader has the basic tiles only)
-                    cands = cands + [t | L.TILE_X3 for t in cands if t in L.X3_BASE_TILES
+                spflag = L.TILE_X3 if self.split else L.TILE_H2 if self.h2 else 0
+                if spflag:      # (the Cin = 4 stem loader has the basic tiles only)
+                    cands = cands + [t | spflag for t in cands if t in L.X3_BASE_TILES
                                      and (d.Cin % 32 == 0 or t in L.BASIC_TILES)]
                 if self._splitk_ok(d) and self.splitk:
                     # split-K candidates: big tiles whose grid alone cannot fill the chip, K cut 2 / 4 ways
-                    x3 = L.TILE_X3 if self.split else 0
+                    x3 = spflag
                     for S in (2, 4):
                         if (d.Kpad // 32) % S == 0 and d.Kpad // S >= 128:
                             cands += [(t | x3) + 256 * S for t in (L.TILE_128x128, L.TILE_64x128, L.TILE_128x64, L.TILE_64x64,
@@ -902,6 +987,8 @@ class Plan:
                   L.TILE_128x128, L.TILE_128x128_S3, L.TILE_128x128_W8_S3, L.TILE_256x128_W8, L.TILE_256x128_W8_S3]
         if self.split:
             wtiles = wtiles + [t | L.TILE_X3 for t in wtiles]
+        if self.h2:     # fp16x2 GEMM tiles, V either fp32 (split on the fly) or written as fp16 planes by the input transform
+            wtiles = wtiles + [t | L.TILE_H2 for t in wtiles] + [t | L.TILE_H2 | L.WINO_PLANES for t in wtiles]
         memo = {}
         for idx, alts in sorted(self.wino_alt.items()):
             fn, dptr, name, where = self.ops[idx]
@@ -909,14 +996,14 @@ class Plan:
                 continue
             w0 = alts[0]
             key = 'wino' + str((w0.B, w0.H, w0.W, w0.C, w0.Cout, w0.act, w0.nseg, tuple(a.m for a in alts))) + (
-                '|x3' if self.split else '')
+                self.mode_key)
             if key not in memo and key in disk:
                 ent = tuple(disk[key])
                 ok = True
                 if ent[1]:                                 # validate the stored (m, tile) with one launch
                     wd = [a for a in alts if a.m == ent[0]]
                     if wd:
-                        wd[0].tile = int(ent[1])
+                        wd[0].tile, wd[0].v_planes = int(ent[1]) & 255, 1 if int(ent[1]) & L.WINO_PLANES else 0
                         ok = lib.ymi_conv3x3_winograd_f32(C.byref(wd[0]), s) == 0
                     else:
                         ok = False
@@ -942,7 +1029,7 @@ class Plan:
                     best_m, best_t, best_ms, per_m = 0, 0, 1e30, {}
                     for wd in alts:
                         for t in wtiles:
-                            wd.tile = t
+                            wd.tile, wd.v_planes = t & 255, 1 if t & L.WINO_PLANES else 0
                             if lib.ymi_conv3x3_winograd_f32(C.byref(wd), s) != 0:
                                 continue
                             ms = timed(lib.ymi_conv3x3_winograd_f32, C.pointer(wd))
@@ -953,10 +1040,11 @@ class Plan:
                                  round(per_m.get(2, 0.0), 4), round(per_m.get(4, 0.0), 4))
                     disk[key] = list(memo[key])
             best_m, best_t, t_direct, t_wino, t_f2, t_f4 = memo[key]
-            self.wino_table.append((name, 'F%d/%s' % (best_m, L.TILE_NAMES.get(best_t, '-')), t_direct, t_wino, t_f2, t_f4))
+            self.wino_table.append((name, 'F%d/%s%s' % (best_m, L.TILE_NAMES.get(int(best_t) & 255, '-'),
+                                                         'p' if int(best_t) & L.WINO_PLANES else ''), t_direct, t_wino, t_f2, t_f4))
             if best_t and (self.wino_force or t_wino < 0.97 * t_direct):
                 wd = [a for a in alts if a.m == best_m][0]
-                wd.tile = int(best_t)
+                wd.tile, wd.v_planes = int(best_t) & 255, 1 if int(best_t) & L.WINO_PLANES else 0
                 self.ops[idx] = (lib.ymi_conv3x3_winograd_f32, C.pointer(wd), name + '[wino]', where)
 
     def conv_flops(self):
@@ -968,4 +1056,4 @@ class _Borrowed(T):
     __slots__ = ()
 
     def __init__(self, t: T):
-        super().__init__(t.buf, t.B, t.H, t.W, t.C)
+        super().__init__(t.buf, t.B, t.H, t.W, t.C, t.slot)
