@@ -182,7 +182,8 @@ def roofline(net, x, reps=3):
     # matrix-pipe utilisation of the whole engine: time the pipe would need at each launch's own peak / time taken
     eng_ms = sum(v[0] for v in by_kernel.values())
     eng_ideal_ms = sum(v[1] / (kernel_peak(k) * 1e12) * 1e3 for k, v in by_kernel.items())
-    x3_ms = sum(v[0] for k, v in by_kernel.items() if kernel_peak(k) != FP32_MFMA_PEAK_TFLOPS)
+    x3_ms = sum(v[0] for k, v in by_kernel.items() if kernel_peak(k) == X3_PEAK_TFLOPS)
+    h2_ms = sum(v[0] for k, v in by_kernel.items() if kernel_peak(k) == H2_PEAK_TFLOPS)
     wino2 = sum(1 for v in layers.values() if v[2].startswith('winograd F(2x2'))
     wino4 = sum(1 for v in layers.values() if v[2].startswith('winograd F(4x4'))
     tr, tr_src = traffic_from_profiles(name)
@@ -208,6 +209,10 @@ def roofline(net, x, reps=3):
         # continuity with round 1, where every tile ran on the exact-fp32 MFMA: the same achieved rate against THAT peak
         'achieved_vs_fp32_mfma_peak': round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
         'peak_basis': ('fp32 MFMA (v_mfma_f32_32x32x2_f32), 157.3 TFLOP/s' if peak == FP32_MFMA_PEAK_TFLOPS else
+                       'fp16x2 tile: every fp32 operand carried as two fp16 pieces (round to nearest, power-of-two scale per '
+                       'tensor / filter row), 3 piece products per fp32-class product on v_mfma_f32_32x32x16_f16 with fp32 '
+                       'accumulate -> peak = 2500 / 3 = 833.3 TFLOP/s of fp32-equivalent work (executed fp16 FLOPs = 3 x '
+                       'achieved)' if peak == H2_PEAK_TFLOPS else
                        'bf16x3 tile: every fp32 operand split exactly into 3 bf16 pieces, 6 piece products per fp32-class '
                        'product on v_mfma_f32_32x32x16_bf16 with fp32 accumulate -> peak = 2500 / 6 = 416.7 TFLOP/s of '
                        'fp32-equivalent work (executed bf16 FLOPs = 6 x achieved)'),
@@ -229,10 +234,10 @@ def roofline(net, x, reps=3):
                    'frac': round(eng_ideal_ms / eng_ms, 4),
                    'executed_vs_fp32_mfma_peak': round(sum(v[1] for v in by_kernel.values()) / (eng_ms * 1e-3) / 1e12
                                                        / FP32_MFMA_PEAK_TFLOPS, 4),
-                   'x3_share_of_time': round(x3_ms / eng_ms, 3),
+                   'x3_share_of_time': round(x3_ms / eng_ms, 3), 'h2_share_of_time': round(h2_ms / eng_ms, 3),
                    'basis': 'fp32(-equivalent) FLOPs executed by all GEMM launches of a step / their summed durations; frac '
-                            '= matrix-pipe time at each launch\'s own peak (157.3 exact-fp32 tiles, 416.7 bf16x3 tiles) / '
-                            'time taken'},
+                            '= matrix-pipe time at each launch\'s own peak (157.3 exact-fp32 tiles, 416.7 bf16x3 tiles, 833.3 '
+                            'fp16x2 tiles) / time taken'},
         'per_kernel': detail,
     })
     return head, layers
@@ -547,7 +552,13 @@ def main():
                               else 'none (RCCL init failed: %s)' % rccl_error,
                 'roofline': rf,
             }
-            if rf['engine']['x3_share_of_time'] > 0:
+            if rf['engine']['h2_share_of_time'] > 0:
+                result['dtype'] = ('f32 (fp32 in / fp32 accumulate / fp32 out; %.0f %% of the GEMM time on fp16x2 tiles = every fp32 '
+                                   'operand as two fp16 pieces by round to nearest (22 significant bits + 2 signs: exact for ~2/3 of '
+                                   'all fp32 values, one fp32 ulp otherwise), 3 exact piece products per product on the fp16 matrix '
+                                   'pipe; measured against fp64 the error is below the exact-fp32 MFMA kernel\'s own (fp32 accumulation '
+                                   'dominates both); the rest on exact-fp32 MFMA)' % (100 * rf['engine']['h2_share_of_time']))
+            elif rf['engine']['x3_share_of_time'] > 0:
                 result['dtype'] = ('f32 (fp32 in / fp32 accumulate; %.0f %% of the GEMM time on bf16x3 tiles = every fp32 product as 6 '
                                    'exact bf16 piece products on the bf16 matrix pipe, error class of one fp32 rounding; the rest '
                                    'on exact-fp32 MFMA)' % (100 * rf['engine']['x3_share_of_time']))

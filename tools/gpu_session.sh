@@ -25,7 +25,9 @@ for st in "$@"; do
   case "${st%%:*}" in pytestf|py) ;; *) arg="${arg//_/ }" ;; esac      # (_ stands for a space except in file names)
   case "${st%%:*}" in
     build) make -C yolact_amd/csrc -j16 > $O/build.log 2>&1; tail -2 $O/build.log ;;
-    tune) timeout 1500 python tools/make_tune_table.py --fresh --copy-to $O/gfx950.json > $O/tune.log 2>&1; grep -E "plan|table" $O/tune.log | cut -c1-160 | tail -14 ;;
+    tune) timeout 1500 python tools/make_tune_table.py --fresh > $O/tune.log 2>&1      # default arithmetic (fp16x2), every plan
+      for m in 1 0; do YOLACT_AMD_SPLIT=$m timeout 600 python tools/make_tune_table.py --only configs1_r50_b8 r50_b1 r50_b2 >> $O/tune.log 2>&1; done   # bf16x3 / exact-fp32 keys of configs[1]
+      cp yolact_amd/tune/gfx950.json $O/gfx950.json; grep -E "plan|table" $O/tune.log | cut -c1-160 | tail -20 ;;
     tune1) timeout 900 python tools/make_tune_table.py --only configs1_r50_b8 r50_b1 r50_b2 --copy-to $O/gfx950.json > $O/tune.log 2>&1; grep -E "plan|table" $O/tune.log | cut -c1-160 ;;
     pytest) timeout 2400 python -m pytest tests -m gpu -q --timeout 900 -rA ${arg:+-k "$arg"} > $O/pytest.log 2>&1; grep -E "passed|failed" $O/pytest.log | tail -3; grep -E "^FAILED|^ERROR" $O/pytest.log | head -20 ;;
     pytestf) timeout 1200 python -m pytest tests/$arg -m gpu -q --timeout 600 -rA -s > $O/pytest_${arg%.py}.log 2>&1; grep -E "passed|failed" $O/pytest_${arg%.py}.log | tail -3; grep -E "^FAILED|^ERROR" $O/pytest_${arg%.py}.log | head -20 ;;

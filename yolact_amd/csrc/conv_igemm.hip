@@ -143,15 +143,14 @@ __device__ __forceinline__ void bilin_coord(int dst, float scale, int in_size, i
 // General epilogue (multi-segment scatter, unaligned rows, bilinear FPN residual, tanh / sigmoid): one row per loop
 // iteration, NOT unrolled — compact code matters more than ILP here (see the fast path's comment).  Inlined: a real
 // call would impose the callee's register budget and a scratch stack on the whole kernel (occupancy 5 -> 2).
+// Returns the magnitude bound (max |value written|) of this thread; the caller commits it at a CONVERGED point of the wave
+// (the reduction uses cross-lane shuffles, so it must not sit behind the early exit of the lanes past Cout).
 template <int BM, int BN, int WK, int RPT, int RSTEP, bool RES_PREFETCH>
-__device__ __forceinline__ void epilogue_general(const KParams &p, const float *es, f32x4 sc, f32x4 bi, const f32x4 *rpre,
-                                              int m0, int n, int c4, int rbase, bool vec_res, float invA) {
+__device__ __forceinline__ float epilogue_general_rows(const KParams &p, const float *es, f32x4 sc, f32x4 bi, const f32x4 *rpre,
+                                                    int m0, int n, int c4, int rbase, bool vec_res, float invA) {
   constexpr int ELD = BN + 4;
   const ymi_conv_desc &d = p.d;
-  if (n >= d.Cout) {                    // (the commit is wave-collective: lanes past Cout still take part, with 0)
-    if (d.y_amax) ymi_amax_commit(0.f, d.y_amax);
-    return;
-  }
+  if (n >= d.Cout) return 0.f;
   // The segment table lives in the kernel arguments; resolve it with compile-time indices + selects (indexing
   // d.seg[] with a per-lane value turns into dependent per-lane global loads).
   struct SegR { float *ptr; int64_t bs; int rs, act, n0; };
@@ -226,7 +225,14 @@ __device__ __forceinline__ void epilogue_general(const KParams &p, const float *
         if (se[e].ptr != nullptr) se[e].ptr[(size_t)b * se[e].bs + (size_t)pix * se[e].rs + (n + e - se[e].n0)] = o[e];
     }
   }
-  if (d.y_amax) ymi_amax_commit(amax, d.y_amax);
+  return amax;
+}
+
+template <int BM, int BN, int WK, int RPT, int RSTEP, bool RES_PREFETCH>
+__device__ __forceinline__ void epilogue_general(const KParams &p, const float *es, f32x4 sc, f32x4 bi, const f32x4 *rpre,
+                                              int m0, int n, int c4, int rbase, bool vec_res, float invA) {
+  const float am = epilogue_general_rows<BM, BN, WK, RPT, RSTEP, RES_PREFETCH>(p, es, sc, bi, rpre, m0, n, c4, rbase, vec_res, invA);
+  if (p.d.y_amax) ymi_amax_commit(am, p.d.y_amax);
 }
 
 // LOADER: 0 = Cin % 32 == 0 (a K chunk lies inside one filter tap; tap is block-uniform)
