@@ -22,7 +22,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 BENCH="python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary"
 for st in "$@"; do
   arg="${st#*:}"; [ "$arg" = "$st" ] && arg=""
-  case "${st%%:*}" in pytestf|py) ;; *) arg="${arg//_/ }" ;; esac      # (_ stands for a space except in file names)
+  case "${st%%:*}" in pytestf|py) arg="${arg//+/ }" ;; *) arg="${arg//_/ }" ;; esac      # (_ stands for a space; + where names contain _)
   case "${st%%:*}" in
     build) make -C yolact_amd/csrc -j16 > $O/build.log 2>&1; tail -2 $O/build.log ;;
     tune) timeout 1500 python tools/make_tune_table.py --fresh > $O/tune.log 2>&1      # default arithmetic (fp16x2), every plan
@@ -66,7 +66,8 @@ PY
       timeout 300 /tmp/split_probe.bin > $O/split_probe.json 2> $O/probe.err; cat $O/split_probe.json | tr '}' '\n' | cut -c1-230 ;;
     dcnref) timeout 600 python -m pytest tests/test_gpu_dcn_reference.py -m gpu -q -rA -s > $O/dcnref.log 2>&1; tail -5 $O/dcnref.log ;;
     evalpy) timeout 1500 bash tools/run_reference_eval.sh $O > $O/evalpy.log 2>&1; tail -30 $O/evalpy.log ;;
-    py) timeout 900 python $arg > $O/$(basename ${arg%% *} .py).log 2>&1; tail -20 $O/$(basename ${arg%% *} .py).log ;;
+    py) n=$(basename ${arg%% *} .py); k=0; while [ -e $O/$n$k.log ]; do k=$((k+1)); done
+      timeout 900 python $arg > $O/$n$k.log 2>&1; tail -${TAILN:-40} $O/$n$k.log | cut -c1-220 ;;
     *) echo "unknown stage $st" ;;
   esac
 done
