@@ -44,18 +44,38 @@ __host__ __device__ __forceinline__ void ymi_h2_scale(float amax, float &s, floa
 }
 
 // Non-negative floats order like their bit patterns: a device-wide running maximum is one integer atomic.  Every wave of a
-// launch ends here, so the atomic is issued only when the wave's maximum EXCEEDS what the slot already holds (a relaxed
-// device-scope load first): a 38 000-wave launch hammering one address with atomics cost 100 us (session r3s3: the 1x1
-// convolutions at 138^2 went from 80 to 190 us); with the check the expected number of atomics per launch is ~ln(waves).
-// The slot only grows within a run, so a stale (smaller) read can at worst issue a redundant atomic.
+// launch ends here, so (session r3s3 / r3s4 measurements: unconditional atomics on one address cost a 38 000-wave launch
+// 100 us, a load-and-compare per wave on the LDS-crossbar shuffle path still 10 %):
+//   * the wave maximum is formed on the DPP data path (6 VALU steps, no LDS crossbar), the result lands in lane 63;
+//   * lane 63 loads the slot (relaxed, device scope) and issues the atomic only when it would RAISE it — the expected number
+//     of atomics per launch is ~ln(waves); the slot only grows within a run, so a stale read at worst costs a redundant atomic;
+//   * begin / end are separate so that a caller can put its output stores between the load and the compare: the load's
+//     latency then overlaps the store issue instead of extending the wave's lifetime.
+struct ymi_amax_ticket { unsigned bits, cur; };
+__device__ __forceinline__ unsigned ymi_wave_umax63(unsigned v) {
+  auto step = [](unsigned x, unsigned y) { return x > y ? x : y; };
+  v = step(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+  v = step(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4e, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+  v = step(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));   // row_shr:4
+  v = step(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));   // row_shr:8
+  v = step(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1, 3
+  v = step(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2, 3
+  return v;                                                                                 // valid in lane 63
+}
+__device__ __forceinline__ ymi_amax_ticket ymi_amax_begin(float m, const float *slot) {
+  ymi_amax_ticket t;
+  t.bits = ymi_wave_umax63(__builtin_bit_cast(unsigned, fmaxf(m, 0.f)));
+  t.cur = 0xffffffffu;
+  if ((threadIdx.x & 63) == 63 && t.bits != 0)
+    t.cur = __hip_atomic_load(reinterpret_cast<const unsigned *>(slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return t;
+}
+__device__ __forceinline__ void ymi_amax_end(const ymi_amax_ticket &t, float *slot) {
+  if ((threadIdx.x & 63) == 63 && t.bits > t.cur) atomicMax(reinterpret_cast<unsigned *>(slot), t.bits);
+}
 __device__ __forceinline__ void ymi_amax_commit(float m, float *slot) {
-#pragma unroll
-  for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-  if ((threadIdx.x & 63) == 0 && m > 0.f) {
-    const unsigned bits = __builtin_bit_cast(unsigned, m);
-    const unsigned cur = __hip_atomic_load(reinterpret_cast<unsigned *>(slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (bits > cur) atomicMax(reinterpret_cast<unsigned *>(slot), bits);
-  }
+  const ymi_amax_ticket t = ymi_amax_begin(m, slot);
+  ymi_amax_end(t, slot);
 }
 __device__ __forceinline__ float ymi_absmax4(const f32x4 v) {
   return fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));

@@ -1002,21 +1002,25 @@ void conv_igemm_f32(const KParams p) {
         if (after) v += rv;
         o[i] = v;
       }
-      if (n < d.Cout) {
-        float *base = g0.ptr + (size_t)grp * p.y_gs + (size_t)(m0 + rbase) * g0.row_stride + n;
-#pragma unroll
-        for (int i = 0; i < RPT; ++i)
-          if (m0 + rbase + RSTEP * i < p.M) *reinterpret_cast<f32x4 *>(base + (size_t)(RSTEP * i) * g0.row_stride) = o[i];
-      }
-      if (d.y_amax) {                     // block-uniform: every lane takes part in the wave reduction
+      // magnitude bound of the tile (ymi_conv_desc.y_amax): wave reduction + the slot's load BEFORE the stores, the compare
+      // (and the rare atomic) after them — block-uniform condition, every lane takes part
+      ymi_amax_ticket tk = {0u, 0xffffffffu};
+      if (d.y_amax) {
         float am = 0.f;
         if (n < d.Cout) {
 #pragma unroll
           for (int i = 0; i < RPT; ++i)
             if (m0 + rbase + RSTEP * i < p.M) am = fmaxf(am, ymi_absmax4(o[i]));
         }
-        ymi_amax_commit(am, d.y_amax);
+        tk = ymi_amax_begin(am, d.y_amax);
       }
+      if (n < d.Cout) {
+        float *base = g0.ptr + (size_t)grp * p.y_gs + (size_t)(m0 + rbase) * g0.row_stride + n;
+#pragma unroll
+        for (int i = 0; i < RPT; ++i)
+          if (m0 + rbase + RSTEP * i < p.M) *reinterpret_cast<f32x4 *>(base + (size_t)(RSTEP * i) * g0.row_stride) = o[i];
+      }
+      if (d.y_amax) ymi_amax_end(tk, d.y_amax);
     } else {
       epilogue_general<BM, BN, WK, RPT, RSTEP, RES_PREFETCH>(p, es, sc, bi, rpre, m0, n, c4, rbase, vec_res, invA);
     }
