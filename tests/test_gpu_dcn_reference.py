@@ -78,10 +78,14 @@ def test_dcn_hip_and_oracle_match_reference_kernel(shape, stride):
     # (2) the HIP path (gather fused into the implicit-GEMM loader, ymi_dcn_v2_forward_f32) == the reference kernel
     hip = run_conv(x, w, b, None, stride, 1, dcn_offmask=om)
     e_hip = (hip.double() - ref).abs().max().item()
-    print('DCN %s stride %d: %.1f%% zero columns, |ref|max %.3f, oracle err %.2e, HIP err %.2e' % (
-        shape[:5], stride, 100 * outside, scale, e_or, e_hip))
+    # (3) the same launch on the fp16x2 tiles (what the default plan runs for the DCN layers)
+    hip2 = run_conv(x, w, b, None, stride, 1, dcn_offmask=om, tile=L.TILE_64x64 | L.TILE_H2)
+    e_h2 = (hip2.double() - ref).abs().max().item()
+    print('DCN %s stride %d: %.1f%% zero columns, |ref|max %.3f, oracle err %.2e, HIP err %.2e (exact-fp32 tile) %.2e (fp16x2 tile)' % (
+        shape[:5], stride, 100 * outside, scale, e_or, e_hip, e_h2))
     assert e_or <= 2e-5 * max(1.0, scale), e_or
     assert e_hip <= 1e-4 * max(1.0, scale), e_hip
+    assert e_h2 <= 1e-4 * max(1.0, scale), e_h2
 
 
 def test_reference_kernel_zero_offset_identity():

@@ -200,12 +200,16 @@ def _dcn_inputs(seed, B=2, Cc=32, H=9, W=8, Co=48, stride=1):
     return x, w, b, om
 
 
+@pytest.mark.parametrize('tile', [L.TILE_AUTO, L.TILE_64x64 | L.TILE_H2, L.TILE_128x64 | L.TILE_H2, L.TILE_128x128 | L.TILE_H2,
+                                  L.TILE_64x128 | L.TILE_H2])
 @pytest.mark.parametrize('stride', [1, 2])
-def test_dcn_matches_oracle(stride):
+def test_dcn_matches_oracle(stride, tile):
+    """The gather-fused DCN GEMM on the exact-fp32 tiles and on the fp16x2 tiles (the gathered, modulated fp32 tile in LDS is split
+    like any other activation tile; its magnitude is bounded by the input's: convex bilinear weights x a sigmoid)."""
     from gpu_utils import run_conv, rel_err
     from oracle.yolact_oracle import dcn_v2_forward
     x, w, b, om = _dcn_inputs(23 + stride, stride=stride)
-    y = run_conv(x, w, b, None, stride, 1, dcn_offmask=om)
+    y = run_conv(x, w, b, None, stride, 1, dcn_offmask=om, tile=tile)
     ref = dcn_v2_forward(x, om[:, :18], torch.sigmoid(om[:, 18:]), w, b, stride, 1, 1)
     assert rel_err(y, ref) < 2e-5
 

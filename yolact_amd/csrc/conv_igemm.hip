@@ -268,7 +268,7 @@ constexpr int conv_occupancy() {
   constexpr int occ = (160 * 1024) / lds_b;
   // the DCN gather keeps per-tap geometry in registers; the bf16x3 path holds 12 registers of split pieces per 32-row
   // fragment on top of the raw fp32 fragment: budget registers (= blocks per CU) so that neither spills
-  constexpr int cap = (LOADER == 2) ? 3
+  constexpr int cap = (LOADER == 2) ? (PREC == 0 ? 3 : 2)
                       : (PREC >= 1 ? (WM * WN * WK == 8 ? 1 : (TM * TN >= 4 ? 2 : (TM * TN == 2 ? (PREC == 1 ? 2 : 3) : 4))) : 5);
   return occ > cap ? cap : (occ < 1 ? 1 : occ);
 }
@@ -300,7 +300,7 @@ void conv_igemm_f32(const KParams p) {
   static_assert(DMA_PER_STEP * (NS - 2) <= 63, "vmcnt is a 6-bit counter");
   static_assert(WM * WN * WK == 4 || WM * WN * WK == 8, "4 or 8 waves per block");
   static_assert(LOADER != 2 || WK == 1, "DCN gather runs without the K split");
-  static_assert(PREC == 0 || LOADER != 2, "the bf16x3 path exists for the LDS-DMA loaders only");
+  static_assert(PREC == 0 || PREC == 3 || LOADER != 2, "the DCN gather: exact-fp32 or fp16x2 (A split on the fly from the fp32 LDS image)");
   static_assert(!BPL || BN % 16 == 0, "16-bit planes: 16-row DMA pieces");
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
@@ -900,7 +900,7 @@ void conv_igemm_f32(const KParams p) {
       if (LOADER == 2) {
         if (stage) issue_tile(st + 1, cur ^ 1);
         __builtin_amdgcn_sched_barrier(0);
-        compute(cur, false, 0, 0);
+        compute_chunk(cur, false, 0, 0);          // exact-fp32 MFMA, or fp16x2 on the gathered fp32 tile (PREC 3)
       } else if (mine) {
         compute_chunk(cur, stage, st + 1, cur ^ 1);
       } else if (stage) {
@@ -1088,6 +1088,7 @@ int launch_cfg(const KParams &kp, int loader, hipStream_t s, int groups) {
   } else if constexpr (ALL_LOADERS) {   // stem (Cin = 4) and DCN gather loaders: basic tiles only; DCN: exact-fp32 MFMA only
     if (loader == 1) hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, NS, 1, PREC>), dim3(grid, groups), dim3(64 * WM * WN * WK), dyn, s, p);
     else if constexpr (PREC == 0) hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, NS, 2, 0>), dim3(grid, groups), dim3(64 * WM * WN * WK), dyn, s, p);
+    else if constexpr (PREC == 3) hipLaunchKernelGGL((conv_igemm_f32<WM, WN, WK, TM, TN, NS, 2, 3>), dim3(grid, groups), dim3(64 * WM * WN * WK), dyn, s, p);
     else return YMI_EARG;
   } else {
     return YMI_EARG;
@@ -1304,7 +1305,7 @@ int run_conv(const ymi_conv_desc *d, int loader, const float *offmask, int ldo, 
 #endif
   kp.trace = g_trace;
   int tile = d->tile ? d->tile : pick_tile(d);
-  if (loader != 0 && (!tile_all_loaders(tile) || (loader == 2 && (tile & (YMI_TILE_X3 | YMI_TILE_H2))))) {
+  if (loader != 0 && (!tile_all_loaders(tile) || (loader == 2 && (tile & YMI_TILE_X3)))) {
     if (d->tile) return YMI_EARG;   // explicit request the stem / DCN loaders cannot honour
     tile = YMI_TILE_64x64;
   }

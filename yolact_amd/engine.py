@@ -370,7 +370,7 @@ class Plan:
         d.y_amax = self._slot_ptr(yslot)        # per wave); consumers on fp16x2 tiles read it as x_amax
         if x.slot is not None:
             d.x_amax = self._slot_ptr(x.slot)
-        if self.h2 and dcn_offmask is None:
+        if self.h2:                             # (DCN layers too: the gathered fp32 tile is split like any other A tile)
             assert x.slot is not None, name
             planes, sc2, winv = pk.h2()
             d.w_h2, d.scale_h2, d.winv_h2 = planes.data_ptr(), sc2.data_ptr(), winv.data_ptr()
@@ -899,7 +899,7 @@ class Plan:
 
     def _apply_choice(self, fn, dptr, where, val, s):
         """Install a table value (tile id + 256 * split_k) in a descriptor; returns the launch status of one run."""
-        d = dptr.contents
+        d = dptr.contents.conv if fn is self.lib.ymi_dcn_v2_forward_f32 else dptr.contents
         tile, S = int(val) & 255, int(val) >> 8
         d.tile = tile
         if S > 1:
@@ -914,10 +914,11 @@ class Plan:
     def _tune_direct(self, e0, e1, s, reps, disk, measure):
         cache = {}
         for fn, dptr, name, where in self.ops:
-            if fn is not self.lib.ymi_conv2d_nhwc_f32:
+            is_dcn = fn is self.lib.ymi_dcn_v2_forward_f32
+            if fn is not self.lib.ymi_conv2d_nhwc_f32 and not is_dcn:
                 continue
-            d = dptr.contents
-            key = (d.B, d.H, d.W, d.Cin, d.Cout, d.kh, d.kw, d.stride, d.pad, d.res_mode, d.nseg, d.Kpad)
+            d = dptr.contents.conv if is_dcn else dptr.contents
+            key = (d.B, d.H, d.W, d.Cin, d.Cout, d.kh, d.kw, d.stride, d.pad, d.res_mode, d.nseg, d.Kpad) + (('dcn',) if is_dcn else ())
             skey = str(key) + self.mode_key
             if key not in cache and skey in disk:
                 if self._apply_choice(fn, dptr, where, disk[skey], s) == 0:   # a stale / foreign entry must not make every forward raise
@@ -928,7 +929,9 @@ class Plan:
                     cache[key] = L.TILE_AUTO
                     d.tile, d.split_k = L.TILE_AUTO, 0
                     continue
-                if d.Cin % 32 != 0:          # stem loader: basic tiles only
+                if is_dcn:                   # DCN gather loader: basic tiles; the bf16x3 arithmetic does not exist for it
+                    cands = [t for t in L.BASIC_TILES if t != L.TILE_128x32]
+                elif d.Cin % 32 != 0:        # stem loader: basic tiles only
                     cands = [L.TILE_128x64, L.TILE_64x64] if d.Cout <= 64 else list(L.BASIC_TILES)
                 elif d.Cout <= 32:
                     cands = [L.TILE_128x32, L.TILE_64x64, L.TILE_64x64_S3, L.TILE_32x32_K4, L.TILE_32x32_K4_S4,
@@ -941,11 +944,11 @@ class Plan:
                     cands = [t for t in sorted(L.TILE_NAMES) if t != L.TILE_128x32 and not (t & (L.TILE_X3 | L.TILE_H2))]
                     if d.Cout < 256:
                         cands = [t for t in cands if t != L.TILE_128x256_W8]
-                spflag = L.TILE_X3 if self.split else L.TILE_H2 if self.h2 else 0
+                spflag = (L.TILE_X3 if self.split else L.TILE_H2 if self.h2 else 0) if not (is_dcn and self.split) else 0
                 if spflag:      # (the Cin = 4 stem loader has the basic tiles only)
                     cands = cands + [t | spflag for t in cands if t in L.X3_BASE_TILES
                                      and (d.Cin % 32 == 0 or t in L.BASIC_TILES)]
-                if self._splitk_ok(d) and self.splitk:
+                if not is_dcn and self._splitk_ok(d) and self.splitk:
                     # split-K candidates: big tiles whose grid alone cannot fill the chip, K cut 2 / 4 ways
                     x3 = spflag
                     for S in (2, 4):
