@@ -1173,6 +1173,7 @@ int launch_prec(const KParams &kp, int loader, hipStream_t s, int groups) {
   X(YMI_TILE_H2 | YMI_TILE_128x64_S3, 2, 2, 1, 2, 1, 3, false, 3)   \
   X(YMI_TILE_H2 | YMI_TILE_128x128_W8, 4, 2, 1, 1, 2, 2, false, 3)  \
   X(YMI_TILE_H2 | YMI_TILE_256x128_W8, 4, 2, 1, 2, 2, 2, false, 3)  \
+  X(YMI_TILE_H2 | YMI_TILE_128x256_W8, 4, 2, 1, 1, 4, 2, false, 3)  \
   X(YMI_TILE_H2 | YMI_TILE_128x128_S3, 2, 2, 1, 2, 2, 3, false, 3)  \
   X(YMI_TILE_H2 | YMI_TILE_128x128_W8_S3, 4, 2, 1, 1, 2, 3, false, 3) \
   X(YMI_TILE_H2 | YMI_TILE_256x128_W8_S3, 4, 2, 1, 2, 2, 3, false, 3) \

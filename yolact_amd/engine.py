@@ -946,7 +946,8 @@ class Plan:
                         cands = [t for t in cands if t != L.TILE_128x256_W8]
                 spflag = (L.TILE_X3 if self.split else L.TILE_H2 if self.h2 else 0) if not (is_dcn and self.split) else 0
                 if spflag:      # (the Cin = 4 stem loader has the basic tiles only)
-                    cands = cands + [t | spflag for t in cands if t in L.X3_BASE_TILES
+                    base_ok = L.H2_BASE_TILES if spflag == L.TILE_H2 else L.X3_BASE_TILES
+                    cands = cands + [t | spflag for t in cands if t in base_ok
                                      and (d.Cin % 32 == 0 or t in L.BASIC_TILES)]
                 if not is_dcn and self._splitk_ok(d) and self.splitk:
                     # split-K candidates: big tiles whose grid alone cannot fill the chip, K cut 2 / 4 ways
@@ -991,7 +992,8 @@ class Plan:
         if self.split:
             wtiles = wtiles + [t | L.TILE_X3 for t in wtiles]
         if self.h2:     # fp16x2 GEMM tiles, V either fp32 (split on the fly) or written as fp16 planes by the input transform
-            wtiles = wtiles + [t | L.TILE_H2 for t in wtiles] + [t | L.TILE_H2 | L.WINO_PLANES for t in wtiles]
+            hb = wtiles + [L.TILE_128x256_W8]
+            wtiles = wtiles + [t | L.TILE_H2 for t in hb] + [t | L.TILE_H2 | L.WINO_PLANES for t in hb]
         memo = {}
         for idx, alts in sorted(self.wino_alt.items()):
             fn, dptr, name, where = self.ops[idx]
