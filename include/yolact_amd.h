@@ -83,14 +83,18 @@ typedef struct {
    * sW[n] that maps max|w[n,:]| into [2^13, 2^14); plane 0 = fp16(w * sW) (round to nearest), plane 1 = fp16(w * sW - plane 0).
    * scale_h2[n] = scale[n] / sW[n]  (or 1 / sW[n] without a scale): the epilogue's per-channel factor with the filter scale
    * folded in (exact: a power of two).  winv_h2[n] = 1 / sW[n] alone (partial sums of split-K launches).
-   * x_amax: DEVICE scalar holding an upper bound on |x| over the whole input tensor — written by the launch that produced x
-   * (its y_amax) or by ymi_amax_f32; the kernel scales x by the power of two sA that maps x_amax * x_amax_mul into
-   * [2^13, 2^14) before the fp16 split and divides the accumulators by sA.  A bound that is too small can overflow fp16. */
+   * x_amax: DEVICE magnitude-bound slot of the input tensor: YMI_AMAX_SUB (16) floats, YMI_AMAX_STRIDE (64) floats apart
+   * (4 KB per slot), whose MAXIMUM is an upper bound on |x| — raised by the launch that produced x (its y_amax) or by
+   * ymi_amax_f32, zeroed by the caller before that launch; the kernel scales x by the power of two sA that maps
+   * bound * x_amax_mul into [2^13, 2^14) before the fp16 split and divides the accumulators by sA.  A bound that is too small
+   * can overflow fp16.  (Sub-slots: thousands of waves commit to one tensor's bound; spread over 16 cache lines the atomics
+   * of a launch's first residency round cost ~1 us instead of ~50.) */
   const void *w_h2;
   const float *scale_h2;
   const float *winv_h2;
   const float *x_amax;
-  float *y_amax;        /* any tile: DEVICE scalar (or NULL) raised atomically to max|y| over everything this launch writes */
+  float *y_amax;        /* any tile: DEVICE slot (same layout as x_amax) or NULL: raised atomically so that its maximum becomes
+                         * max|y| over everything this launch writes */
   float x_amax_mul;     /* static factor on *x_amax; 0 = 1 */
   int32_t _pad3;
 } ymi_conv_desc;
@@ -169,8 +173,11 @@ typedef struct {
 } ymi_wino_desc;
 int ymi_conv3x3_winograd_f32(const ymi_wino_desc *d, void *stream);
 
-/* *out = max(*out, max_i |x[i]|) over n floats (n % 4 == 0, x 16-byte aligned): the magnitude bound of a tensor that no
- * ymi_conv launch produced (the network input), for ymi_conv_desc.x_amax.  The caller zeroes *out beforehand. */
+/* Raises the magnitude-bound slot `out` (ymi_conv_desc.x_amax layout: 16 sub-slots 64 floats apart, 961 floats in all) to
+ * max_i |x[i]| over n floats (n % 4 == 0, x 16-byte aligned): the bound of a tensor that no ymi_conv launch produced (the
+ * network input).  The caller zeroes the slot beforehand. */
+#define YMI_AMAX_SUB 16
+#define YMI_AMAX_STRIDE 64
 int ymi_amax_f32(const float *x, long n, float *out, void *stream);
 
 /* -- layout / pooling / resize ---------------------------------------------------------- */

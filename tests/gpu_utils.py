@@ -47,9 +47,10 @@ def run_conv(x, weight, bias=None, bn=None, stride=1, pad=0, act=L.ACT_NONE, res
     d.seg[0] = L.ConvSeg(0, pk.Cout, act, pk.Cout, Ho * Wo * pk.Cout, y.data_ptr())
     if (tile & L.TILE_X3) and planes and dcn_offmask is None:
         d.w_x3 = pk.w3().data_ptr()
-    amax = torch.zeros(2, device=DEV)                 # [0]: bound of x (ymi_amax_f32), [1]: what the launch reports for y
+    amax = torch.zeros(2 * 1024, device=DEV)          # two magnitude-bound slots (16 sub-slots, 64 floats apart): [0] bound of x
+                                                      # (ymi_amax_f32), [1] what the launch reports for y
     L.check(L.lib().ymi_amax_f32(xd.data_ptr(), xd.numel(), amax.data_ptr(), L.stream_ptr()), 'amax')
-    d.x_amax, d.y_amax = amax.data_ptr(), amax.data_ptr() + 4
+    d.x_amax, d.y_amax = amax.data_ptr(), amax.data_ptr() + 4096
     if tile & L.TILE_H2:
         hp, sc2, winv = pk.h2()
         d.w_h2, d.scale_h2, d.winv_h2 = hp.data_ptr(), sc2.data_ptr(), winv.data_ptr()
@@ -67,7 +68,7 @@ def run_conv(x, weight, bias=None, bn=None, stride=1, pad=0, act=L.ACT_NONE, res
     else:
         L.check(L.lib().ymi_conv2d_nhwc_f32(C.byref(d), s), 'conv')
     torch.cuda.synchronize()
-    run_conv.last_amax = amax.cpu().tolist()
+    run_conv.last_amax = amax.view(2, 1024).amax(1).cpu().tolist()
     return nchw(y.cpu())
 
 
@@ -107,13 +108,13 @@ def run_wino(x, weight, bias=None, bn=None, act=L.ACT_NONE, tile=L.TILE_AUTO, m=
     d.B, d.H, d.W, d.C, d.Cout, d.act, d.tile, d.m = B, H, W, Cc, Cout, act, tile, m
     if tile & L.TILE_X3:
         d.u_x3 = wp.u3().data_ptr()
-    amax = torch.zeros(2, device=DEV)
+    amax = torch.zeros(2 * 1024, device=DEV)
     L.check(L.lib().ymi_amax_f32(xd.data_ptr(), xd.numel(), amax.data_ptr(), L.stream_ptr()), 'amax')
-    d.x_amax, d.y_amax = amax.data_ptr(), amax.data_ptr() + 4
+    d.x_amax, d.y_amax = amax.data_ptr(), amax.data_ptr() + 4096
     if tile & L.TILE_H2:
         up, uinv = wp.h2()
         d.u_h2, d.uinv_h2, d.v_planes = up.data_ptr(), uinv.data_ptr(), 1 if v_planes else 0
     L.check(L.lib().ymi_conv3x3_winograd_f32(C.byref(d), L.stream_ptr()), 'winograd')
     torch.cuda.synchronize()
-    run_wino.last_amax = amax.cpu().tolist()
+    run_wino.last_amax = amax.view(2, 1024).amax(1).cpu().tolist()
     return nchw(y.cpu())

@@ -41,6 +41,7 @@ def main():
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--tiles', default='')
     ap.add_argument('--shapes', default='')
+    ap.add_argument('--cold', type=int, default=0, help='1: zero the output bound slot before every launch (what a real run sees)')
     ap.add_argument('--amax', type=int, default=1, help='0: launches do not report max|y| (A/B of the epilogue atomic)')
     args = ap.parse_args()
     dev = 'cuda:0'
@@ -69,11 +70,11 @@ def main():
         d.seg[0] = L.ConvSeg(0, Cout, L.ACT_RELU, Cout, Ho * Wo * Cout, y.data_ptr())
         if os.environ.get('PROBE_PLANES', '1') == '1':
             d.w_x3 = pk.w3().data_ptr()          # bf16x3 tiles: pre-split filter planes (PROBE_PLANES=0: split both on the fly)
-        amax = torch.zeros(2, device=dev)        # fp16x2 tiles: filter planes, folded scales, the input's magnitude bound
+        amax = torch.zeros(2 * 1024, device=dev)        # fp16x2 tiles: filter planes, folded scales, the input's magnitude bound
         L.check(lib.ymi_amax_f32(x.data_ptr(), x.numel(), amax.data_ptr(), L.stream_ptr()))
         hp, sc2, winv = pk.h2()
         d.w_h2, d.scale_h2, d.winv_h2, d.x_amax = hp.data_ptr(), sc2.data_ptr(), winv.data_ptr(), amax.data_ptr()
-        d.y_amax = amax.data_ptr() + 4 if args.amax else None
+        d.y_amax = amax.data_ptr() + 4096 if args.amax else None
         fl = lib.ymi_conv_flops(C.byref(d))
         s = L.stream_ptr()
         for t in tiles:
@@ -88,6 +89,8 @@ def main():
                     continue
                 e0.record()
                 for _ in range(args.reps):
+                    if args.cold:
+                        amax[1024:].zero_()
                     lib.ymi_conv2d_nhwc_f32(C.byref(d), s)
                 e1.record()
                 e1.synchronize()

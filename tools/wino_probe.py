@@ -37,7 +37,7 @@ def main():
         pk = Packed(w, torch.randn(Cout, generator=g), None, 1, 1, None, dev)
         x = torch.relu(torch.randn(B, H, W, Cin, generator=g)).to(dev)
         y = torch.empty(B, H, W, Cout, device=dev)
-        amax = torch.zeros(2, device=dev)
+        amax = torch.zeros(2 * 1024, device=dev)
         L.check(lib.ymi_amax_f32(x.data_ptr(), x.numel(), amax.data_ptr(), L.stream_ptr()))
         for m in [int(v) for v in args.m.split(',')]:
             wp = WinoPacked(w, dev, m)
@@ -50,7 +50,7 @@ def main():
             d.B, d.H, d.W, d.C, d.Cout, d.act, d.m = B, H, W, Cin, Cout, L.ACT_RELU, m
             d.u_x3 = wp.u3().data_ptr()
             up, uinv = wp.h2()
-            d.u_h2, d.uinv_h2, d.x_amax, d.y_amax = up.data_ptr(), uinv.data_ptr(), amax.data_ptr(), amax.data_ptr() + 4
+            d.u_h2, d.uinv_h2, d.x_amax, d.y_amax = up.data_ptr(), uinv.data_ptr(), amax.data_ptr(), amax.data_ptr() + 4096
             alg = 2.0 * B * H * W * Cout * 9 * Cin
             for base in [int(t) for t in args.tiles.split(',')]:
                 for label, flag, planes in (('fp32', 0, 0), ('x3', L.TILE_X3, 0), ('h2', L.TILE_H2, 0), ('h2+Vplanes', L.TILE_H2, 1)):

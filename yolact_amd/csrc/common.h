@@ -51,7 +51,14 @@ __host__ __device__ __forceinline__ void ymi_h2_scale(float amax, float &s, floa
 //     of atomics per launch is ~ln(waves); the slot only grows within a run, so a stale read at worst costs a redundant atomic;
 //   * begin / end are separate so that a caller can put its output stores between the load and the compare: the load's
 //     latency then overlaps the store issue instead of extending the wave's lifetime.
-struct ymi_amax_ticket { unsigned bits, cur; };
+//   * a slot is YMI_AMAX_SUB sub-slots, YMI_AMAX_STRIDE floats (one cache line and more) apart; a wave commits to sub-slot
+//     (blockIdx.x + blockIdx.y) % YMI_AMAX_SUB and a reader takes the maximum over all of them (ymi_amax_read).  Every run
+//     starts from zeroed slots, so the first residency round of a launch — thousands of waves finishing together, all seeing
+//     0 — does raise the value with atomics; on ONE address that burst cost the plan 1 ms per step (session r3s6: a probe that
+//     re-launches a layer never sees it, the slot already holds the maximum), spread over 16 lines it is ~1 us.
+#define YMI_AMAX_SUB 16
+#define YMI_AMAX_STRIDE 64
+struct ymi_amax_ticket { unsigned bits, cur; float *sub; };
 __device__ __forceinline__ unsigned ymi_wave_umax63(unsigned v) {
   auto step = [](unsigned x, unsigned y) { return x > y ? x : y; };
   v = step(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
@@ -62,16 +69,24 @@ __device__ __forceinline__ unsigned ymi_wave_umax63(unsigned v) {
   v = step(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2, 3
   return v;                                                                                 // valid in lane 63
 }
-__device__ __forceinline__ ymi_amax_ticket ymi_amax_begin(float m, const float *slot) {
+__device__ __forceinline__ ymi_amax_ticket ymi_amax_begin(float m, float *slot) {
   ymi_amax_ticket t;
   t.bits = ymi_wave_umax63(__builtin_bit_cast(unsigned, fmaxf(m, 0.f)));
   t.cur = 0xffffffffu;
+  t.sub = slot + ((blockIdx.x + blockIdx.y) & (YMI_AMAX_SUB - 1)) * YMI_AMAX_STRIDE;
   if ((threadIdx.x & 63) == 63 && t.bits != 0)
-    t.cur = __hip_atomic_load(reinterpret_cast<const unsigned *>(slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t.cur = __hip_atomic_load(reinterpret_cast<const unsigned *>(t.sub), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return t;
 }
-__device__ __forceinline__ void ymi_amax_end(const ymi_amax_ticket &t, float *slot) {
-  if ((threadIdx.x & 63) == 63 && t.bits > t.cur) atomicMax(reinterpret_cast<unsigned *>(slot), t.bits);
+__device__ __forceinline__ void ymi_amax_end(const ymi_amax_ticket &t, float *) {
+  if ((threadIdx.x & 63) == 63 && t.bits > t.cur) atomicMax(reinterpret_cast<unsigned *>(t.sub), t.bits);
+}
+// The bound a consumer reads: the maximum over the sub-slots (lanes 0 .. YMI_AMAX_SUB-1 load one each; wave-uniform result).
+__device__ __forceinline__ float ymi_amax_read(const float *slot) {
+  unsigned v = 0;
+  if ((threadIdx.x & 63) < YMI_AMAX_SUB) v = reinterpret_cast<const unsigned *>(slot)[(threadIdx.x & 63) * YMI_AMAX_STRIDE];
+  v = ymi_wave_umax63(v);
+  return __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_readlane((int)v, 63));
 }
 __device__ __forceinline__ void ymi_amax_commit(float m, float *slot) {
   const ymi_amax_ticket t = ymi_amax_begin(m, slot);

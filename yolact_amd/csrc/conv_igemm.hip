@@ -328,7 +328,7 @@ void conv_igemm_f32(const KParams p) {
   // fp16x2: the power-of-two scale of the activation operand, from the producer's magnitude bound (ymi_h2_scale)
   float sA = 1.f, invA = 1.f;
   if (H2) {
-    float xam = d.x_amax ? *d.x_amax : 0.f;
+    float xam = d.x_amax ? ymi_amax_read(d.x_amax) : 0.f;
     if (d.x_amax_mul != 0.f) xam *= d.x_amax_mul;
     ymi_h2_scale(xam, sA, invA);
   }

@@ -48,7 +48,7 @@ template <bool PLANES>
 __global__ __launch_bounds__(256) void wino_in_k(const float *__restrict__ x, float *__restrict__ V, int H, int W, int C4,
                                                  int th, int tw, long T, long total, const float *__restrict__ x_amax) {
   float vs = 1.f, vinv = 1.f;
-  if (PLANES) ymi_h2_scale(*x_amax * 4.f, vs, vinv);
+  if (PLANES) ymi_h2_scale(ymi_amax_read(x_amax) * 4.f, vs, vinv);
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
     const int c4 = (int)(i % C4);
     const long t = i / C4;
@@ -304,7 +304,7 @@ template <bool PLANES>
 __global__ __launch_bounds__(256) void wino43_in_k(const float *__restrict__ x, float *__restrict__ V, int H, int W, int C4,
                                                    int th, int tw, long T, long total, const float *__restrict__ x_amax) {
   float vs = 1.f, vinv = 1.f;
-  if (PLANES) ymi_h2_scale(*x_amax * 100.f, vs, vinv);
+  if (PLANES) ymi_h2_scale(ymi_amax_read(x_amax) * 100.f, vs, vinv);
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
     const int c4 = (int)(i % C4);
     const long t = i / C4;

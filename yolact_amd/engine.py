@@ -27,6 +27,7 @@ def _ceil(a, b):
 # ---- shipped tile / algorithm table ------------------------------------------------------------------------------
 SPLIT_DEFAULT = '2'   # default of YOLACT_AMD_SPLIT (see Plan.__init__): 0 exact-fp32 MFMA, 1 bf16x3, 2 fp16x2
 TUNE_GEN = 4          # bump whenever tile ids or kernel variants change meaning: older tables are ignored
+AMAX_SLOT_FLOATS = 16 * 64   # one magnitude-bound slot: YMI_AMAX_SUB sub-slots, YMI_AMAX_STRIDE floats apart (include/yolact_amd.h)
 TUNE_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tune')
 _table_cache = {}
 
@@ -302,7 +303,7 @@ class Plan:
         self.split = smode == '1'
         self.h2 = smode == '2'
         self.mode_key = '|x3' if self.split else '|h2' if self.h2 else ''
-        self.amax = torch.zeros(2048, dtype=torch.float32, device=device)
+        self.amax = torch.zeros(512 * AMAX_SLOT_FLOATS, dtype=torch.float32, device=device)     # 2 MB: 512 slots
         self._nslots = 0
         # YOLACT_AMD_SPLITK=0 keeps every GEMM a single pass (no split-K candidates in the tuner)
         self.splitk = os.environ.get('YOLACT_AMD_SPLITK', '1') == '1'
@@ -333,11 +334,15 @@ class Plan:
     def _slot(self):
         """A fresh magnitude-bound slot (index into self.amax)."""
         self._nslots += 1
-        assert self._nslots <= self.amax.numel()
+        assert self._nslots * AMAX_SLOT_FLOATS <= self.amax.numel()
         return self._nslots - 1
 
     def _slot_ptr(self, slot):
-        return self.amax.data_ptr() + 4 * slot
+        return self.amax.data_ptr() + 4 * AMAX_SLOT_FLOATS * slot
+
+    def bound(self, slot):
+        """Host read of a slot's value (diagnostics / tests): the maximum over its sub-slots."""
+        return float(self.amax[slot * AMAX_SLOT_FLOATS:(slot + 1) * AMAX_SLOT_FLOATS].max())
 
     def free(self, t):
         self._arena().free(t)
@@ -964,11 +969,16 @@ class Plan:
                 for t in cands:                       # warm every candidate once (code fetch, clocks); skip the
                     if self._apply_choice(fn, dptr, where, t, s) == 0:        # ones this layer cannot use
                         ok_cands.append(t)
+                # the launch's own magnitude-bound slot is zeroed before every timed launch, as at the start of a real run:
+                # a slot that already holds the maximum hides the atomics of the first residency round
+                yslot = self.amax[(d.y_amax - self.amax.data_ptr()) // 4:][:AMAX_SLOT_FLOATS] if d.y_amax else None
                 for rnd in range(2):                  # two interleaved rounds, keep each tile's best time: a single
                     for t in ok_cands:                # noisy sample used to flip near-ties and move bench by +-3 %
                         self._apply_choice(fn, dptr, where, t, s)
                         e0.record()
                         for _ in range(reps):
+                            if yslot is not None:
+                                yslot.zero_()
                             fn(dptr, s)
                         e1.record()
                         e1.synchronize()
