@@ -51,8 +51,8 @@ __host__ __device__ __forceinline__ void ymi_h2_scale(float amax, float &s, floa
 //     of atomics per launch is ~ln(waves); the slot only grows within a run, so a stale read at worst costs a redundant atomic;
 //   * begin / end are separate so that a caller can put its output stores between the load and the compare: the load's
 //     latency then overlaps the store issue instead of extending the wave's lifetime.
-//   * a slot is YMI_AMAX_SUB sub-slots, YMI_AMAX_STRIDE floats (one cache line and more) apart; a wave commits to sub-slot
-//     (blockIdx.x + blockIdx.y) % YMI_AMAX_SUB and a reader takes the maximum over all of them (ymi_amax_read).  Every run
+//   * a slot is YMI_AMAX_SUB sub-slots, YMI_AMAX_STRIDE floats (one cache line and more) apart; a wave commits to the
+//     sub-slot of its XCD (below) and a reader takes the maximum over all of them (ymi_amax_read).  Every run
 //     starts from zeroed slots, so the first residency round of a launch — thousands of waves finishing together, all seeing
 //     0 — does raise the value with atomics; on ONE address that burst cost the plan 1 ms per step (session r3s6: a probe that
 //     re-launches a layer never sees it, the slot already holds the maximum), spread over 16 lines it is ~1 us.
@@ -73,13 +73,20 @@ __device__ __forceinline__ ymi_amax_ticket ymi_amax_begin(float m, float *slot) 
   ymi_amax_ticket t;
   t.bits = ymi_wave_umax63(__builtin_bit_cast(unsigned, fmaxf(m, 0.f)));
   t.cur = 0xffffffffu;
-  t.sub = slot + ((blockIdx.x + blockIdx.y) & (YMI_AMAX_SUB - 1)) * YMI_AMAX_STRIDE;
+  // sub-slot = 2 * (the XCD this wave runs on) + one grid bit: a sub-slot is only ever touched from ONE XCD, so both the
+  // load and the atomic can be XCD-local operations on that XCD's L2 (workgroup scope: no sc1, i.e. not forced out to the
+  // memory-side coherence point the way device-scope accesses are on a multi-XCD part — 38 000 device-scope LOADS of 16 lines
+  // still cost an 80 us launch 18 us, session r3s7).  The kernel-end release writes the L2 lines back, the consumer's
+  // kernel-start acquire re-reads them: the ordinary path of every global store.
+  const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;     // HW_REG_XCC_ID[3:0]
+  t.sub = slot + (2 * xcc + ((blockIdx.x + blockIdx.y) & 1)) * YMI_AMAX_STRIDE;
   if ((threadIdx.x & 63) == 63 && t.bits != 0)
-    t.cur = __hip_atomic_load(reinterpret_cast<const unsigned *>(t.sub), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t.cur = __hip_atomic_load(reinterpret_cast<const unsigned *>(t.sub), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   return t;
 }
 __device__ __forceinline__ void ymi_amax_end(const ymi_amax_ticket &t, float *) {
-  if ((threadIdx.x & 63) == 63 && t.bits > t.cur) atomicMax(reinterpret_cast<unsigned *>(t.sub), t.bits);
+  if ((threadIdx.x & 63) == 63 && t.bits > t.cur)
+    __hip_atomic_fetch_max(reinterpret_cast<unsigned *>(t.sub), t.bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // The bound a consumer reads: the maximum over the sub-slots (lanes 0 .. YMI_AMAX_SUB-1 load one each; wave-uniform result).
 __device__ __forceinline__ float ymi_amax_read(const float *slot) {
