@@ -43,22 +43,22 @@ __host__ __device__ __forceinline__ void ymi_h2_scale(float amax, float &s, floa
   inv = __builtin_bit_cast(float, (unsigned)(254 - es) << 23);
 }
 
-// Non-negative floats order like their bit patterns: a device-wide running maximum is one integer atomic.  Every wave of a
-// launch ends here, so (session r3s3 / r3s4 measurements: unconditional atomics on one address cost a 38 000-wave launch
-// 100 us, a load-and-compare per wave on the LDS-crossbar shuffle path still 10 %):
-//   * the wave maximum is formed on the DPP data path (6 VALU steps, no LDS crossbar), the result lands in lane 63;
-//   * lane 63 loads the slot (relaxed, device scope) and issues the atomic only when it would RAISE it — the expected number
-//     of atomics per launch is ~ln(waves); the slot only grows within a run, so a stale read at worst costs a redundant atomic;
-//   * begin / end are separate so that a caller can put its output stores between the load and the compare: the load's
-//     latency then overlaps the store issue instead of extending the wave's lifetime.
-//   * a slot is YMI_AMAX_SUB sub-slots, YMI_AMAX_STRIDE floats (one cache line and more) apart; a wave commits to the
-//     sub-slot of its XCD (below) and a reader takes the maximum over all of them (ymi_amax_read).  Every run
-//     starts from zeroed slots, so the first residency round of a launch — thousands of waves finishing together, all seeing
-//     0 — does raise the value with atomics; on ONE address that burst cost the plan 1 ms per step (session r3s6: a probe that
-//     re-launches a layer never sees it, the slot already holds the maximum), spread over 16 lines it is ~1 us.
+// Magnitude-bound slots (ymi_conv_desc.x_amax / y_amax).  Non-negative floats order like their bit patterns, so a running
+// maximum is one integer atomic; but EVERY wave of a producing launch ends with one, and every run starts from zeroed slots.
+// What the measurements of round 3 forced (sessions r3s3 .. r3s8):
+//   * unconditional device-scope atomics on one address: a 38 000-wave launch went from 80 to 190 us;
+//   * compare first, atomic only when it would RAISE the value: fine for a probe that re-launches a layer (the slot already
+//     holds the maximum), but in a real run the first residency round of every launch sees 0 and bursts: +1 ms per step;
+//   * device-scope LOADS for that compare are not free either on a multi-XCD part (they go to the memory-side coherence
+//     point): 38 000 of them on 16 lines cost 18 us;
+// hence: a slot is YMI_AMAX_SUB sub-slots, YMI_AMAX_STRIDE floats (their own cache lines) apart; a wave only touches the
+// sub-slot of the XCD it runs on, with XCD-local (workgroup-scope) operations on that XCD's L2; the current value is loaded at
+// the START of the kernel (latency hidden), the wave maximum is formed on the DPP data path (6 VALU steps, no LDS crossbar),
+// and the atomic — fire and forget — is issued only if it raises what the prefetch saw.  A reader takes the maximum over the
+// sub-slots (ymi_amax_read).
 #define YMI_AMAX_SUB 16
 #define YMI_AMAX_STRIDE 64
-struct ymi_amax_ticket { unsigned bits, cur; float *sub; };
+struct ymi_amax_pre { float *sub; unsigned cur; };
 __device__ __forceinline__ unsigned ymi_wave_umax63(unsigned v) {
   auto step = [](unsigned x, unsigned y) { return x > y ? x : y; };
   v = step(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
@@ -69,24 +69,29 @@ __device__ __forceinline__ unsigned ymi_wave_umax63(unsigned v) {
   v = step(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2, 3
   return v;                                                                                 // valid in lane 63
 }
-__device__ __forceinline__ ymi_amax_ticket ymi_amax_begin(float m, float *slot) {
-  ymi_amax_ticket t;
-  t.bits = ymi_wave_umax63(__builtin_bit_cast(unsigned, fmaxf(m, 0.f)));
-  t.cur = 0xffffffffu;
-  // sub-slot = 2 * (the XCD this wave runs on) + one grid bit: a sub-slot is only ever touched from ONE XCD, so both the
-  // load and the atomic can be XCD-local operations on that XCD's L2 (workgroup scope: no sc1, i.e. not forced out to the
-  // memory-side coherence point the way device-scope accesses are on a multi-XCD part — 38 000 device-scope LOADS of 16 lines
-  // still cost an 80 us launch 18 us, session r3s7).  The kernel-end release writes the L2 lines back, the consumer's
-  // kernel-start acquire re-reads them: the ordinary path of every global store.
+// At the START of a kernel: pick the sub-slot and load what it holds (lane 63 only; the latency hides behind the kernel's
+// own prologue / main loop).  slot == nullptr: the launch reports nothing.
+//   sub-slot = 2 * (the XCD this wave runs on) + one grid bit: a sub-slot is only ever touched from ONE XCD, so both the load
+//   and the atomic are XCD-local operations on that XCD's L2 (workgroup scope: not forced out to the memory-side coherence
+//   point the way device-scope accesses are on a multi-XCD part — 38 000 device-scope LOADS of 16 lines still cost an 80 us
+//   launch 18 us, session r3s7).  The kernel-end release writes the L2 lines back, the consumer's kernel-start acquire
+//   re-reads them: the ordinary path of every global store.
+__device__ __forceinline__ ymi_amax_pre ymi_amax_prefetch(float *slot) {
+  ymi_amax_pre p;
   const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;     // HW_REG_XCC_ID[3:0]
-  t.sub = slot + (2 * xcc + ((blockIdx.x + blockIdx.y) & 1)) * YMI_AMAX_STRIDE;
-  if ((threadIdx.x & 63) == 63 && t.bits != 0)
-    t.cur = __hip_atomic_load(reinterpret_cast<const unsigned *>(t.sub), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  return t;
+  p.sub = slot ? slot + (2 * xcc + ((blockIdx.x + blockIdx.y) & 1)) * YMI_AMAX_STRIDE : nullptr;
+  p.cur = 0xffffffffu;
+  if (slot && (threadIdx.x & 63) == 63)
+    p.cur = __hip_atomic_load(reinterpret_cast<const unsigned *>(p.sub), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  return p;
 }
-__device__ __forceinline__ void ymi_amax_end(const ymi_amax_ticket &t, float *) {
-  if ((threadIdx.x & 63) == 63 && t.bits > t.cur)
-    __hip_atomic_fetch_max(reinterpret_cast<unsigned *>(t.sub), t.bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+// At the END (a converged point of the wave): wave maximum on the DPP path, then the atomic — fire and forget, no returned
+// value to wait for — only if it RAISES what the prefetch saw.  The value seen may be stale (lower): that costs a redundant
+// atomic, never a wrong bound; blocks that start after the first residency round see an almost final value and stay silent.
+__device__ __forceinline__ void ymi_amax_finish(const ymi_amax_pre &p, float m) {
+  const unsigned bits = ymi_wave_umax63(__builtin_bit_cast(unsigned, fmaxf(m, 0.f)));
+  if ((threadIdx.x & 63) == 63 && bits > p.cur)
+    __hip_atomic_fetch_max(reinterpret_cast<unsigned *>(p.sub), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // The bound a consumer reads: the maximum over the sub-slots (lanes 0 .. YMI_AMAX_SUB-1 load one each; wave-uniform result).
 __device__ __forceinline__ float ymi_amax_read(const float *slot) {
@@ -94,10 +99,6 @@ __device__ __forceinline__ float ymi_amax_read(const float *slot) {
   if ((threadIdx.x & 63) < YMI_AMAX_SUB) v = reinterpret_cast<const unsigned *>(slot)[(threadIdx.x & 63) * YMI_AMAX_STRIDE];
   v = ymi_wave_umax63(v);
   return __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_readlane((int)v, 63));
-}
-__device__ __forceinline__ void ymi_amax_commit(float m, float *slot) {
-  const ymi_amax_ticket t = ymi_amax_begin(m, slot);
-  ymi_amax_end(t, slot);
 }
 __device__ __forceinline__ float ymi_absmax4(const f32x4 v) {
   return fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));

@@ -230,9 +230,9 @@ __device__ __forceinline__ float epilogue_general_rows(const KParams &p, const f
 
 template <int BM, int BN, int WK, int RPT, int RSTEP, bool RES_PREFETCH>
 __device__ __forceinline__ void epilogue_general(const KParams &p, const float *es, f32x4 sc, f32x4 bi, const f32x4 *rpre,
-                                              int m0, int n, int c4, int rbase, bool vec_res, float invA) {
+                                              int m0, int n, int c4, int rbase, bool vec_res, float invA, const ymi_amax_pre &apre) {
   const float am = epilogue_general_rows<BM, BN, WK, RPT, RSTEP, RES_PREFETCH>(p, es, sc, bi, rpre, m0, n, c4, rbase, vec_res, invA);
-  if (p.d.y_amax) ymi_amax_commit(am, p.d.y_amax);
+  if (p.d.y_amax) ymi_amax_finish(apre, am);
 }
 
 // LOADER: 0 = Cin % 32 == 0 (a K chunk lies inside one filter tap; tap is block-uniform)
@@ -332,6 +332,8 @@ void conv_igemm_f32(const KParams p) {
     if (d.x_amax_mul != 0.f) xam *= d.x_amax_mul;
     ymi_h2_scale(xam, sA, invA);
   }
+  // magnitude bound of the output (y_amax): what the slot holds NOW, fetched here so that the epilogue need not wait for it
+  const ymi_amax_pre apre = ymi_amax_prefetch(d.y_amax);
 
   // ---- epilogue thread mapping + residual prefetch -----------------------------------------------
   // Each thread owns 4 consecutive output channels of RPT rows.  A plain residual (bottleneck shortcut) is fetched
@@ -1002,27 +1004,23 @@ void conv_igemm_f32(const KParams p) {
         if (after) v += rv;
         o[i] = v;
       }
-      // magnitude bound of the tile (ymi_conv_desc.y_amax): wave reduction + the slot's load BEFORE the stores, the compare
-      // (and the rare atomic) after them — block-uniform condition, every lane takes part
-      ymi_amax_ticket tk = {0u, 0xffffffffu};
-      if (d.y_amax) {
-        float am = 0.f;
-        if (n < d.Cout) {
-#pragma unroll
-          for (int i = 0; i < RPT; ++i)
-            if (m0 + rbase + RSTEP * i < p.M) am = fmaxf(am, ymi_absmax4(o[i]));
-        }
-        tk = ymi_amax_begin(am, d.y_amax);
-      }
       if (n < d.Cout) {
         float *base = g0.ptr + (size_t)grp * p.y_gs + (size_t)(m0 + rbase) * g0.row_stride + n;
 #pragma unroll
         for (int i = 0; i < RPT; ++i)
           if (m0 + rbase + RSTEP * i < p.M) *reinterpret_cast<f32x4 *>(base + (size_t)(RSTEP * i) * g0.row_stride) = o[i];
       }
-      if (d.y_amax) ymi_amax_end(tk, d.y_amax);
+      if (d.y_amax) {                     // magnitude bound of the tile: block-uniform condition, every lane takes part
+        float am = 0.f;
+        if (n < d.Cout) {
+#pragma unroll
+          for (int i = 0; i < RPT; ++i)
+            if (m0 + rbase + RSTEP * i < p.M) am = fmaxf(am, ymi_absmax4(o[i]));
+        }
+        ymi_amax_finish(apre, am);
+      }
     } else {
-      epilogue_general<BM, BN, WK, RPT, RSTEP, RES_PREFETCH>(p, es, sc, bi, rpre, m0, n, c4, rbase, vec_res, invA);
+      epilogue_general<BM, BN, WK, RPT, RSTEP, RES_PREFETCH>(p, es, sc, bi, rpre, m0, n, c4, rbase, vec_res, invA, apre);
     }
   }
   if (p.trace && t == 0) {
@@ -1342,6 +1340,7 @@ __global__ __launch_bounds__(256) void splitk_fixup_k(const float *__restrict__ 
                                                       int act, int res_after_act, float *__restrict__ y_amax) {
   const long total = M * N4;
   float am = 0.f;
+  const ymi_amax_pre apre = ymi_amax_prefetch(y_amax);
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
     const long m = i / N4;
     const int n = (int)(i - m * N4) * 4;
@@ -1360,7 +1359,7 @@ __global__ __launch_bounds__(256) void splitk_fixup_k(const float *__restrict__ 
     am = fmaxf(am, ymi_absmax4(v));
     *reinterpret_cast<f32x4 *>(y + m * ldy + n) = v;
   }
-  if (y_amax) ymi_amax_commit(am, y_amax);
+  if (y_amax) ymi_amax_finish(apre, am);
 }
 
 int ymi_internal_prof_begin_fwd(double flops, int tile, int kind, hipStream_t s);

@@ -115,9 +115,10 @@ namespace {
 // floats order like their bit patterns).  Feeds ymi_conv_desc.x_amax for tensors no conv launch produced (the network input).
 __global__ __launch_bounds__(256) void amax_k(const float *__restrict__ x, long n4, float *__restrict__ out) {
   float am = 0.f;
+  const ymi_amax_pre apre = ymi_amax_prefetch(out);
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256L)
     am = fmaxf(am, ymi_absmax4(*reinterpret_cast<const f32x4 *>(x + 4 * i)));
-  ymi_amax_commit(am, out);
+  ymi_amax_finish(apre, am);
 }
 }  // namespace
 

@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void wino_out_k(const float *__restrict__ Mm, 
                                                   int Wo, int N4, int th, int tw, long T, int act, long total,
                                                   float *__restrict__ y_amax) {
   float am = 0.f;
+  const ymi_amax_pre apre = ymi_amax_prefetch(y_amax);
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
     const int n4 = (int)(i % N4);
     const long t = i / N4;
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(256) void wino_out_k(const float *__restrict__ Mm, 
       }
     }
   }
-  if (y_amax) ymi_amax_commit(am, y_amax);
+  if (y_amax) ymi_amax_finish(apre, am);
 }
 
 // Same output transform, scattering to up to 3 output segments with their own strides / activations (the shared
@@ -211,6 +212,7 @@ __global__ __launch_bounds__(256) void wino_out_seg_k(const float *__restrict__ 
                                                       const float *__restrict__ scale, const float *__restrict__ bias,
                                                       int Ho, int Wo, int N4, int Cout, int th, int tw, long T, long total, float *__restrict__ y_amax) {
   float am = 0.f;
+  const ymi_amax_pre apre = ymi_amax_prefetch(y_amax);
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
     const int n4 = (int)(i % N4);
     const long t = i / N4;
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(256) void wino_out_seg_k(const float *__restrict__ 
       }
     }
   }
-  if (y_amax) ymi_amax_commit(am, y_amax);
+  if (y_amax) ymi_amax_finish(apre, am);
 }
 
 // ---- F(4x4, 3x3): 36 multiplications per 4x4 output tile instead of 144 (4x fewer MFMA FLOPs than direct, 1.78x fewer
@@ -373,6 +375,7 @@ __global__ __launch_bounds__(256) void wino43_out_k(const float *__restrict__ Mm
                                                     int Wo, int N4, int th, int tw, long T, int act, long total,
                                                     float *__restrict__ y_amax) {
   float am = 0.f;
+  const ymi_amax_pre apre = ymi_amax_prefetch(y_amax);
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
     const int n4 = (int)(i % N4);
     const long t = i / N4;
@@ -402,13 +405,14 @@ __global__ __launch_bounds__(256) void wino43_out_k(const float *__restrict__ Mm
       }
     }
   }
-  if (y_amax) ymi_amax_commit(am, y_amax);
+  if (y_amax) ymi_amax_finish(apre, am);
 }
 
 __global__ __launch_bounds__(256) void wino43_out_seg_k(const float *__restrict__ Mm, const SegTab st,
                                                         const float *__restrict__ scale, const float *__restrict__ bias,
                                                         int Ho, int Wo, int N4, int Cout, int th, int tw, long T, long total, float *__restrict__ y_amax) {
   float am = 0.f;
+  const ymi_amax_pre apre = ymi_amax_prefetch(y_amax);
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
     const int n4 = (int)(i % N4);
     const long t = i / N4;
@@ -457,7 +461,7 @@ __global__ __launch_bounds__(256) void wino43_out_seg_k(const float *__restrict_
       }
     }
   }
-  if (y_amax) ymi_amax_commit(am, y_amax);
+  if (y_amax) ymi_amax_finish(apre, am);
 }
 
 unsigned grid_for(long total) {
