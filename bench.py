@@ -442,6 +442,9 @@ def main():
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    if world > 1:                                     # one launch loop per GPU: give each rank its own slice of the host's CPUs
+        from yolact_amd import parallel as _par
+        _par.pin_rank_affinity(local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', world)))
     rccl_error = None
     if launched:
         dist.init_process_group('nccl', device_id=dev)                                 # RCCL over xGMI
@@ -472,11 +475,12 @@ def main():
         # --no-pipeline restores the launch / blocking read / launch sequence.
         host_counts = [torch.empty(args.batch * world, dtype=torch.float32, pin_memory=True) for _ in range(2)]
         turn = {'i': 0}
+        gatherer = parallel.RecordGatherer(0)        # persistent receive buffers: no allocation, no torch.cat per step
 
         def launch():
             out = net.forward_device(x)
-            rec = parallel.gather_records(parallel.pack_records(out), dst=0, rows_per_rank=args.batch,
-                                          force_collective=have_pg)
+            # pack_records = the record tensor the Detect selection kernel wrote itself (no torch op)
+            rec = gatherer(parallel.pack_records(out), args.batch, force_collective=have_pg)
             handle = None
             if rec is not None:
                 buf = host_counts[turn['i'] & 1]

@@ -234,6 +234,9 @@ typedef struct {
   int64_t *out_class;   /* [B,cap] */
   float *out_coef;      /* [B,cap,D] */
   int32_t *out_prior;   /* [B,cap] index of the source prior (parity checks) */
+  float *out_rec;       /* optional [B, 1 + cap*(6+D)]: the same detections as ONE fixed-size fp32 record per image — count, then per
+                         * detection box 4 | score | class | coef D — i.e. the payload of the data-parallel gather
+                         * (yolact_amd/parallel.py) written by the selection kernel itself; rows past the count are left untouched */
 } ymi_detect_desc;
 int ymi_detect_f32(const ymi_detect_desc *d, void *stream);
 

@@ -27,6 +27,30 @@ def test_world1_nccl_gather_roundtrip_equals_detect_finish():
         assert dist.get_backend() == 'nccl' and dist.get_world_size() == 1
         dev_out = net.forward_device(x)
         rec = parallel.pack_records(dev_out)
+        # the record tensor is what the Detect selection kernel wrote itself (ymi_detect_desc.out_rec): valid rows equal the
+        # cat / cast form built from the separate outputs
+        assert rec is dev_out['rec']
+        legacy = parallel.pack_records({k: v for k, v in dev_out.items() if k != 'rec'})
+        cnt = dev_out['count'].tolist()
+        L_ = 6 + dev_out['coef'].shape[2]
+        for b, n in enumerate(cnt):
+            assert torch.equal(rec[b, :1 + n * L_], legacy[b, :1 + n * L_]), b
+        # persistent-buffer gatherer (what bench.py and Yolact.forward_sharded use): same bytes, same storage every step
+        gat = parallel.RecordGatherer(0)
+        g1 = gat(rec, rec.shape[0], force_collective=True)
+        p1 = g1.data_ptr()
+        g2 = gat(rec, rec.shape[0], force_collective=True)
+        torch.cuda.synchronize()
+        assert g2.data_ptr() == p1 and torch.equal(g2, rec)
+        sharded = net.forward_sharded(x)
+        ref0 = net.detect.finish(dev_out, dev_out['proto'], net)
+        assert len(sharded) == len(ref0)
+        for a, r in zip(sharded, ref0):
+            assert (a['detection'] is None) == (r['detection'] is None)
+            if a['detection'] is not None:
+                assert torch.equal(a['detection']['box'], r['detection']['box'])
+                assert torch.equal(a['detection']['class'], r['detection']['class'])
+                assert a['detection']['proto'].shape == r['detection']['proto'].shape
         same = parallel.gather_records(rec, dst=0)                         # world 1, not forced: passthrough
         assert same is rec
         got = parallel.gather_records(rec, dst=0, force_collective=True)   # the real collective, one rank

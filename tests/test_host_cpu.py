@@ -79,7 +79,7 @@ def test_struct_sizes_match_header():
     assert ctypes.sizeof(L.ConvSeg) == 32
     assert ctypes.sizeof(L.ConvDesc) == 5 * 8 + 22 * 4 + 3 * 32 + 16 + 8 + 5 * 8 + 8      # + fp16x2 planes / scales / amax slots
     assert ctypes.sizeof(L.DcnDesc) == ctypes.sizeof(L.ConvDesc) + 16
-    assert ctypes.sizeof(L.DetectDesc) == 4 * 8 + 7 * 4 + 2 * 4 + 4 + 2 * 4 + 13 * 8
+    assert ctypes.sizeof(L.DetectDesc) == 4 * 8 + 7 * 4 + 2 * 4 + 4 + 2 * 4 + 14 * 8
 
 
 def test_product_path_rejects_cpu_tensors():
@@ -234,3 +234,76 @@ def test_head_gemm_is_padded_for_vector_stores_but_accounted_algorithmically(con
                [s.n1 - s.n0 for s in segs].count(anchors * 84) == 1            # loc | conf (padded) | coef in some order
         for s in segs:
             assert s.n0 % 4 == 0 and (s.n1 - s.n0) % 4 == 0, 'segments must start and end on float4 boundaries'
+
+
+def _gloo8_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from yolact_amd import parallel
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
+    B, cap, D = 13, 5, 4                     # 13 images over 8 ranks: shards of 2,2,2,2,2,2,1,0 images
+    L_ = 1 + cap * (6 + D)
+    g = torch.Generator().manual_seed(7)
+    full = dict(count=torch.randint(0, cap + 1, (B,), generator=g).to(torch.int32), box=torch.rand(B, cap, 4, generator=g),
+                score=torch.rand(B, cap, generator=g), cls=torch.randint(0, 80, (B, cap), generator=g),
+                coef=torch.rand(B, cap, D, generator=g), proto=torch.rand(B, 3, 3, D, generator=g))
+    calls = []
+
+    class FakeNet:                            # stands in for Yolact: the device forward is the GPU part, not under test here
+        class detect:
+            top_k, use_cross_class_nms = 200, False
+
+        def forward_device(self, xs):
+            lo = int(xs[0, 0, 0, 0])
+            calls.append((lo, xs.shape[0]))
+            return {k: v[lo:lo + xs.shape[0]] for k, v in full.items()}
+    import yolact_amd
+    yolact_amd.set_cfg('yolact_resnet50_config')
+    yolact_amd.cfg.max_num_detections = cap
+    x = torch.arange(B, dtype=torch.float32).view(B, 1, 1, 1).expand(B, 3, 4, 4).contiguous()
+    gat = parallel.RecordGatherer(0)
+    net = FakeNet()
+    for step in range(3):                     # persistent buffers: the same storage every step
+        rec, mine = parallel.sharded_forward(net.forward_device, x, D, gat)
+        if rank == 0:
+            assert rec.shape == (B, L_)
+            if step == 0:
+                ptr = rec.data_ptr()
+            assert rec.data_ptr() == ptr, 'gather buffers must be allocated once'
+    lo, hi = parallel.shard_range(B, rank, world)
+    assert (hi - lo) == [2, 2, 2, 2, 2, 2, 1, 0][rank]
+    assert calls == ([(lo, hi - lo)] * 3 if hi > lo else [])
+    if rank == 0:
+        dets = parallel.unpack_records(rec, D)
+        ok = len(dets) == B
+        for b in range(B):
+            n = int(full['count'][b])
+            if n == 0:
+                ok = ok and dets[b] is None
+            else:
+                ok = ok and torch.equal(dets[b]['box'], full['box'][b, :n]) and torch.equal(dets[b]['score'], full['score'][b, :n])
+                ok = ok and torch.equal(dets[b]['class'], full['cls'][b, :n]) and torch.equal(dets[b]['mask'], full['coef'][b, :n])
+        q.put(bool(ok))
+    else:
+        assert rec is None
+    cpus = parallel.pin_rank_affinity(rank, world)
+    assert cpus is None or len(cpus) >= 1
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_world8_uneven_shards_gloo():
+    """BASELINE's 8-GPU layout on CPU/gloo: 13 images over 8 ranks (shards 2,2,2,2,2,2,1,0 — one rank idle), the sharded
+    forward + ONE gather into persistent buffers, three steps, per-rank CPU affinity.  The device forward is faked: what is under
+    test is everything of the N > 1 path that does not need a GPU."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo8_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True

@@ -79,7 +79,7 @@ class DetectDesc(C.Structure):
                 ('maxsc', C.c_void_p), ('argmax', C.c_void_p),
                 ('cand_score', C.c_void_p), ('cand_prior', C.c_void_p),
                 ('out_count', C.c_void_p), ('out_box', C.c_void_p), ('out_score', C.c_void_p),
-                ('out_class', C.c_void_p), ('out_coef', C.c_void_p), ('out_prior', C.c_void_p)]
+                ('out_class', C.c_void_p), ('out_coef', C.c_void_p), ('out_prior', C.c_void_p), ('out_rec', C.c_void_p)]
 
 
 class JpegInfo(C.Structure):

@@ -342,7 +342,8 @@ __global__ __launch_bounds__(NT, (EPT > 80 ? 1 : 2)) void final_topk_k(const flo
                                                    int P, int D, int nclass, int top_k, int cap, int cross_class,
                                                    int *__restrict__ out_count, float *__restrict__ out_box,
                                                    float *__restrict__ out_score, long long *__restrict__ out_class,
-                                                   float *__restrict__ out_coef, int *__restrict__ out_prior) {
+                                                   float *__restrict__ out_coef, int *__restrict__ out_prior,
+                                                   float *__restrict__ out_rec) {
   __shared__ SelShared sh;
   __shared__ unsigned nvalid;
   const int b = blockIdx.x, t = threadIdx.x;
@@ -358,6 +359,10 @@ __global__ __launch_bounds__(NT, (EPT > 80 ? 1 : 2)) void final_topk_k(const flo
   const int nv = (int)nvalid;
   const int k = nv < cap ? nv : cap;
   if (t == 0) out_count[b] = k;
+  // packed record of image b (ymi_detect_desc.out_rec): count | cap x (box 4, score, class, coef D), all fp32
+  const int RL = 6 + D;
+  float *rec = out_rec ? out_rec + (size_t)b * (1 + (size_t)cap * RL) : nullptr;
+  if (rec && t == 0) rec[0] = (float)k;
   if (k == 0) return;
   if constexpr (EPT > 0) {
     unsigned keys[EPT];
@@ -380,14 +385,21 @@ __global__ __launch_bounds__(NT, (EPT > 80 ? 1 : 2)) void final_topk_k(const flo
     float *ob = out_box + ((size_t)b * cap + j) * 4;
     ob[0] = bb[0]; ob[1] = bb[1]; ob[2] = bb[2]; ob[3] = bb[3];
     out_score[(size_t)b * cap + j] = cs[f];
-    out_class[(size_t)b * cap + j] = cross_class ? (long long)argmax[(size_t)b * P + prior] : (long long)(f / top_k);
+    const long long cls = cross_class ? (long long)argmax[(size_t)b * P + prior] : (long long)(f / top_k);
+    out_class[(size_t)b * cap + j] = cls;
     out_prior[(size_t)b * cap + j] = prior;
+    if (rec) {
+      float *r = rec + 1 + (size_t)j * RL;
+      r[0] = bb[0]; r[1] = bb[1]; r[2] = bb[2]; r[3] = bb[3]; r[4] = cs[f]; r[5] = (float)cls;
+    }
   }
   // coefficient rows: D floats each, copied by all threads
   for (int i = t; i < k * D; i += NT) {
     const int j = i / D, e = i - j * D;
     const int f = (int)(0xffffffffu - (unsigned)(sh.comp[j] & 0xffffffffull));
-    out_coef[((size_t)b * cap + j) * D + e] = coef[((size_t)b * P + cp[f]) * D + e];
+    const float cv = coef[((size_t)b * P + cp[f]) * D + e];
+    out_coef[((size_t)b * cap + j) * D + e] = cv;
+    if (rec) rec[1 + (size_t)j * RL + 6 + e] = cv;
   }
 }
 
@@ -434,7 +446,7 @@ extern "C" int ymi_detect_f32(const ymi_detect_desc *d, void *stream) {
 #define YMI_K3(EPT)                                                                                                   \
   hipLaunchKernelGGL(final_topk_k<EPT>, dim3(d->B), dim3(NT), 0, s, d->cand_score, d->cand_prior, d->loc, d->priors, \
                      d->coef, d->argmax, d->P, d->D, nclass, d->top_k, cap, d->cross_class, d->out_count, d->out_box, \
-                     d->out_score, (long long *)d->out_class, d->out_coef, d->out_prior)
+                     d->out_score, (long long *)d->out_class, d->out_coef, d->out_prior, d->out_rec)
   const long ncand = (long)nclass * d->top_k;
   if (ncand <= NT * 64) YMI_K3(64);
   else if (ncand <= NT * 128) YMI_K3(128);

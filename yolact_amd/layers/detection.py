@@ -101,7 +101,10 @@ class Detect(object):
     def _launch(self, loc, conf, mask, priors, conf_is_logits, stream, ws, B, P, Ccls, D, dev, max_det, cap, conf_ld=0):
         out = dict(count=torch.empty(B, dtype=torch.int32, device=dev), box=torch.empty(B, cap, 4, device=dev),
                    score=torch.empty(B, cap, device=dev), cls=torch.empty(B, cap, dtype=torch.int64, device=dev),
-                   coef=torch.empty(B, cap, D, device=dev), prior=torch.empty(B, cap, dtype=torch.int32, device=dev))
+                   coef=torch.empty(B, cap, D, device=dev), prior=torch.empty(B, cap, dtype=torch.int32, device=dev),
+                   # the same detections as one fixed-size record per image (count | cap x (box, score, class, coef)): the
+                   # payload of the data-parallel gather, written by the selection kernel itself (parallel.pack_records)
+                   rec=torch.empty(B, 1 + cap * (6 + D), device=dev))
         d = L.DetectDesc()
         loc, conf, mask, priors = (t.contiguous() for t in (loc.float(), conf.float(), mask.float(), priors.float()))
         d.conf, d.loc, d.coef, d.priors = conf.data_ptr(), loc.data_ptr(), mask.data_ptr(), priors.data_ptr()
@@ -116,6 +119,7 @@ class Detect(object):
         d.cand_score, d.cand_prior = ws['cand_score'].data_ptr(), ws['cand_prior'].data_ptr()
         d.out_count, d.out_box, d.out_score = out['count'].data_ptr(), out['box'].data_ptr(), out['score'].data_ptr()
         d.out_class, d.out_coef, d.out_prior = out['cls'].data_ptr(), out['coef'].data_ptr(), out['prior'].data_ptr()
+        d.out_rec = out['rec'].data_ptr()
         with torch.cuda.device(dev):
             L.check(L.lib().ymi_detect_f32(C.byref(d), stream if stream is not None else L.stream_ptr()), 'ymi_detect_f32')
         out['_keepalive'] = (loc, conf, mask, priors)

@@ -23,7 +23,11 @@ def shard_range(n_items: int, rank: int, world: int):
 
 
 def pack_records(dev_out: Dict[str, torch.Tensor]) -> torch.Tensor:
-    """Fixed-capacity Detect outputs -> one [B, 1 + cap*(6+D)] fp32 tensor (count first). Device-side, no sync."""
+    """Fixed-capacity Detect outputs -> one [B, 1 + cap*(6+D)] fp32 tensor (count first). Device-side, no sync.
+    The Detect selection kernel writes this record itself (ymi_detect_desc.out_rec -> dev_out['rec']): no torch op at all in
+    the step; the cat / cast form below only serves outputs that come without it (tests with hand-made tensors)."""
+    if 'rec' in dev_out:
+        return dev_out['rec']
     B, cap, D = dev_out['coef'].shape
     body = torch.cat([dev_out['box'], dev_out['score'].unsqueeze(-1), dev_out['cls'].to(torch.float32).unsqueeze(-1),
                       dev_out['coef']], dim=-1).reshape(B, cap * (6 + D))
@@ -55,6 +59,90 @@ def pad_records(rec: torch.Tensor, rows: int) -> torch.Tensor:
         raise ValueError('shard has %d records, expected at most %d' % (rec.shape[0], rows))
     pad = torch.zeros(rows - rec.shape[0], rec.shape[1], dtype=rec.dtype, device=rec.device)
     return torch.cat([rec, pad], 0)
+
+
+class RecordGatherer:
+    """The gather with PERSISTENT buffers: one [world * rows, L] tensor per (rows, L, device) allocated once; the per-rank
+    receive buffers are views of it, so a step allocates nothing and needs no torch.cat afterwards (the collective itself
+    assembles the global batch).  `rows` = records every rank contributes (ceil(global batch / world)); shorter shards are
+    padded into a persistent staging buffer."""
+
+    def __init__(self, dst: int = 0):
+        self.dst = dst
+        self._out = {}
+        self._pad = {}
+
+    def __call__(self, rec: torch.Tensor, rows: int, n_items: Optional[int] = None, force_collective: bool = False):
+        import os
+        if not (dist.is_available() and dist.is_initialized()):
+            return rec
+        world = dist.get_world_size()
+        if world == 1 and not (force_collective or os.environ.get('YOLACT_AMD_FORCE_GATHER', '0') == '1'):
+            return rec
+        if rec.shape[0] > rows:
+            raise ValueError('shard has %d records, expected at most %d' % (rec.shape[0], rows))
+        key = (rows, rec.shape[1], rec.device, rec.dtype)
+        if rec.shape[0] < rows:                               # uneven last shard: count-0 records up to `rows`
+            pad = self._pad.get(key)
+            if pad is None:
+                pad = self._pad[key] = torch.zeros(rows, rec.shape[1], dtype=rec.dtype, device=rec.device)
+            pad[:rec.shape[0]].copy_(rec)
+            pad[rec.shape[0]:, 0].zero_()
+            rec = pad
+        rec = rec.contiguous()
+        if dist.get_rank() != self.dst:
+            dist.gather(rec, None, dst=self.dst)
+            return None
+        out = self._out.get(key)
+        if out is None:
+            out = self._out[key] = torch.empty(world * rows, rec.shape[1], dtype=rec.dtype, device=rec.device)
+        dist.gather(rec, [out[r * rows:(r + 1) * rows] for r in range(world)], dst=self.dst)
+        return out if n_items is None else out[:n_items]
+
+
+def pin_rank_affinity(local_rank: int, local_world: int):
+    """Give every rank of a node its own contiguous slice of the host's CPUs (one process per GPU: eight Python launch loops
+    sharing all cores migrate and contend; the launch path is latency-sensitive).  Returns the CPU set, or None when the
+    platform has no sched_setaffinity."""
+    import os
+    if not hasattr(os, 'sched_setaffinity') or local_world < 1:
+        return None
+    cpus = sorted(os.sched_getaffinity(0))
+    per = max(1, len(cpus) // local_world)
+    mine = cpus[local_rank * per:(local_rank + 1) * per] or cpus
+    os.sched_setaffinity(0, mine)
+    return mine
+
+
+def sharded_forward(forward_device, x_global: torch.Tensor, D: int, gatherer: Optional[RecordGatherer] = None, dst: int = 0):
+    """Data-parallel forward of one GLOBAL batch (every rank holds the same x_global, or at least its own shard of it):
+    rank r runs `forward_device` (Yolact.forward_device: forward + Detect, no host sync) on images shard_range(B, r, world)
+    and the fixed-size detection records of all images are gathered on `dst` with the ONE collective of the path.  Returns
+    (records [B, L] on dst | None elsewhere, this rank's device outputs or None for an empty shard).  The prototypes stay on
+    the rank that computed them (masks are assembled where the prototypes live)."""
+    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    rank = dist.get_rank() if world > 1 else 0
+    B = int(x_global.shape[0])
+    lo, hi = shard_range(B, rank, world)
+    rows = (B + world - 1) // world
+    out = forward_device(x_global[lo:hi].contiguous()) if hi > lo else None
+    if out is not None:
+        rec = pack_records(out)
+    else:                                         # more ranks than images: contribute count-0 records only
+        L_ = 1 + int(_cap_of(forward_device)) * (6 + D)
+        rec = torch.zeros(0, L_, dtype=torch.float32, device=x_global.device)
+    g = gatherer or RecordGatherer(dst)
+    allrec = g(rec, rows, n_items=B, force_collective=world > 1)
+    return allrec, out
+
+
+def _cap_of(forward_device):
+    net = getattr(forward_device, '__self__', None)
+    det = getattr(net, 'detect', None)
+    if det is None:
+        raise RuntimeError('sharded_forward: an empty shard needs the record length; pass a bound Yolact.forward_device')
+    from .config import active_cfg
+    return det.top_k if det.use_cross_class_nms else int(active_cfg().max_num_detections)
 
 
 def gather_records(rec: torch.Tensor, dst: int = 0, rows_per_rank: Optional[int] = None, n_items: Optional[int] = None,

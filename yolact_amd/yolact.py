@@ -274,6 +274,31 @@ class Yolact(nn.Module):
         with torch.cuda.device(x.device):
             return self._forward_device_one(x)
 
+    def forward_sharded(self, x_global, dst=0):
+        """Data-parallel inference of one global batch across the ranks of torch.distributed (one process per GPU, RCCL): this
+        rank computes its contiguous share of the images (parallel.shard_range), then ONE gather of the fixed-size detection
+        records brings every image's detections to `dst` (eval.py:630-634,661 is batch splitting with a no-op gather; there is
+        no collective inside the network).  Returns, on dst, the list the reference's Detect would return for the global
+        batch — {'detection': {...}|None, 'net': self} per image, `proto` present for the images this rank computed itself —
+        and None on the other ranks."""
+        from . import parallel
+        L.require_cuda(x_global, 'input batch')
+        if not hasattr(self, '_gatherer') or self._gatherer.dst != dst:
+            self._gatherer = parallel.RecordGatherer(dst)
+        rec, mine = parallel.sharded_forward(self.forward_device, x_global, self.mask_dim, self._gatherer, dst)
+        if rec is None:
+            return None
+        import torch.distributed as dist
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        rank = dist.get_rank() if world > 1 else 0
+        lo, hi = parallel.shard_range(int(x_global.shape[0]), rank, world)
+        out = []
+        for b, det in enumerate(parallel.unpack_records(rec, self.mask_dim)):
+            if det is not None and mine is not None and lo <= b < hi:
+                det['proto'] = mine['proto'][b - lo]
+            out.append({'detection': det, 'net': self})
+        return out
+
     def forward_raw(self, x):
         """Head outputs before Detect (for parity tests): loc, conf (logits), mask, priors, proto — clones."""
         L.require_cuda(x, 'input batch')
