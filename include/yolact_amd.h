@@ -271,6 +271,19 @@ int ymi_fast_base_transform_f32(const float *img, float *out, int N, int H, int 
 int ymi_mask_iou_f32(const float *masks_a, const float *masks_b, int A, int B, long n, int iscrowd, float *ws, float *iou,
                      void *stream);
 
+/* -- prep_metrics without float masks (eval.py:376-384,416-440; layers/box_utils.py:33-80,98-113) ------------------------ */
+/* out[a,b] = IoU of point-form boxes a, b (iscrowd: intersection / area_a), reference op order.  box_a [A,4], box_b [B,4]. */
+int ymi_jaccard_f32(const float *box_a, const float *box_b, int A, int B, int iscrowd, float *out, void *stream);
+/* Masks as bits: word j of mask m (bits[m * W64 + j], W64 = ceil(n / 64)) holds pixels 64 j .. 64 j + 63 of the flat [h*w] mask
+ * (bit i = pixel 64 j + i; padding bits 0).  ymi_mask_bits_f32 packs float masks [N, n] (bit = value > 0.5: ground truth);
+ * ymi_mask_upsample_bits does F.interpolate(masks_lo [N,ph,pw], (h,w), bilinear) > thresh (output_utils.py:91-94) straight into
+ * bits: every bit equals the pixel ymi_mask_upsample_f32 writes, 1/32 of the bytes. */
+int ymi_mask_bits_f32(const float *masks, int N, long n, uint64_t *bits, void *stream);
+int ymi_mask_upsample_bits(const float *masks_lo, int N, int ph, int pw, int h, int w, float thresh, uint64_t *bits, void *stream);
+/* iou[a,b] from bit masks: popcount(a & b) / (|a| + |b| - popcount(a & b))  (iscrowd: / |a|) — integers below 2^24 evaluated in
+ * fp32 exactly as box_utils.py:98-113 evaluates the float masks: bit-identical results. */
+int ymi_mask_iou_bits(const uint64_t *bits_a, const uint64_t *bits_b, int A, int B, long W64, int iscrowd, float *iou, void *stream);
+
 /* -- prep_display, GPU half (eval.py:186-209,228): alpha-composite n instance masks onto a frame.
  * img [h,w,3] float32 0..255 (channel order as given), masks [n,h,w] float32, colors [n,3] float32 0..1 (device, same
  * channel order as img), out [h,w,3] uint8.  n = 0 just converts the frame. */

@@ -117,6 +117,10 @@ SYMBOLS = [
     ('ymi_dcn_v2_forward_f32', C.c_int, [C.POINTER(DcnDesc), _P]),
     ('ymi_composite_masks_u8', C.c_int, [_P, _P, _P, _I, _I, _I, _F, _P, _P]),
     ('ymi_mask_iou_f32', C.c_int, [_P, _P, _I, _I, C.c_long, _I, _P, _P, _P]),
+    ('ymi_jaccard_f32', C.c_int, [_P, _P, _I, _I, _I, _P, _P]),
+    ('ymi_mask_bits_f32', C.c_int, [_P, _I, C.c_long, _P, _P]),
+    ('ymi_mask_upsample_bits', C.c_int, [_P, _I, _I, _I, _I, _I, _F, _P, _P]),
+    ('ymi_mask_iou_bits', C.c_int, [_P, _P, _I, _I, C.c_long, _I, _P, _P]),
     ('ymi_mask_rle_f32', C.c_int, [_P, _I, _I, _I, _P, _P, _I, _P]),
     ('ymi_mask_rle_upsampled_f32', C.c_int, [_P, _I, _I, _I, _I, _I, _F, _P, _P, _I, _P]),
     ('ymi_rle_to_string', C.c_int, [_P, _P, _I, _I, _P, _P, _I, _P]),

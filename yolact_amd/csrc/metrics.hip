@@ -10,6 +10,7 @@
 // K2: iou = inter / (area_a + area_b - inter).
 // HBM-bound: (A + B) * n * 4 bytes read once when B <= 32 (145 MB for 100 detections x 20 GT at 550 x 550).
 #include "common.h"
+#include "upsample_math.h"
 #include "../../include/yolact_amd.h"
 
 namespace {
@@ -153,3 +154,142 @@ extern "C" int ymi_composite_masks_u8(const float *img, const float *masks, cons
                      alpha, out);
   return ymi_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// prep_metrics without the 121 MB / image float masks (second half; eval.py:376-384,416-440):
+//   * jaccard of predicted boxes vs ground truth on the device, reference op order (layers/box_utils.py:33-80);
+//   * masks as BITS: one uint64 word per 64 consecutive pixels of the flat [h*w] mask (bit i of word j = pixel 64 j + i);
+//     a wave's ballot IS the word.  ymi_mask_bits_f32 packs existing 0/1 float masks (ground truth);
+//     ymi_mask_upsample_bits upsamples + thresholds the low-resolution masks of postprocess (output_utils.py:91-94) straight
+//     into bits — the same up_coord / up_lerp2 arithmetic as the float kernel, so every bit equals the float path's pixel —
+//     3.8 MB instead of 121 MB per image at 550 x 550;
+//   * mask_iou from bits: intersection = popcount(a & b), areas = popcounts; all three are integers < 2^24, so
+//     inter / (area_a + area_b - inter) evaluated in fp32 is bit-identical to box_utils.py:98-113 on the float masks.
+namespace {
+
+__global__ void jaccard_k(const float *__restrict__ a, const float *__restrict__ b, int A, int B, int iscrowd,
+                          float *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= A * B) return;
+  const int ia = i / B, ib = i - ia * B;
+  const float ax1 = a[ia * 4 + 0], ay1 = a[ia * 4 + 1], ax2 = a[ia * 4 + 2], ay2 = a[ia * 4 + 3];
+  const float bx1 = b[ib * 4 + 0], by1 = b[ib * 4 + 1], bx2 = b[ib * 4 + 2], by2 = b[ib * 4 + 3];
+  // box_utils.py:47-51: inter = clamp(min(a.xy2, b.xy2) - max(a.xy1, b.xy1), 0).prod
+  float iw = fminf(ax2, bx2) - fmaxf(ax1, bx1), ih = fminf(ay2, by2) - fmaxf(ay1, by1);
+  iw = iw < 0.f ? 0.f : iw; ih = ih < 0.f ? 0.f : ih;
+  const float inter = iw * ih;
+  const float area_a = (ax2 - ax1) * (ay2 - ay1), area_b = (bx2 - bx1) * (by2 - by1);      // :72-75
+  out[i] = iscrowd ? inter / area_a : inter / ((area_a + area_b) - inter);                 // :77-79
+}
+
+__global__ __launch_bounds__(256) void mask_bits_k(const float *__restrict__ m, long n, long W64, unsigned long long *__restrict__ bits) {
+  const long mask = blockIdx.y;
+  const float *src = m + mask * n;
+  for (long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6); wv < W64; wv += (long)gridDim.x * 4) {
+    const long p = wv * 64 + (threadIdx.x & 63);
+    const float v = p < n ? src[p] : 0.f;
+    const unsigned long long word = __ballot(v > 0.5f);
+    if ((threadIdx.x & 63) == 0) bits[mask * W64 + wv] = word;
+  }
+}
+
+__global__ __launch_bounds__(256) void mask_upsample_bits_k(const float *__restrict__ lo, int ph, int pw, int h, int w, float sh,
+                                                            float sw, float thresh, long W64,
+                                                            unsigned long long *__restrict__ bits) {
+  const long mask = blockIdx.y;
+  const float *img = lo + mask * (long)ph * pw;
+  const long n = (long)h * w;
+  for (long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6); wv < W64; wv += (long)gridDim.x * 4) {
+    const long p = wv * 64 + (threadIdx.x & 63);
+    bool on = false;
+    if (p < n) {
+      const int y = (int)(p / w), x = (int)(p - (long)y * w);
+      int y0, y1, x0, x1; float ly, lx;
+      up_coord(y, sh, ph, y0, y1, ly);
+      up_coord(x, sw, pw, x0, x1, lx);
+      const float v = up_lerp2(img[y0 * pw + x0], img[y0 * pw + x1], img[y1 * pw + x0], img[y1 * pw + x1], lx, ly);
+      on = v > thresh;
+    }
+    const unsigned long long word = __ballot(on);
+    if ((threadIdx.x & 63) == 0) bits[mask * W64 + wv] = word;
+  }
+}
+
+// grid (A, ceil(B / 8)): a block intersects mask a with 8 masks b; areas ride along
+__global__ __launch_bounds__(256) void mask_iou_bits_k(const unsigned long long *__restrict__ ba, const unsigned long long *__restrict__ bb,
+                                                       int A, int B, long W64, int iscrowd, float *__restrict__ iou) {
+  __shared__ unsigned red[4][17];
+  const int a = blockIdx.x, b0 = blockIdx.y * 8;
+  const unsigned long long *pa = ba + (long)a * W64;
+  unsigned cnt[17];
+#pragma unroll
+  for (int k = 0; k < 17; ++k) cnt[k] = 0;
+  for (long j = threadIdx.x; j < W64; j += 256) {
+    const unsigned long long wa = pa[j];
+    cnt[16] += (unsigned)__popcll(wa);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (b0 + k < B) {
+        const unsigned long long wb = bb[(long)(b0 + k) * W64 + j];
+        cnt[k] += (unsigned)__popcll(wa & wb);
+        cnt[8 + k] += (unsigned)__popcll(wb);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 17; ++k) {
+    unsigned v = cnt[k];
+#pragma unroll
+    for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8 && b0 + threadIdx.x < B) {
+    const int k = threadIdx.x;
+    const float inter = (float)(red[0][k] + red[1][k] + red[2][k] + red[3][k]);
+    const float area_b = (float)(red[0][8 + k] + red[1][8 + k] + red[2][8 + k] + red[3][8 + k]);
+    const float area_a = (float)(red[0][16] + red[1][16] + red[2][16] + red[3][16]);
+    iou[(long)a * B + b0 + k] = iscrowd ? inter / area_a : inter / ((area_a + area_b) - inter);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ymi_jaccard_f32(const float *box_a, const float *box_b, int A, int B, int iscrowd, float *out, void *stream) {
+  if (!box_a || !box_b || !out) return YMI_ENULL;
+  if (A <= 0 || B <= 0 || (long)A * B > (1L << 30)) return YMI_EARG;
+  hipLaunchKernelGGL(jaccard_k, dim3((A * B + 255) / 256), dim3(256), 0, (hipStream_t)stream, box_a, box_b, A, B, iscrowd, out);
+  return ymi_launch_status();
+}
+
+int ymi_mask_bits_f32(const float *masks, int N, long n, uint64_t *bits, void *stream) {
+  if (!masks || !bits) return YMI_ENULL;
+  if (N <= 0 || N > 65535 || n <= 0) return YMI_EARG;
+  const long W64 = (n + 63) / 64;
+  long g = (W64 + 3) / 4;
+  hipLaunchKernelGGL(mask_bits_k, dim3((unsigned)(g > 1024 ? 1024 : g), N), dim3(256), 0, (hipStream_t)stream, masks, n, W64,
+                     (unsigned long long *)bits);
+  return ymi_launch_status();
+}
+
+int ymi_mask_upsample_bits(const float *masks_lo, int N, int ph, int pw, int h, int w, float thresh, uint64_t *bits, void *stream) {
+  if (!masks_lo || !bits) return YMI_ENULL;
+  if (N <= 0 || N > 65535 || ph <= 0 || pw <= 0 || h <= 0 || w <= 0) return YMI_EARG;
+  const long W64 = ((long)h * w + 63) / 64;
+  long g = (W64 + 3) / 4;
+  hipLaunchKernelGGL(mask_upsample_bits_k, dim3((unsigned)(g > 1024 ? 1024 : g), N), dim3(256), 0, (hipStream_t)stream, masks_lo, ph,
+                     pw, h, w, (float)ph / (float)h, (float)pw / (float)w, thresh, W64, (unsigned long long *)bits);
+  return ymi_launch_status();
+}
+
+int ymi_mask_iou_bits(const uint64_t *bits_a, const uint64_t *bits_b, int A, int B, long W64, int iscrowd, float *iou, void *stream) {
+  if (!bits_a || !bits_b || !iou) return YMI_ENULL;
+  if (A <= 0 || B <= 0 || W64 <= 0 || A > 65535 || (B + 7) / 8 > 65535) return YMI_EARG;
+  hipLaunchKernelGGL(mask_iou_bits_k, dim3(A, (B + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const unsigned long long *)bits_a,
+                     (const unsigned long long *)bits_b, A, B, W64, iscrowd, iou);
+  return ymi_launch_status();
+}
+
+}  // extern "C"

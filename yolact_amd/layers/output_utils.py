@@ -106,6 +106,25 @@ def postprocess_rle(det_output, w, h, batch_idx=0, crop_masks=True, score_thresh
     return classes, scores, boxes_px, rle_encode(masks)
 
 
+def postprocess_bits(det_output, w, h, batch_idx=0, crop_masks=True, score_threshold=0):
+    """`postprocess` for the metric path (eval.py:403-440 prep_metrics): same classes / scores / integer boxes, but the masks come
+    back as BITS — int64 [N, ceil(h*w/64)], bit i of word j = pixel 64 j + i of the flat [h, w] mask — written by one kernel
+    that upsamples and thresholds the prototype-resolution masks (the float kernel's arithmetic: every bit equals the pixel
+    `postprocess` would have written).  3.8 MB instead of 121 MB per image at 550 x 550; layers.box_utils.mask_iou_bits scores
+    them against bit-packed ground truth with popcounts, bit-identical to mask_iou on the float masks.  Empty: ([], [], [], None)."""
+    r = _lowres_masks(det_output, w, h, batch_idx, 'bilinear', False, crop_masks, score_threshold)
+    if r is None:
+        return [], [], [], None
+    classes, scores, boxes_px, masks_lo = r
+    N, ph, pw = masks_lo.shape
+    W64 = (h * w + 63) // 64
+    with torch.cuda.device(masks_lo.device):
+        bits = torch.empty(N, W64, dtype=torch.int64, device=masks_lo.device)
+        L.check(L.lib().ymi_mask_upsample_bits(masks_lo.data_ptr(), N, ph, pw, h, w, C.c_float(0.5), bits.data_ptr(),
+                                               L.stream_ptr()), 'ymi_mask_upsample_bits')
+    return classes, scores, boxes_px, bits
+
+
 def postprocess_batch(dev_out, w, h, crop_masks=True):
     """postprocess() for a whole batch with NO per-image Python loop and no host synchronisation: the fixed-capacity
     device outputs of `Yolact.forward_device` (count [B], box [B,cap,4], score, cls, coef [B,cap,D], proto [B,ph,pw,D])
