@@ -64,6 +64,11 @@ PY
     probe)
       /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/split_probe.hip -o /tmp/split_probe.bin > $O/probe_build.log 2>&1
       timeout 300 /tmp/split_probe.bin > $O/split_probe.json 2> $O/probe.err; cat $O/split_probe.json | tr '}' '\n' | cut -c1-230 ;;
+    b1) # batch-1 anatomy: kernel trace of the batch-1 bench (two streams / one stream) + per-step timeline
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $R/$O/b1_2 -- bash -c "cd $R && python bench.py --batch 1 --steps 60 --warmup 5 --no-cpu-baseline --no-secondary" > $R/$O/b1_2.log 2>&1)
+      (cd /tmp && YOLACT_AMD_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $R/$O/b1_1 -- bash -c "cd $R && python bench.py --batch 1 --steps 60 --warmup 5 --no-cpu-baseline --no-secondary" > $R/$O/b1_1.log 2>&1)
+      for v in 2 1; do f=$(find $O/b1_$v -name "*kernel_trace.csv" | head -1); echo "streams=$v"; python tools/step_timeline.py $f 30; done > $O/b1_timeline.txt 2>&1; cat $O/b1_timeline.txt
+      f=$(find $O/b1_1 -name "*kernel_stats.csv" | head -1); head -25 $f | cut -c1-150 > $O/b1_kernel_stats_head.txt; cat $O/b1_kernel_stats_head.txt ;;
     dcnref) timeout 600 python -m pytest tests/test_gpu_dcn_reference.py -m gpu -q -rA -s > $O/dcnref.log 2>&1; tail -5 $O/dcnref.log ;;
     evalpy) timeout 1500 bash tools/run_reference_eval.sh $O > $O/evalpy.log 2>&1; tail -30 $O/evalpy.log ;;
     py) n=$(basename ${arg%% *} .py); k=0; while [ -e $O/$n$k.log ]; do k=$((k+1)); done
