@@ -39,7 +39,10 @@ for st in "$@"; do
         set -- $c
         timeout 400 python bench.py --config $1 --batch $2 --steps 10 --no-cpu-baseline --no-secondary > $O/bench_$3.json 2>/dev/null; head -1 $O/bench_$3.json | cut -c1-200
       done
-      YOLACT_AMD_SPLIT=0 timeout 400 python bench.py --no-cpu-baseline --no-secondary > $O/bench_fp32only.json 2>/dev/null; head -1 $O/bench_fp32only.json | cut -c1-200 ;;
+      YOLACT_AMD_SPLIT=0 timeout 400 python bench.py --no-cpu-baseline --no-secondary > $O/bench_fp32only.json 2>/dev/null; head -1 $O/bench_fp32only.json | cut -c1-200
+      YOLACT_AMD_SPLIT=1 timeout 400 python bench.py --no-cpu-baseline --no-secondary > $O/bench_bf16x3.json 2>/dev/null; head -1 $O/bench_bf16x3.json | cut -c1-200 ;;
+    ab) # same-box A/B of the three arithmetics on configs[1] (box-to-box spread is larger than most single changes)
+      for m in 2 1 0 2 1; do YOLACT_AMD_SPLIT=$m timeout 300 python bench.py --steps 30 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('SPLIT=$m', d['value'], d['ms_per_step'], d['config']['plan']['tune_misses'])"; done | tee $O/ab.txt ;;
     stats)
       (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $R/$O/stats2 -- bash -c "cd $R && $BENCH" > $R/$O/stats2.log 2>&1)
       (cd /tmp && YOLACT_AMD_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $R/$O/stats1 -- bash -c "cd $R && $BENCH" > $R/$O/stats1.log 2>&1)
