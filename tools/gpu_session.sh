@@ -64,6 +64,10 @@ PY
       (cd /tmp && YOLACT_AMD_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --kernel-include-regex conv_igemm -f csv -d $R/$O/pmc1 -- bash -c "cd $R && python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary" > $R/$O/pmc1.log 2>&1)
       python tools/pmc_summary.py $O/pmc1 > $O/pmc_plan_p1.tsv 2> $O/pmc.err; head -20 $O/pmc_plan_p1.tsv | cut -c1-200
       find $O -name "*counter_collection.csv" -size +4M -delete ;;
+    pmcw) # wave-level counters of the Winograd GEMM variants on proto.8 (one pass, counters only)
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-include-regex conv_igemm -f csv -d $R/$O/pmcw -- bash -c "cd $R && python tools/wino_probe.py --shapes 0 --tiles 1,17,21 --reps 3" > $R/$O/pmcw.log 2>&1)
+      python tools/pmc_summary.py $O/pmcw > $O/pmc_wino.tsv 2> $O/pmcw.err; cat $O/pmc_wino.tsv | cut -c1-400
+      find $O -name "*counter_collection.csv" -size +4M -delete ;;
     probe)
       /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/split_probe.hip -o /tmp/split_probe.bin > $O/probe_build.log 2>&1
       timeout 300 /tmp/split_probe.bin > $O/split_probe.json 2> $O/probe.err; cat $O/split_probe.json | tr '}' '\n' | cut -c1-230 ;;
