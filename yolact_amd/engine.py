@@ -371,8 +371,9 @@ class Plan:
         d.cout_alg = pk.cout_alg
         if self.split and dcn_offmask is None:
             d.w_x3 = pk.w3().data_ptr()
-        yslot = self._slot()                    # every launch records the magnitude bound of what it writes (cheap: one atomic
-        d.y_amax = self._slot_ptr(yslot)        # per wave); consumers on fp16x2 tiles read it as x_amax
+        yslot = self._slot()                    # fp16x2 plans: every launch records the magnitude bound of what it writes
+        if self.h2:                             # (csrc/common.h: one XCD-local atomic per wave at most); consumers read it as
+            d.y_amax = self._slot_ptr(yslot)    # x_amax.  The bf16x3 / exact-fp32 plans need no bounds and do not pay for them
         if x.slot is not None:
             d.x_amax = self._slot_ptr(x.slot)
         if self.h2:                             # (DCN layers too: the gathered fp32 tile is split like any other A tile)
@@ -436,7 +437,8 @@ class Plan:
             d.u_h2, d.uinv_h2 = planes.data_ptr(), uinv.data_ptr()
         if x.slot is not None:
             d.x_amax = self._slot_ptr(x.slot)
-        d.y_amax = self._slot_ptr(self.last_yslot)        # same slot as the direct descriptor of this layer
+        if self.h2:
+            d.y_amax = self._slot_ptr(self.last_yslot)    # same slot as the direct descriptor of this layer
         if segs is None:
             d.y = y.ptr
         else:
@@ -795,7 +797,8 @@ class Plan:
         sb = C.c_void_p(self.stream_b.cuda_stream) if two else sa
         proto = torch.empty(self.proto_shape, dtype=torch.float32, device=self.device)
         self.proto_patch.seg[0].ptr = proto.data_ptr()
-        self.amax.zero_()            # magnitude bounds are re-derived by every run (on the caller's stream, ahead of every op)
+        if self.h2:                  # magnitude bounds are re-derived by every run (on the caller's stream, ahead of every op)
+            self.amax[:self._nslots * AMAX_SLOT_FLOATS].zero_()
         # only a module with the reference's timer API (utils/timer.py: start / stop / env) is driven
         if timer is not None and not all(hasattr(timer, a) for a in ('start', 'stop', 'env')):
             timer = None
@@ -825,7 +828,7 @@ class Plan:
             if fn == 'input':
                 a = self.in_args
                 rc = lib.ymi_nchw_to_nhwc4_f32(x.data_ptr(), a[1], a[2], a[3], a[4], a[5], s)
-                if rc == 0:
+                if rc == 0 and self.h2:
                     rc = lib.ymi_amax_f32(self.in_amax[0], self.in_amax[1], self.in_amax[2], s)
             elif fn == 'record':
                 if two:
