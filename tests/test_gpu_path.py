@@ -94,6 +94,34 @@ def test_detect_ties_and_small_k():
     assert torch.equal(got['score'].cpu(), ref['score'])
 
 
+def test_detect_ties_at_the_top_k_cut():
+    """More exact ties on the selection threshold than slots left (K > top_k): the lowest prior indices win (the kernel's
+    prefix-sum tie path, csrc/detect.hip block_topk_regs), per class and again in the final cross-class top-N."""
+    import yolact_amd
+    from oracle import yolact_oracle as O
+    yolact_amd.set_cfg('yolact_resnet50_config')
+    cfg = yolact_amd.cfg
+    g = torch.Generator().manual_seed(11)
+    P, Cc, D = 19248, 81, 32
+    conf = torch.full((1, P, Cc), 1e-4)
+    conf[0, :, 0] = 0.9
+    tied = torch.randperm(P, generator=g)[:900]
+    conf[0, tied, 7] = 0.25                                   # 900 priors tied at 0.25 in class 6: top_k = 200 of them
+    conf[0, tied[:30], 7] = 0.5                                # 30 clear winners above the tie
+    conf[0, tied[100:700], 12] = 0.25                          # a second class tied at the same value (final top-N ties)
+    pri = torch.rand(P, 4, generator=g) * 0.02 + 0.05          # small boxes scattered: few suppressions
+    pri[:, :2] = torch.rand(P, 2, generator=g)
+    loc = torch.randn(1, P, 4, generator=g) * 0.1
+    mask = torch.tanh(torch.randn(1, P, D, generator=g))
+    ref = O.detect_image(conf[0], loc[0], mask[0], pri)
+    det = _detect_obj(cfg)
+    out = det({'loc': loc.to(DEV), 'conf': conf.to(DEV), 'mask': mask.to(DEV), 'priors': pri.to(DEV)}, None)
+    got = out[0]['detection']
+    assert torch.equal(det.last_prior_idx[0].cpu().long(), ref['prior'])
+    assert torch.equal(got['class'].cpu(), ref['class'])
+    assert torch.equal(got['score'].cpu(), ref['score'])
+
+
 def test_detect_fused_softmax_scores():
     """conf_is_logits path: device softmax within 1e-6 of torch's; detections margin-matched."""
     import yolact_amd

@@ -41,6 +41,7 @@ def main():
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--tiles', default='')
     ap.add_argument('--shapes', default='')
+    ap.add_argument('--batch', type=int, default=0, help='override the batch size of every shape')
     ap.add_argument('--cold', type=int, default=0, help='1: zero the output bound slot before every launch (what a real run sees)')
     ap.add_argument('--amax', type=int, default=1, help='0: launches do not report max|y| (A/B of the epilogue atomic)')
     args = ap.parse_args()
@@ -52,6 +53,7 @@ def main():
     for si, (name, B, H, W, Cin, Cout, k, st, pad, has_res) in enumerate(SHAPES):
         if args.shapes and str(si) not in args.shapes.split(','):
             continue
+        B = args.batch or B
         g = torch.Generator().manual_seed(si)
         w = torch.randn(Cout, Cin, k, k, generator=g) * 0.05
         pk = Packed(w, torch.randn(Cout, generator=g), None, st, pad, None, dev)
