@@ -29,11 +29,12 @@ for _t in X3_BASE_TILES:
     TILE_NAMES[_t | TILE_X3] = TILE_NAMES[_t] + 'x3'
 BASIC_TILES = (1, 2, 3, 4, 5)      # available for every loader (stem, DCN)
 TILE_H2 = 64                        # tile | TILE_H2: fp16x2 split-precision variant (two fp16 pieces, 3 MFMAs per product)
-H2_BASE_TILES = X3_BASE_TILES + (18,)          # + 128x256w8: one column block for the Cout = 256 Winograd GEMMs (V read once)
+H2_BASE_TILES = X3_BASE_TILES + (18, 13, 14, 15)   # + 128x256w8: one column block for the Cout = 256 Winograd GEMMs (V read once);
+                                                  # + the deeper-pipelined K-split tiles (batch 1: ~23 % of the kernel time sat in 32x32k4)
 for _t in H2_BASE_TILES:
     TILE_NAMES[_t | TILE_H2] = TILE_NAMES[_t] + 'h2'
 WINO_PLANES = 1024                  # tune-table flag on a Winograd GEMM tile id: V written as fp16x2 planes (ymi_wino_desc.v_planes)
-KSPLIT_TILES = (6, 7, 8, 13, 14, 15, 6 | 32, 7 | 32, 8 | 32, 6 | 64, 7 | 64, 8 | 64)   # different (still deterministic) fp32 summation order than the unsplit tiles
+KSPLIT_TILES = (6, 7, 8, 13, 14, 15, 6 | 32, 7 | 32, 8 | 32, 6 | 64, 7 | 64, 8 | 64, 13 | 64, 14 | 64, 15 | 64)   # different (still deterministic) fp32 summation order than the unsplit tiles
 
 
 class ConvSeg(C.Structure):

@@ -1175,7 +1175,10 @@ int launch_prec(const KParams &kp, int loader, hipStream_t s, int groups) {
   X(YMI_TILE_H2 | YMI_TILE_128x128_S3, 2, 2, 1, 2, 2, 3, false, 3)  \
   X(YMI_TILE_H2 | YMI_TILE_128x128_W8_S3, 4, 2, 1, 1, 2, 3, false, 3) \
   X(YMI_TILE_H2 | YMI_TILE_256x128_W8_S3, 4, 2, 1, 2, 2, 3, false, 3) \
-  X(YMI_TILE_H2 | YMI_TILE_128x128_W8_S4, 4, 2, 1, 1, 2, 4, false, 3)
+  X(YMI_TILE_H2 | YMI_TILE_128x128_W8_S4, 4, 2, 1, 1, 2, 4, false, 3) \
+  X(YMI_TILE_H2 | YMI_TILE_32x32_K4_S4, 1, 1, 4, 1, 1, 4, false, 3)   \
+  X(YMI_TILE_H2 | YMI_TILE_64x32_K2_S3, 2, 1, 2, 1, 1, 3, false, 3)   \
+  X(YMI_TILE_H2 | YMI_TILE_32x64_K2_S3, 1, 2, 2, 1, 1, 3, false, 3)
 
 int tile_dims(int tile, int &bm, int &bn) {
   switch (tile) {
