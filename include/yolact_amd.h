@@ -183,6 +183,9 @@ int ymi_amax_f32(const float *x, long n, float *out, void *stream);
 /* -- layout / pooling / resize ---------------------------------------------------------- */
 /* x [B,C,H,W] (C<=4) -> y [B,H,W,4], zero-filled channels C..3.  Entry of Yolact.forward (yolact.py:564). */
 int ymi_nchw_to_nhwc4_f32(const float *x, float *y, int B, int C, int H, int W, void *stream);
+/* the same, and raises the magnitude-bound slot `amax` (ymi_amax_f32's layout, zeroed by the caller) to max |x|: one launch
+ * for the two passes over the network input */
+int ymi_nchw_to_nhwc4_amax_f32(const float *x, float *y, int B, int C, int H, int W, float *amax, void *stream);
 /* y [B,H,W,C] NHWC -> x [B,C,H,W] (returning NCHW tensors to callers that expect them) */
 int ymi_nhwc_to_nchw_f32(const float *x, float *y, int B, int C, int H, int W, void *stream);
 /* nn.MaxPool2d(3, stride 2, pad 1) on NHWC, C % 4 == 0 (backbone.py:80,131). */

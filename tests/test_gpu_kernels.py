@@ -164,6 +164,12 @@ def test_layout_pool_resize():
     y = torch.empty(2, 37, 29, 4, device=DEV)
     L.check(lib.ymi_nchw_to_nhwc4_f32(xd.data_ptr(), y.data_ptr(), 2, 3, 37, 29, s))
     assert torch.equal(y.cpu()[..., :3], nhwc(x)) and y.cpu()[..., 3].abs().max() == 0
+    # the fused variant: same layout change + the magnitude bound of the input in its slot (16 sub-slots, 64 floats apart)
+    y2 = torch.empty(2, 37, 29, 4, device=DEV)
+    slot = torch.zeros(1024, device=DEV)
+    L.check(lib.ymi_nchw_to_nhwc4_amax_f32(xd.data_ptr(), y2.data_ptr(), 2, 3, 37, 29, slot.data_ptr(), s))
+    assert torch.equal(y2, y) and slot.max().item() == x.abs().max().item()
+    assert slot.view(16, 64)[:, 1:].abs().max().item() == 0
     a = torch.randn(2, 40, 21, 19, generator=g)
     ad = nhwc(a).to(DEV)
     back = torch.empty(2, 40, 21, 19, device=DEV)

@@ -104,6 +104,7 @@ SYMBOLS = [
     ('ymi_conv_pick_tile', C.c_int, [C.POINTER(ConvDesc)]),
     ('ymi_amax_f32', C.c_int, [_P, C.c_long, _P, _P]),
     ('ymi_nchw_to_nhwc4_f32', C.c_int, [_P, _P, _I, _I, _I, _I, _P]),
+    ('ymi_nchw_to_nhwc4_amax_f32', C.c_int, [_P, _P, _I, _I, _I, _I, _P, _P]),
     ('ymi_nhwc_to_nchw_f32', C.c_int, [_P, _P, _I, _I, _I, _I, _P]),
     ('ymi_maxpool3x3s2_nhwc_f32', C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     ('ymi_bilinear_nhwc_f32', C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _I, _P]),

@@ -5,8 +5,14 @@
 namespace {
 
 // x [B,C,H,W] (C <= 4) -> y [B,H,W,4]; one thread per pixel, plane reads coalesced, 16-byte stores.
+// AMAX: also raise *amax to max |element| (the magnitude bound of the network input, ymi_conv_desc.x_amax of the stem) — the
+// values pass through registers here anyway, a separate ymi_amax_f32 launch re-reads them (10 us of a 1.6 ms batch-1 step)
+template <bool AMAX>
 __global__ __launch_bounds__(256) void nchw_to_nhwc4_k(const float *__restrict__ x, float *__restrict__ y,
-                                                        int C, int HW, long total) {
+                                                        int C, int HW, long total, float *__restrict__ amax) {
+  float am = 0.f;
+  ymi_amax_pre apre = {};
+  if (AMAX) apre = ymi_amax_prefetch(amax);
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
     const long b = i / HW, pix = i - b * HW;
     const float *src = x + b * C * HW + pix;
@@ -16,7 +22,9 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc4_k(const float *__restrict__
     if (C > 2) v[2] = src[2L * HW];
     if (C > 3) v[3] = src[3L * HW];
     *reinterpret_cast<f32x4 *>(y + i * 4) = v;
+    if (AMAX) am = fmaxf(am, ymi_absmax4(v));
   }
+  if (AMAX) ymi_amax_finish(apre, am);
 }
 
 // x [B,H,W,C] -> y [B,C,H,W] through a 32x33 LDS tile (pixels x channels) so both sides coalesce.
@@ -39,12 +47,10 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_k(const float *__restrict__ 
 // MaxPool 3x3 / stride 2 / pad 1, -inf padding (nn.MaxPool2d semantics). One thread per (pixel, 4 channels).
 __global__ __launch_bounds__(256) void maxpool3x3s2_k(const float *__restrict__ x, float *__restrict__ y,
                                                        int H, int W, int C4, int Ho, int Wo, long total) {
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
-    const int c4 = (int)(i % C4);
-    long r = i / C4;
-    const int ox = (int)(r % Wo); r /= Wo;
-    const int oy = (int)(r % Ho);
-    const long b = r / Ho;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256u) {   // 32-bit index math (total <
+    const unsigned pu = i / (unsigned)C4, ru = pu / (unsigned)Wo, bu = ru / (unsigned)Ho;          // 2^31, host-checked): the 64-bit
+    const int c4 = (int)(i - pu * (unsigned)C4), ox = (int)(pu - ru * (unsigned)Wo), oy = (int)(ru - bu * (unsigned)Ho);   // div / mod
+    const long b = bu;                                                                          // chain cost more than the pooling
     const float ninf = -__builtin_inff();
     f32x4 m = {ninf, ninf, ninf, ninf};
 #pragma unroll
@@ -60,7 +66,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_k(const float *__restrict__ 
         for (int e = 0; e < 4; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
       }
     }
-    *reinterpret_cast<f32x4 *>(y + i * 4) = m;
+    *reinterpret_cast<f32x4 *>(y + (long)i * 4) = m;
   }
 }
 
@@ -77,12 +83,10 @@ __device__ __forceinline__ void bl_coord(int dst, float scale, int in_size, int 
 __global__ __launch_bounds__(256) void bilinear_nhwc_k(const float *__restrict__ x, float *__restrict__ y,
                                                         int Hi, int Wi, int C4, int Ho, int Wo, float sh, float sw,
                                                         int relu, long total) {
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
-    const int c4 = (int)(i % C4);
-    long r = i / C4;
-    const int ox = (int)(r % Wo); r /= Wo;
-    const int oy = (int)(r % Ho);
-    const long b = r / Ho;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256u) {   // 32-bit index math, see above
+    const unsigned pu = i / (unsigned)C4, ru = pu / (unsigned)Wo, bu = ru / (unsigned)Ho;
+    const int c4 = (int)(i - pu * (unsigned)C4), ox = (int)(pu - ru * (unsigned)Wo), oy = (int)(ru - bu * (unsigned)Ho);
+    const long b = bu;
     int y0, y1, x0, x1; float ly, lx;
     bl_coord(oy, sh, Hi, y0, y1, ly);
     bl_coord(ox, sw, Wi, x0, x1, lx);
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(256) void bilinear_nhwc_k(const float *__restrict__
       float v = hy * (hx * v00[e] + lx * v01[e]) + ly * (hx * v10[e] + lx * v11[e]);
       o[e] = (relu && v < 0.f) ? 0.f : v;
     }
-    *reinterpret_cast<f32x4 *>(y + i * 4) = o;
+    *reinterpret_cast<f32x4 *>(y + (long)i * 4) = o;
   }
 }
 
@@ -136,7 +140,16 @@ int ymi_nchw_to_nhwc4_f32(const float *x, float *y, int B, int C, int H, int W, 
   if (!x || !y) return YMI_ENULL;
   if (B <= 0 || C <= 0 || C > 4 || H <= 0 || W <= 0) return YMI_EARG;
   const long total = (long)B * H * W;
-  hipLaunchKernelGGL(nchw_to_nhwc4_k, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, C, H * W, total);
+  hipLaunchKernelGGL(nchw_to_nhwc4_k<false>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, C, H * W, total,
+                     (float *)nullptr);
+  return ymi_launch_status();
+}
+
+int ymi_nchw_to_nhwc4_amax_f32(const float *x, float *y, int B, int C, int H, int W, float *amax, void *stream) {
+  if (!x || !y || !amax) return YMI_ENULL;
+  if (B <= 0 || C <= 0 || C > 4 || H <= 0 || W <= 0) return YMI_EARG;
+  const long total = (long)B * H * W;
+  hipLaunchKernelGGL(nchw_to_nhwc4_k<true>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, C, H * W, total, amax);
   return ymi_launch_status();
 }
 
@@ -155,6 +168,7 @@ int ymi_maxpool3x3s2_nhwc_f32(const float *x, float *y, int B, int H, int W, int
   if (C % 4 != 0 || B <= 0) return YMI_ESHAPE;
   if (Ho != (H + 2 - 3) / 2 + 1 || Wo != (W + 2 - 3) / 2 + 1) return YMI_ESHAPE;
   const long total = (long)B * Ho * Wo * (C / 4);
+  if (total >= (1L << 31)) return YMI_ESHAPE;
   hipLaunchKernelGGL(maxpool3x3s2_k, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C / 4, Ho,
                      Wo, total);
   return ymi_launch_status();
@@ -167,6 +181,7 @@ int ymi_bilinear_nhwc_f32(const float *x, float *y, int B, int Hi, int Wi, int C
   const float sh = scale_h > 0.f ? scale_h : (float)Hi / (float)Ho;
   const float sw = scale_w > 0.f ? scale_w : (float)Wi / (float)Wo;
   const long total = (long)B * Ho * Wo * (C / 4);
+  if (total >= (1L << 31)) return YMI_ESHAPE;
   hipLaunchKernelGGL(bilinear_nhwc_k, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, Hi, Wi, C / 4,
                      Ho, Wo, sh, sw, relu, total);
   return ymi_launch_status();

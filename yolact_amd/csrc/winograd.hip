@@ -49,13 +49,10 @@ __global__ __launch_bounds__(256) void wino_in_k(const float *__restrict__ x, fl
                                                  int th, int tw, long T, long total, const float *__restrict__ x_amax) {
   float vs = 1.f, vinv = 1.f;
   if (PLANES) ymi_h2_scale(ymi_amax_read(x_amax) * 4.f, vs, vinv);
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
-    const int c4 = (int)(i % C4);
-    const long t = i / C4;
-    const int tx = (int)(t % tw);
-    const long r = t / tw;
-    const int ty = (int)(r % th);
-    const long b = r / th;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256u) {   // 32-bit index math
+    const unsigned tu = i / (unsigned)C4, ru = tu / (unsigned)tw, bu = ru / (unsigned)th;          // (total < 2^31, host-checked;
+    const int c4 = (int)(i - tu * (unsigned)C4), tx = (int)(tu - ru * (unsigned)tw), ty = (int)(ru - bu * (unsigned)th);   // 64-bit
+    const long t = tu, b = bu;                                                                  // div / mod cost ~3x the transform)
     const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
     const float *base = x + ((b * H) * (long)W) * (C4 * 4L) + c4 * 4;
     f32x4 d[4][4];
@@ -107,13 +104,10 @@ __global__ __launch_bounds__(256) void wino_out_k(const float *__restrict__ Mm, 
                                                   float *__restrict__ y_amax) {
   float am = 0.f;
   const ymi_amax_pre apre = ymi_amax_prefetch(y_amax);
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
-    const int n4 = (int)(i % N4);
-    const long t = i / N4;
-    const int tx = (int)(t % tw);
-    const long r = t / tw;
-    const int ty = (int)(r % th);
-    const long b = r / th;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256u) {   // 32-bit index math
+    const unsigned tu = i / (unsigned)N4, ru = tu / (unsigned)tw, bu = ru / (unsigned)th;          // (total < 2^31, host-checked;
+    const int n4 = (int)(i - tu * (unsigned)N4), tx = (int)(tu - ru * (unsigned)tw), ty = (int)(ru - bu * (unsigned)th);   // 64-bit
+    const long t = tu, b = bu;                                                                  // div / mod cost ~3x the transform)
     const long stride_e = T * (N4 * 4L);
     const float *src = Mm + t * (N4 * 4L) + n4 * 4;
     f32x4 m[4][4];
@@ -213,13 +207,10 @@ __global__ __launch_bounds__(256) void wino_out_seg_k(const float *__restrict__ 
                                                       int Ho, int Wo, int N4, int Cout, int th, int tw, long T, long total, float *__restrict__ y_amax) {
   float am = 0.f;
   const ymi_amax_pre apre = ymi_amax_prefetch(y_amax);
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
-    const int n4 = (int)(i % N4);
-    const long t = i / N4;
-    const int tx = (int)(t % tw);
-    const long r = t / tw;
-    const int ty = (int)(r % th);
-    const long b = r / th;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256u) {   // 32-bit index math
+    const unsigned tu = i / (unsigned)N4, ru = tu / (unsigned)tw, bu = ru / (unsigned)th;          // (total < 2^31, host-checked;
+    const int n4 = (int)(i - tu * (unsigned)N4), tx = (int)(tu - ru * (unsigned)tw), ty = (int)(ru - bu * (unsigned)th);   // 64-bit
+    const long t = tu, b = bu;                                                                  // div / mod cost ~3x the transform)
     const long stride_e = T * (N4 * 4L);
     const float *src = Mm + t * (N4 * 4L) + n4 * 4;
     f32x4 m[4][4];
@@ -307,13 +298,10 @@ __global__ __launch_bounds__(256) void wino43_in_k(const float *__restrict__ x, 
                                                    int th, int tw, long T, long total, const float *__restrict__ x_amax) {
   float vs = 1.f, vinv = 1.f;
   if (PLANES) ymi_h2_scale(ymi_amax_read(x_amax) * 100.f, vs, vinv);
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
-    const int c4 = (int)(i % C4);
-    const long t = i / C4;
-    const int tx = (int)(t % tw);
-    const long r = t / tw;
-    const int ty = (int)(r % th);
-    const long b = r / th;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256u) {   // 32-bit index math
+    const unsigned tu = i / (unsigned)C4, ru = tu / (unsigned)tw, bu = ru / (unsigned)th;          // (total < 2^31, host-checked;
+    const int c4 = (int)(i - tu * (unsigned)C4), tx = (int)(tu - ru * (unsigned)tw), ty = (int)(ru - bu * (unsigned)th);   // 64-bit
+    const long t = tu, b = bu;                                                                  // div / mod cost ~3x the transform)
     const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
     const float *base = x + ((b * H) * (long)W) * (C4 * 4L) + c4 * 4;
     f32x4 u[6][6];                         // u = B^T d, built column by column
@@ -376,13 +364,10 @@ __global__ __launch_bounds__(256) void wino43_out_k(const float *__restrict__ Mm
                                                     float *__restrict__ y_amax) {
   float am = 0.f;
   const ymi_amax_pre apre = ymi_amax_prefetch(y_amax);
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
-    const int n4 = (int)(i % N4);
-    const long t = i / N4;
-    const int tx = (int)(t % tw);
-    const long r = t / tw;
-    const int ty = (int)(r % th);
-    const long b = r / th;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256u) {   // 32-bit index math
+    const unsigned tu = i / (unsigned)N4, ru = tu / (unsigned)tw, bu = ru / (unsigned)th;          // (total < 2^31, host-checked;
+    const int n4 = (int)(i - tu * (unsigned)N4), tx = (int)(tu - ru * (unsigned)tw), ty = (int)(ru - bu * (unsigned)th);   // 64-bit
+    const long t = tu, b = bu;                                                                  // div / mod cost ~3x the transform)
     f32x4 o[4][4];
     wino43_out_tile(Mm + t * (N4 * 4L) + n4 * 4, T * (N4 * 4L), o);
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
@@ -413,13 +398,10 @@ __global__ __launch_bounds__(256) void wino43_out_seg_k(const float *__restrict_
                                                         int Ho, int Wo, int N4, int Cout, int th, int tw, long T, long total, float *__restrict__ y_amax) {
   float am = 0.f;
   const ymi_amax_pre apre = ymi_amax_prefetch(y_amax);
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
-    const int n4 = (int)(i % N4);
-    const long t = i / N4;
-    const int tx = (int)(t % tw);
-    const long r = t / tw;
-    const int ty = (int)(r % th);
-    const long b = r / th;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256u) {   // 32-bit index math
+    const unsigned tu = i / (unsigned)N4, ru = tu / (unsigned)tw, bu = ru / (unsigned)th;          // (total < 2^31, host-checked;
+    const int n4 = (int)(i - tu * (unsigned)N4), tx = (int)(tu - ru * (unsigned)tw), ty = (int)(ru - bu * (unsigned)th);   // 64-bit
+    const long t = tu, b = bu;                                                                  // div / mod cost ~3x the transform)
     f32x4 o[4][4];
     wino43_out_tile(Mm + t * (N4 * 4L) + n4 * 4, T * (N4 * 4L), o);
     const int kv = seg_vec4(st, n4 * 4, Cout);

@@ -827,9 +827,10 @@ class Plan:
                         self._priors_timed = True
             if fn == 'input':
                 a = self.in_args
-                rc = lib.ymi_nchw_to_nhwc4_f32(x.data_ptr(), a[1], a[2], a[3], a[4], a[5], s)
-                if rc == 0 and self.h2:
-                    rc = lib.ymi_amax_f32(self.in_amax[0], self.in_amax[1], self.in_amax[2], s)
+                if self.h2:          # layout change + magnitude bound of the input in one launch
+                    rc = lib.ymi_nchw_to_nhwc4_amax_f32(x.data_ptr(), a[1], a[2], a[3], a[4], a[5], self.in_amax[2], s)
+                else:
+                    rc = lib.ymi_nchw_to_nhwc4_f32(x.data_ptr(), a[1], a[2], a[3], a[4], a[5], s)
             elif fn == 'record':
                 if two:
                     self.events[args].record(self.stream_b if where == 'B' else cur)
