@@ -28,6 +28,7 @@ def main():
     ap.add_argument('--tiles', default='1,17,5')
     ap.add_argument('--m', default='4')
     ap.add_argument('--shapes', default='', help='comma-separated shape indices (default: all)')
+    ap.add_argument('--batch', type=int, default=0, help='override the batch size of every shape')
     args = ap.parse_args()
     dev = 'cuda:0'
     lib = L.lib()
@@ -35,6 +36,7 @@ def main():
     for si, (name, B, H, W, Cin, Cout) in enumerate(SHAPES):
         if args.shapes and str(si) not in args.shapes.split(','):
             continue
+        B = args.batch or B
         g = torch.Generator().manual_seed(1)
         w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.02
         pk = Packed(w, torch.randn(Cout, generator=g), None, 1, 1, None, dev)
