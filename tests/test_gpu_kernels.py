@@ -513,7 +513,7 @@ def test_fused_bottleneck_matches_fp64_reference_and_the_three_launches():
     """ymi_bottleneck_f32 (csrc/bottleneck.hip: conv1 1x1 -> conv2 3x3 -> conv3 1x1 + identity shortcut in ONE launch, intermediates
     in LDS as fp16x2 planes with per-tile scales) on a ragged size with one hot pixel (so neighbouring tiles pick different scales):
     fp32-class against an fp64 reference, and the same error class as the three separate fp16x2 launches it would replace.
-    Not part of the default plan: measured 0.193 ms against 0.174 ms for the three launches at 138^2 x 8 (profiles/README.md)."""
+    Not part of the default plan: measured 0.180 ms against 0.170 ms for the three launches at 138^2 x 8 (profiles/README.md)."""
     from gpu_utils import DEV
     import ctypes as C
     import torch.nn as nn

@@ -76,10 +76,12 @@ __global__ __launch_bounds__(NTHR) void bottleneck_k(const BnParams p) {
   constexpr int W3CH = 2 * C * 64;                    // ... of the w3 planes
   constexpr int ACH = M1 * 128;                       // bytes of one 32-channel chunk of the x halo tile (fp32)
   constexpr int NS1 = 3, P1S = T1_END, P1STAGE = ACH + WCH;
-  constexpr int NS2 = 4, W2S = T2_END, W3C0 = W2S + NS2 * WCH, RED = W3C0 + W3CH;
-  constexpr int LDS_BYTES = RED + 64;
-  static_assert(NPIX * (C + 4) * 4 <= RED, "output tile");
-  static_assert(P1S + NS1 * P1STAGE <= RED, "phase-1 staging overlaps the reduction scratch");
+  constexpr int NS2 = 3, TAPB = (P / 32) * WCH;          // phase 2 stages one filter TAP (P / 32 chunks) at a time, 3 deep
+  constexpr int W2S = T2_END, W3C0 = W2S + NS2 * TAPB;
+  constexpr int RED = T1H + NHALO * ROWB;                // reduction scratch: the 12 padding rows of the t1 h-plane (never read)
+  constexpr int LDS_BYTES = W3C0 + W3CH;
+  static_assert(NPIX * (C + 4) * 4 <= LDS_BYTES, "output tile");
+  static_assert(P1S + NS1 * P1STAGE <= LDS_BYTES, "phase-1 staging");
   static_assert(W3CH <= T1_END, "the second w3 chunk reuses the t1 planes");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
   static_assert(P == 64, "tile / wave mapping written for P = 64");
@@ -102,6 +104,11 @@ __global__ __launch_bounds__(NTHR) void bottleneck_k(const BnParams p) {
   ymi_h2_scale(ymi_amax_read(p.x_amax), sA, invA);
   const ymi_amax_pre apre = ymi_amax_prefetch(p.y_amax);
   BN_STAMP(0);
+  // folded BN scale / bias of conv1 and conv2 for this lane's output columns: fetched now, not behind the filter DMAs
+  float sc1r[2], bi1r[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { sc1r[j] = p.sc1[32 * j + (lane & 31)]; bi1r[j] = p.bi1[32 * j + (lane & 31)]; }
+  const float sc2r = p.sc2[32 * (wave >> 2) + (lane & 31)], bi2r = p.bi2[32 * (wave >> 2) + (lane & 31)];
 
   // ---- staging addresses ----------------------------------------------------------------------------------------------
   // x chunk: [192 rows][32 floats], 16-byte slots swizzled by (row >> 1) & 7; one wave instruction = 8 rows x 128 bytes
@@ -135,8 +142,11 @@ __global__ __launch_bounds__(NTHR) void bottleneck_k(const BnParams p) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(As + (wave * 8 + 64 * i) * 128), 16, a_voff[i], kc * 128, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(w1rs, (lds_ptr_t)(As + ACH + wave * 1024), 16, w1_voff, kc * 64, 0, 0);
   };
-  auto issue_w2 = [&](int kc, int st) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(w2rs, (lds_ptr_t)(lds + W2S + st * WCH + wave * 1024), 16, w2_voff, kc * 64, 0, 0);
+  auto issue_w2 = [&](int tap, int st) {                   // the P / 32 chunks of one filter tap -> stage st
+#pragma unroll
+    for (int c = 0; c < P / 32; ++c)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w2rs, (lds_ptr_t)(lds + W2S + st * TAPB + c * WCH + wave * 1024), 16, w2_voff,
+                                               (tap * (P / 32) + c) * 64, 0, 0);
   };
   auto issue_w3 = [&](int kc, int base) {
 #pragma unroll
@@ -195,6 +205,7 @@ __global__ __launch_bounds__(NTHR) void bottleneck_k(const BnParams p) {
   constexpr int NK1 = C / 32;
   issue_p1(0, 0);
   issue_p1(1, 1);
+  asm volatile("" ::"v"(sc1r[0]), "v"(sc1r[1]), "v"(bi1r[0]), "v"(bi1r[1]), "v"(sc2r), "v"(bi2r));   // (keeps those loads up here)
   const int fsw = (lane >> 1) & 7;
   for (int kc = 0; kc < NK1; ++kc) {
     if (kc + 1 < NK1) BN_WAIT_VM(4); else BN_WAIT_VM(0);
@@ -219,15 +230,13 @@ __global__ __launch_bounds__(NTHR) void bottleneck_k(const BnParams p) {
   issue_w3(0, W3C0);
   issue_w2(0, 0);
   issue_w2(1, 1);
-  issue_w2(2, 2);
   {
     float v1[2][16];
     float am = 0.f;
     if (wave < M1 / 32) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const int n = 32 * j + (lane & 31);
-        const float sc = p.sc1[n], bi = p.bi1[n];
+        const float sc = sc1r[j], bi = bi1r[j];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = wave * 32 + crow(r, lane);
@@ -256,26 +265,26 @@ __global__ __launch_bounds__(NTHR) void bottleneck_k(const BnParams p) {
     f32x16 acc2;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
-    constexpr int NK2 = 9 * P / 32, CPT = P / 32;          // chunks, chunks per filter tap
-    for (int kc = 0; kc < NK2; ++kc) {
-      const int rem = NK2 - 1 - kc;                        // later chunks
-      if (rem >= 2) BN_WAIT_VM(2); else if (rem == 1) BN_WAIT_VM(1); else BN_WAIT_VM(0);
+    constexpr int CPT = P / 32;                            // chunks per filter tap
+    for (int tap = 0; tap < 9; ++tap) {                    // one barrier per tap (2 chunks, 12 MFMAs per wave)
+      if (tap + 1 < 9) BN_WAIT_VM(CPT); else BN_WAIT_VM(0);
       BN_BARRIER();                                        // (the first one also publishes the t1 planes)
-      if (kc + 3 < NK2) issue_w2(kc + 3, (kc + 3) % NS2);
-      const int tap = kc / CPT, cc = kc - tap * CPT;
+      if (tap + 2 < 9) issue_w2(tap + 2, (tap + 2) % NS2);
       const int ky = tap / 3, kx = tap - ky * 3;
       const int hp = (py + ky) * HW2 + (px + kx);
-      const unsigned char *Bp = lds + W2S + (kc % NS2) * WCH;
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-        mfma3(acc2, load_t(T1H, T1L, hp, 4 * cc + 2 * s2 + hh), load_b(Bp, P, nt, s2));
+      for (int cc = 0; cc < CPT; ++cc) {
+        const unsigned char *Bp = lds + W2S + (tap % NS2) * TAPB + cc * WCH;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+          mfma3(acc2, load_t(T1H, T1L, hp, 4 * cc + 2 * s2 + hh), load_b(Bp, P, nt, s2));
+      }
     }
     BN_STAMP(3);
     float v2[16];
     float am2 = 0.f;
     {
-      const int n = 32 * nt + (lane & 31);
-      const float sc = p.sc2[n], bi = p.bi2[n];
+      const float sc = sc2r, bi = bi2r;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float v = (acc2[r] * inv1) * sc + bi;
