@@ -125,7 +125,8 @@ def roofline(net, x, reps=3):
     # record kinds: 0/1/2 = one direct conv launch (loader id), 7 = a direct 1x1 launch on the pointwise loader (kernel
     # template LOADER 3); 3 / 4 = a whole Winograd F(2x2) / F(4x4) layer (input transform + 16- / 36-group GEMM + output
     # transform, ALGORITHMIC conv FLOPs); 5 / 6 = the Winograd GEMM launch alone (the FLOPs it executes).
-    # Layer table / all_conv: kinds 0-4 and 7.  Single-kernel roofline: kinds 0-2, 7, 5 and 6.
+    # 8 = the fused ResNet stem launch (layout change + 7x7 conv + BN + ReLU + max-pool; the conv's algorithmic FLOPs).
+    # Layer table / all_conv: kinds 0-4, 7 and 8.  Single-kernel roofline: kinds 0-2, 7, 8, 5 and 6.
     by_kernel, layers = {}, {}
     tot_ms = tot_fl = 0.0
     li = -1
@@ -142,6 +143,9 @@ def roofline(net, x, reps=3):
             nbytes = 0.0
         elif kind.value in (5, 6):
             nbytes = wino_pending['gemm']
+        elif kind.value == 8:                        # fused stem (csrc/stem.hip): NCHW image in, filters, POOLED map out
+            d8 = descs[(li + 1) % nl]
+            nbytes = 4.0 * (d8.B * d8.H * d8.W * 3 + 64 * 147 + d8.B * ((d8.Ho - 1) // 2 + 1) * ((d8.Wo - 1) // 2 + 1) * 64)
         else:
             nbytes = conv_alg_bytes(descs[(li + 1) % nl])
         if kind.value not in (3, 4):
@@ -153,13 +157,15 @@ def roofline(net, x, reps=3):
         if kind.value not in (5, 6):
             li += 1
             lkey = ('winograd F(%dx%d,3x3) <gemm %s> (3 launches)' % (2 * kind.value - 4, 2 * kind.value - 4, tname)) \
-                if kind.value in (3, 4) else 'conv_igemm_f32<%s,loader%d>' % (tname, 3 if kind.value == 7 else kind.value)
+                if kind.value in (3, 4) else 'stem_pool_k<%s,conv 7x7/2 + BN + ReLU + max-pool 3x3/2 fused>' % tname if kind.value == 8 \
+                else 'conv_igemm_f32<%s,loader%d>' % (tname, 3 if kind.value == 7 else kind.value)
             la = layers.setdefault(names[li % nl], [0.0, fl.value, lkey])
             la[0] += ms.value / reps
             la[2] = lkey
             tot_ms += ms.value; tot_fl += fl.value
         if kind.value not in (3, 4):
             key = ('conv_igemm_f32<%s,winograd grouped GEMM>' % tname) if kind.value in (5, 6) else \
+                ('stem_pool_k<%s,fused stem>' % tname) if kind.value == 8 else \
                 'conv_igemm_f32<%s,loader%d>' % (tname, 3 if kind.value == 7 else kind.value)
             a = by_kernel.setdefault(key, [0.0, 0.0, 0, 0.0, 0.0, 0.0])
             a[0] += ms.value; a[1] += fl.value; a[2] += 1; a[3] += nbytes

@@ -375,6 +375,22 @@ typedef struct ymi_bneck_desc {
 } ymi_bneck_desc;
 int ymi_bottleneck_f32(const ymi_bneck_desc *d, void *stream);
 
+/* -- ResNet stem in one launch (backbone.py:126-133 + the layout change of yolact.py:564) ---------------------------------
+ * x [B,3,H,W] NCHW fp32 (the normalised image) -> conv 7x7 / 2 / pad 3 (3 -> 64) + folded BN + ReLU -> max-pool 3x3 / 2 / pad 1
+ * -> y [B,Hp,Wp,64] NHWC fp32, Hp = ((H - 1) / 2 + 1 - 1) / 2 + 1.  The 64-channel stem output stays in LDS (csrc/stem.hip).
+ * fp16x2 arithmetic: filters as the two fp16 planes of engine.Packed(cin_pad = 4).h2() (k = (7 ky + kx) * 4 + c, Kpad 224);
+ * the input is scaled per tile from the tile's own maximum, so no magnitude bound of x is needed; y_amax as in ymi_conv_desc. */
+typedef struct ymi_stem_desc {
+  const float *x;        /* [B,3,H,W] */
+  float *y;              /* [B,Hp,Wp,64] */
+  int32_t B, H, W, cout_pad;
+  const void *w_h2;      /* fp16 planes [2][cout_pad][kpad] */
+  const float *scale_h2, *bias;
+  float *y_amax;         /* magnitude-bound slot of y (may be NULL) */
+  int32_t kpad, _pad0;   /* 224 */
+} ymi_stem_desc;
+int ymi_stem_pool_f32(const ymi_stem_desc *d, void *stream);
+
 /* -- profiling hooks -------------------------------------------------------------------- */
 /* When enabled, every conv launch is bracketed by hipEvents on its stream; ymi_prof_read returns
  * (after synchronising) per-launch milliseconds, flops and tile ids. Used by bench.py roofline. */

@@ -565,3 +565,61 @@ def test_fused_bottleneck_matches_fp64_reference_and_the_three_launches():
     assert amax[1024:].max().item() == y.max().item()            # the launch reports the magnitude bound of what it wrote
     d.P = 128
     assert lib.ymi_bottleneck_f32(C.byref(d), s) == -2              # YMI_ESHAPE: only the 64-channel form is instantiated
+
+
+@pytest.mark.parametrize('B,H,W', [(2, 61, 77), (1, 550, 550)])
+def test_fused_stem_matches_reference_and_the_three_launches(B, H, W):
+    """ymi_stem_pool_f32 (csrc/stem.hip): NCHW image -> conv 7x7/2 + BN + ReLU -> max-pool 3x3/2 -> NHWC in one launch, per-tile input
+    scales.  fp32-class against an fp64 torch reference (ragged size, a hot patch so that tiles pick different scales), and
+    BIT-IDENTICAL to the three launches it replaces in the plan (a power-of-two scale does not change which mantissa bits the two
+    fp16 pieces keep), including the magnitude bound it reports."""
+    from gpu_utils import DEV
+    import ctypes as C
+    import torch.nn as nn
+    from yolact_amd.engine import Packed, out_size
+    lib, s = L.lib(), L.stream_ptr()
+    g = _g(7)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.08
+    bn = nn.BatchNorm2d(64)
+    bn.weight.data = torch.rand(64, generator=g) + 0.5
+    bn.bias.data = torch.randn(64, generator=g) * 0.2
+    bn.running_mean = torch.randn(64, generator=g) * 0.1
+    bn.running_var = torch.rand(64, generator=g) + 0.5
+    bn.eval()
+    pk = Packed(w, None, bn, 2, 3, 4, DEV)
+    hp, sc2, winv = pk.h2()
+    x = torch.randn(B, 3, H, W, generator=g) * 1.3
+    x[-1, :, H // 2:H // 2 + 4, W // 2:W // 2 + 4] *= 30.0
+    xd = x.to(DEV)
+    Hs, Ws = out_size(H, 7, 2, 3), out_size(W, 7, 2, 3)
+    Hp, Wp = out_size(Hs, 3, 2, 1), out_size(Ws, 3, 2, 1)
+    y = torch.zeros(B, Hp, Wp, 64, device=DEV)
+    amax = torch.zeros(3 * 1024, device=DEV)
+    d = L.StemDesc()
+    d.x, d.y, d.B, d.H, d.W, d.cout_pad, d.kpad = xd.data_ptr(), y.data_ptr(), B, H, W, pk.CoutPad, pk.Kpad
+    d.w_h2, d.scale_h2, d.bias, d.y_amax = hp.data_ptr(), sc2.data_ptr(), pk.bias.data_ptr(), amax.data_ptr()
+    L.check(lib.ymi_stem_pool_f32(C.byref(d), s), 'stem')
+    # the plan's three launches
+    x4 = torch.empty(B, H, W, 4, device=DEV); st = torch.empty(B, Hs, Ws, 64, device=DEV); y3 = torch.empty_like(y)
+    L.check(lib.ymi_nchw_to_nhwc4_amax_f32(xd.data_ptr(), x4.data_ptr(), B, 3, H, W, amax.data_ptr() + 4096, s))
+    cd = L.ConvDesc()
+    cd.x, cd.w, cd.bias, cd.scale = x4.data_ptr(), pk.w.data_ptr(), pk.bias.data_ptr(), pk.scale.data_ptr()
+    cd.B, cd.H, cd.W, cd.Cin, cd.ldx, cd.Ho, cd.Wo, cd.Cout = B, H, W, 4, 4, Hs, Ws, 64
+    cd.kh, cd.kw, cd.stride, cd.pad, cd.Kpad, cd.nseg, cd.cin_alg = 7, 7, 2, 3, pk.Kpad, 1, 3
+    cd.seg[0] = L.ConvSeg(0, 64, L.ACT_RELU, 64, Hs * Ws * 64, st.data_ptr())
+    cd.w_h2, cd.scale_h2, cd.winv_h2 = hp.data_ptr(), sc2.data_ptr(), winv.data_ptr()
+    cd.x_amax, cd.y_amax = amax.data_ptr() + 4096, amax.data_ptr() + 8192
+    cd.tile = L.TILE_128x64 | L.TILE_H2
+    L.check(lib.ymi_conv2d_nhwc_f32(C.byref(cd), s), 'stem conv')
+    L.check(lib.ymi_maxpool3x3s2_nhwc_f32(st.data_ptr(), y3.data_ptr(), B, Hs, Ws, 64, Hp, Wp, s))
+    torch.cuda.synchronize()
+    assert torch.equal(y, y3), 'fused stem differs from conv + max-pool'
+    assert amax[:1024].max().item() == y.max().item()
+    if H < 100:
+        t = torch.nn.functional.conv2d(x.double(), w.double(), stride=2, padding=3)
+        inv = 1.0 / torch.sqrt(bn.running_var.double() + bn.eps)
+        t = t * (bn.weight.double() * inv).view(1, -1, 1, 1) + (bn.bias.double() - bn.running_mean.double() * bn.weight.double() * inv).view(1, -1, 1, 1)
+        ref = torch.nn.functional.max_pool2d(torch.relu(t), 3, 2, 1).permute(0, 2, 3, 1).contiguous()
+        err = (y.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+        print('fused stem: max error %.2e of max|y|' % err)
+        assert err < 1e-6

@@ -55,6 +55,8 @@ def _accesses(plan, op, bufs):
     lib = plan.lib
     if fn == 'input':
         return set(), {_owner(bufs, plan.in_args[1])}
+    if fn == 'stem':                                   # fused stem: reads the caller's NCHW image, writes the pooled map
+        return set(), {_owner(bufs, args.y)}
     if fn == 'detect':
         return {('loc', None), ('conf', None), ('coef', None)}, set()
     if fn is lib.ymi_dcn_v2_forward_f32:

@@ -9,7 +9,7 @@ rows = [r for r in csv.DictReader(open(sys.argv[1])) if r['Kind'] == 'KERNEL_DIS
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 # a step starts at the input layout kernel
-starts = [i for i, r in enumerate(rows) if 'nchw_to_nhwc4_k' in r['Kernel_Name']]
+starts = [i for i, r in enumerate(rows) if 'nchw_to_nhwc4_k' in r['Kernel_Name'] or 'stem_pool_k' in r['Kernel_Name']]
 starts = starts[-(nsteps + 4):-3]              # drop the 3 serialised roofline passes at the end, keep the last timed steps
 tot = defaultdict(float)
 for a, b in zip(starts[:-1], starts[1:]):

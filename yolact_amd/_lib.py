@@ -99,6 +99,12 @@ class BneckDesc(C.Structure):
                 ('scale3', C.c_void_p), ('bias3', C.c_void_p), ('x_amax', C.c_void_p), ('y_amax', C.c_void_p)]
 
 
+class StemDesc(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('y', C.c_void_p), ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('cout_pad', C.c_int32),
+                ('w_h2', C.c_void_p), ('scale_h2', C.c_void_p), ('bias', C.c_void_p), ('y_amax', C.c_void_p),
+                ('kpad', C.c_int32), ('_pad0', C.c_int32)]
+
+
 EFORMAT, EUNSUPPORTED = -4, -5
 
 # every symbol include/yolact_amd.h declares: (name, restype, argtypes)
@@ -132,6 +138,7 @@ SYMBOLS = [
     ('ymi_mask_upsample_bits', C.c_int, [_P, _I, _I, _I, _I, _I, _F, _P, _P]),
     ('ymi_mask_iou_bits', C.c_int, [_P, _P, _I, _I, C.c_long, _I, _P, _P]),
     ('ymi_bottleneck_f32', C.c_int, [_P, _P]),
+    ('ymi_stem_pool_f32', C.c_int, [_P, _P]),
     ('ymi_mask_rle_f32', C.c_int, [_P, _I, _I, _I, _P, _P, _I, _P]),
     ('ymi_mask_rle_upsampled_f32', C.c_int, [_P, _I, _I, _I, _I, _I, _F, _P, _P, _I, _P]),
     ('ymi_rle_to_string', C.c_int, [_P, _P, _I, _I, _P, _P, _I, _P]),

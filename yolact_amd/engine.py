@@ -481,13 +481,21 @@ class Plan:
         lib = self.lib
         ar = self.arena
 
-        # input: NCHW fp32 -> NHWC with C padded to 4 (pointer patched per call)
-        x4 = self._new(B, H, W, 4, slot=self._slot())
-        self.in_args = [None, x4.ptr, B, 3, H, W]
-        self.in_amax = (x4.ptr, B * H * W * 4, self._slot_ptr(x4.slot))    # the input's magnitude bound: ymi_amax_f32
-        self.ops.append(('input', None, 'nchw_to_nhwc4', 'A'))
-
         bb = net.backbone
+        # ResNet stem (fp16x2 plans): layout change + 7x7/2 conv + BN + ReLU + 3x3/2 max-pool in ONE launch straight from the NCHW
+        # input (csrc/stem.hip: 0.107 vs 0.168 ms for the three launches at batch 8, 0.020 vs 0.035 at batch 1, bit-identical
+        # output; profiles/r03_stem_probe.txt).  YOLACT_AMD_FUSED_STEM=0 keeps the separate launches.
+        c1 = getattr(bb, 'conv1', None)
+        self.fused_stem = (self.h2 and isinstance(bb, M.ResNetBackbone) and os.environ.get('YOLACT_AMD_FUSED_STEM', '1') == '1'
+                           and c1 is not None and tuple(c1.kernel_size) == (7, 7) and tuple(c1.stride) == (2, 2)
+                           and tuple(c1.padding) == (3, 3) and c1.in_channels == 3 and c1.out_channels == 64 and H >= 7 and W >= 7)
+        x4 = None
+        if not self.fused_stem:
+            # input: NCHW fp32 -> NHWC with C padded to 4 (pointer patched per call)
+            x4 = self._new(B, H, W, 4, slot=self._slot())
+            self.in_args = [None, x4.ptr, B, 3, H, W]
+            self.in_amax = (x4.ptr, B * H * W * 4, self._slot_ptr(x4.slot))    # the input's magnitude bound: ymi_amax_f32
+            self.ops.append(('input', None, 'nchw_to_nhwc4', 'A'))
         if isinstance(bb, M.ResNetBackbone):
             outs = self._resnet(bb, x4)
         else:
@@ -677,12 +685,29 @@ class Plan:
 
     def _resnet(self, bb: M.ResNetBackbone, x4: T):
         dev, ar, lib = self.device, self.arena, self.lib
-        stem = self.conv('stem', x4, pack_module(bb.conv1, bb.bn1, dev, cin_pad=4), act=L.ACT_RELU)
-        ar.free(x4)
-        Hp, Wp = out_size(stem.H, 3, 2, 1), out_size(stem.W, 3, 2, 1)
-        x = self._new(stem.B, Hp, Wp, stem.C, slot=stem.slot)        # max-pooling cannot raise the magnitude bound
-        self.call(lib.ymi_maxpool3x3s2_nhwc_f32, stem.ptr, x.ptr, stem.B, stem.H, stem.W, stem.C, Hp, Wp, name='maxpool')
-        ar.free(stem)
+        pk0 = pack_module(bb.conv1, bb.bn1, dev, cin_pad=4)
+        if self.fused_stem:
+            B, H, W = self.B, self.H, self.W
+            Hs, Ws = out_size(H, 7, 2, 3), out_size(W, 7, 2, 3)
+            Hp, Wp = out_size(Hs, 3, 2, 1), out_size(Ws, 3, 2, 1)
+            x = self._new(B, Hp, Wp, 64, slot=self._slot())
+            planes, sc2, winv = pk0.h2()
+            sd = L.StemDesc()
+            sd.y, sd.B, sd.H, sd.W, sd.cout_pad, sd.kpad = x.ptr, B, H, W, pk0.CoutPad, pk0.Kpad
+            sd.w_h2, sd.scale_h2, sd.bias, sd.y_amax = planes.data_ptr(), sc2.data_ptr(), pk0.bias.data_ptr(), self._slot_ptr(x.slot)
+            self.keepalive.append(pk0)
+            md = L.ConvDesc()          # accounting only (FLOPs of the 7x7 conv; bench.py takes the bytes of the fused launch)
+            md.B, md.H, md.W, md.Cin, md.ldx, md.Ho, md.Wo, md.Cout = B, H, W, 4, 4, Hs, Ws, 64
+            md.kh, md.kw, md.stride, md.pad, md.Kpad, md.cin_alg, md.cout_alg = 7, 7, 2, 3, pk0.Kpad, 3, 64
+            self.conv_meta.append(('stem', md))
+            self.ops.append(('stem', sd, 'stem+maxpool', 'A'))
+        else:
+            stem = self.conv('stem', x4, pk0, act=L.ACT_RELU)
+            ar.free(x4)
+            Hp, Wp = out_size(stem.H, 3, 2, 1), out_size(stem.W, 3, 2, 1)
+            x = self._new(stem.B, Hp, Wp, stem.C, slot=stem.slot)        # max-pooling cannot raise the magnitude bound
+            self.call(lib.ymi_maxpool3x3s2_nhwc_f32, stem.ptr, x.ptr, stem.B, stem.H, stem.W, stem.C, Hp, Wp, name='maxpool')
+            ar.free(stem)
         outs = []
         for li, layer in enumerate(bb.layers):
             for bi, blk in enumerate(layer):
@@ -831,6 +856,9 @@ class Plan:
                     rc = lib.ymi_nchw_to_nhwc4_amax_f32(x.data_ptr(), a[1], a[2], a[3], a[4], a[5], self.in_amax[2], s)
                 else:
                     rc = lib.ymi_nchw_to_nhwc4_f32(x.data_ptr(), a[1], a[2], a[3], a[4], a[5], s)
+            elif fn == 'stem':
+                args.x = x.data_ptr()
+                rc = lib.ymi_stem_pool_f32(C.byref(args), s)
             elif fn == 'record':
                 if two:
                     self.events[args].record(self.stream_b if where == 'B' else cur)
