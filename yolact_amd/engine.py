@@ -483,7 +483,7 @@ class Plan:
 
         bb = net.backbone
         # ResNet stem (fp16x2 plans): layout change + 7x7/2 conv + BN + ReLU + 3x3/2 max-pool in ONE launch straight from the NCHW
-        # input (csrc/stem.hip: 0.107 vs 0.168 ms for the three launches at batch 8, 0.020 vs 0.035 at batch 1, bit-identical
+        # input (csrc/stem.hip: 0.107 vs 0.168 ms for the three launches at batch 8, 0.020 vs 0.035 at batch 1, bit-identical (see the test for the exact statement)
         # output; profiles/r03_stem_probe.txt).  YOLACT_AMD_FUSED_STEM=0 keeps the separate launches.
         c1 = getattr(bb, 'conv1', None)
         self.fused_stem = (self.h2 and isinstance(bb, M.ResNetBackbone) and os.environ.get('YOLACT_AMD_FUSED_STEM', '1') == '1'
