@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define YMI_ABI_VERSION 3
+#define YMI_ABI_VERSION 4
 
 /* negative return codes (ymi_strerror) */
 #define YMI_EFORMAT (-4)       /* corrupt or truncated input stream (ymi_jpeg_*) */
@@ -170,6 +170,12 @@ typedef struct {
   const float *uinv_h2;
   const float *x_amax;
   float *y_amax;
+  /* ABI 4, m = 4 only.  x_up != NULL: the layer's input is F.interpolate(x_up, scale_factor 2, bilinear, align_corners False)
+   * (+ ReLU if up_relu) of x_up [B,H/2,W/2,C] (H, W even), evaluated INSIDE the input transform with the operation order of
+   * ymi_bilinear_nhwc_f32 (bit-identical to materialising it; `x` is ignored).  Saves the write and the read of the upsampled
+   * tensor: protonet's interpolate -> conv (utils/functions.py:187-206, yolact.py:588-599).  x_amax = the bound of x_up. */
+  const float *x_up;
+  int32_t up_relu, _pad4;
 } ymi_wino_desc;
 int ymi_conv3x3_winograd_f32(const ymi_wino_desc *d, void *stream);
 

@@ -88,8 +88,9 @@ def build_net(meta, device=DEV):
     return net.to(device)
 
 
-def run_wino(x, weight, bias=None, bn=None, act=L.ACT_NONE, tile=L.TILE_AUTO, m=2, v_planes=False):
-    """3x3 / stride 1 / pad 1 conv through ymi_conv3x3_winograd_f32. x: CPU NCHW. Returns CPU NCHW."""
+def run_wino(x, weight, bias=None, bn=None, act=L.ACT_NONE, tile=L.TILE_AUTO, m=2, v_planes=False, up_from=None, up_relu=False):
+    """3x3 / stride 1 / pad 1 conv through ymi_conv3x3_winograd_f32. x: CPU NCHW. Returns CPU NCHW.
+    up_from (CPU NCHW, half the size of x): the launch interpolates its input from it (ymi_wino_desc.x_up); `x` only gives the shape."""
     from yolact_amd.engine import WinoPacked
     pk = Packed(weight, bias, bn, 1, 1, None, DEV)          # folded scale / bias
     wp = WinoPacked(weight, DEV, m)
@@ -111,6 +112,9 @@ def run_wino(x, weight, bias=None, bn=None, act=L.ACT_NONE, tile=L.TILE_AUTO, m=
     amax = torch.zeros(2 * 1024, device=DEV)
     L.check(L.lib().ymi_amax_f32(xd.data_ptr(), xd.numel(), amax.data_ptr(), L.stream_ptr()), 'amax')
     d.x_amax, d.y_amax = amax.data_ptr(), amax.data_ptr() + 4096
+    if up_from is not None:
+        lo = nhwc(up_from).to(DEV)
+        d.x, d.x_up, d.up_relu = None, lo.data_ptr(), 1 if up_relu else 0
     if tile & L.TILE_H2:
         up, uinv = wp.h2()
         d.u_h2, d.uinv_h2, d.v_planes = up.data_ptr(), uinv.data_ptr(), 1 if v_planes else 0

@@ -630,3 +630,32 @@ def test_fused_stem_matches_reference_and_the_three_launches(B, H, W):
         err = (y.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
         print('fused stem: max error %.2e of max|y|' % err)
         assert err < 1e-6
+
+
+@pytest.mark.parametrize('tile,v_planes,relu', [(L.TILE_64x64, False, True), (L.TILE_64x64 | L.TILE_H2, True, True),
+                                                (L.TILE_128x128 | L.TILE_H2, False, False)])
+def test_winograd_fused_upsample_is_bit_identical(tile, v_planes, relu):
+    """ymi_wino_desc.x_up: the F(4x4,3x3) input transform interpolates its 6 x 6 patches from the half-size tensor (protonet's
+    interpolate -> conv, utils/functions.py:187-206) instead of reading a materialised upsampling: same bits as
+    ymi_bilinear_nhwc_f32 followed by the plain launch, including the image borders where the reference clamps its source rows."""
+    from gpu_utils import DEV, run_wino, nhwc, nchw
+    g = _g(23)
+    B, Cc, Hl, Wl = 2, 32, 11, 13
+    lo = torch.randn(B, Cc, Hl, Wl, generator=g)
+    w = torch.randn(32, Cc, 3, 3, generator=g) * 0.1
+    bias = torch.randn(32, generator=g) * 0.1
+    lod = nhwc(lo).to(DEV)
+    up = torch.empty(B, 2 * Hl, 2 * Wl, Cc, device=DEV)
+    L.check(L.lib().ymi_bilinear_nhwc_f32(lod.data_ptr(), up.data_ptr(), B, Hl, Wl, Cc, 2 * Hl, 2 * Wl, 0.5, 0.5, 1 if relu else 0,
+                                         L.stream_ptr()))
+    torch.cuda.synchronize()
+    x_up = nchw(up.cpu())
+    ref = torch.nn.functional.interpolate(lo, scale_factor=2, mode='bilinear', align_corners=False)
+    if relu:
+        ref = torch.relu(ref)
+    assert (x_up - ref).abs().max().item() < 1e-6          # the materialised upsampling itself is torch's
+    y_sep = run_wino(x_up, w, bias, None, L.ACT_RELU, tile, 4, v_planes)
+    y_fused = run_wino(x_up, w, bias, None, L.ACT_RELU, tile, 4, v_planes, up_from=lo, up_relu=relu)
+    assert torch.equal(y_fused, y_sep)
+    with pytest.raises(RuntimeError):                      # F(2x2) has no fused form
+        run_wino(x_up, w, bias, None, L.ACT_RELU, tile, 2, v_planes, up_from=lo, up_relu=relu)

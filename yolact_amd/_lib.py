@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libyolact_amd.so')
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 ACT_NONE, ACT_RELU, ACT_LEAKY01, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 RES_NONE, RES_ADD, RES_BILINEAR = 0, 1, 2
@@ -63,7 +63,8 @@ class WinoDesc(C.Structure):
                 ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('C', C.c_int32), ('Cout', C.c_int32),
                 ('act', C.c_int32), ('tile', C.c_int32), ('nseg', C.c_int32), ('m', C.c_int32), ('_pad0', C.c_int32),
                 ('seg', ConvSeg * 3), ('u_x3', C.c_void_p), ('cout_alg', C.c_int32), ('v_planes', C.c_int32),
-                ('u_h2', C.c_void_p), ('uinv_h2', C.c_void_p), ('x_amax', C.c_void_p), ('y_amax', C.c_void_p)]
+                ('u_h2', C.c_void_p), ('uinv_h2', C.c_void_p), ('x_amax', C.c_void_p), ('y_amax', C.c_void_p),
+                ('x_up', C.c_void_p), ('up_relu', C.c_int32), ('_pad4', C.c_int32)]
 
 
 class DcnDesc(C.Structure):

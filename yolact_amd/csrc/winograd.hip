@@ -293,9 +293,24 @@ __device__ __forceinline__ void bt6(const f32x4 v0, const f32x4 v1, const f32x4 
 
 // one thread = one 6x6 input patch (tile) x 4 channels.  x [B,H,W,C] NHWC, V [36][T][C]  (PLANES: fp16x2 planes [36][2][T][C];
 // |B^T d B| <= 100 max|d|: every row of B^T has an absolute sum of at most 10)
-template <bool PLANES>
+// torch's area_pixel_compute_source_index for align_corners = False, exactly as csrc/layout.hip bl_coord evaluates it
+__device__ __forceinline__ void up2_coord(int dst, int in_size, float &l1) {
+  float src = 0.5f * ((float)dst + 0.5f) - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  int i0 = (int)src;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  l1 = src - (float)i0;
+}
+
+// UPS: the layer's input is the 2x bilinear upsampling (+ ReLU) of xl [B,H/2,W/2,C]: the 6 x 6 patch of a tile (hi-res rows
+// 4 ty - 1 .. 4 ty + 4) only touches the 4 x 4 low-res window starting at (2 ty - 1, 2 tx - 1): hi-res offset r uses window rows
+// r >> 1 and (r >> 1) + 1 (window addresses clamped to the image: where the reference clamps i0 / i1 the weights it derives are
+// such that the duplicated row reproduces its arithmetic), with the weights of bl_coord and the operation order of
+// bilinear_nhwc_k: hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11).  16 loads instead of 36, no upsampled tensor in HBM.
+template <bool PLANES, bool UPS = false>
 __global__ __launch_bounds__(256) void wino43_in_k(const float *__restrict__ x, float *__restrict__ V, int H, int W, int C4,
-                                                   int th, int tw, long T, long total, const float *__restrict__ x_amax) {
+                                                   int th, int tw, long T, long total, const float *__restrict__ x_amax,
+                                                   int up_relu = 0) {
   float vs = 1.f, vinv = 1.f;
   if (PLANES) ymi_h2_scale(ymi_amax_read(x_amax) * 100.f, vs, vinv);
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256u) {   // 32-bit index math
@@ -303,8 +318,47 @@ __global__ __launch_bounds__(256) void wino43_in_k(const float *__restrict__ x, 
     const int c4 = (int)(i - tu * (unsigned)C4), tx = (int)(tu - ru * (unsigned)tw), ty = (int)(ru - bu * (unsigned)th);   // 64-bit
     const long t = tu, b = bu;                                                                  // div / mod cost ~3x the transform)
     const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
-    const float *base = x + ((b * H) * (long)W) * (C4 * 4L) + c4 * 4;
     f32x4 u[6][6];                         // u = B^T d, built column by column
+    if constexpr (UPS) {
+      const int Hl = H >> 1, Wl = W >> 1;
+      const float *lbase = x + ((b * Hl) * (long)Wl) * (C4 * 4L) + c4 * 4;
+      f32x4 lo[4][4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        int wy = 2 * ty - 1 + k; wy = wy < 0 ? 0 : (wy > Hl - 1 ? Hl - 1 : wy);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          int wx = 2 * tx - 1 + q; wx = wx < 0 ? 0 : (wx > Wl - 1 ? Wl - 1 : wx);
+          lo[k][q] = *reinterpret_cast<const f32x4 *>(lbase + ((long)wy * Wl + wx) * (C4 * 4L));
+        }
+      }
+      float lx[6], ly[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) { up2_coord(x0 + j, Wl, lx[j]); up2_coord(y0 + j, Hl, ly[j]); }
+      f32x4 hrow[4][6];                    // horizontal pass first (the reference's inner brackets)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) hrow[k][j] = (1.f - lx[j]) * lo[k][j >> 1] + lx[j] * lo[k][(j >> 1) + 1];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const bool xok = (unsigned)(x0 + j) < (unsigned)W;
+        f32x4 dcol[6];
+#pragma unroll
+        for (int iy = 0; iy < 6; ++iy) {
+          const bool ok = xok && (unsigned)(y0 + iy) < (unsigned)H;
+          f32x4 v = (1.f - ly[iy]) * hrow[iy >> 1][j] + ly[iy] * hrow[(iy >> 1) + 1][j];
+          if (up_relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];
+          }
+          const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          dcol[iy] = ok ? v : z;
+        }
+        bt6(dcol[0], dcol[1], dcol[2], dcol[3], dcol[4], dcol[5], u[0][j], u[1][j], u[2][j], u[3][j], u[4][j], u[5][j]);
+      }
+    } else {
+    const float *base = x + ((b * H) * (long)W) * (C4 * 4L) + c4 * 4;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       const int xx = x0 + j;
@@ -317,6 +371,7 @@ __global__ __launch_bounds__(256) void wino43_in_k(const float *__restrict__ x, 
         dcol[iy] = ld4(base + ((long)(ok ? yy : 0) * W + (ok ? xx : 0)) * (C4 * 4L), ok);
       }
       bt6(dcol[0], dcol[1], dcol[2], dcol[3], dcol[4], dcol[5], u[0][j], u[1][j], u[2][j], u[3][j], u[4][j], u[5][j]);
+    }
     }
     const long stride_e = T * (C4 * 4L);
     float *o = V + t * (C4 * 4L) + c4 * 4;
@@ -455,7 +510,8 @@ unsigned grid_for(long total) {
 }  // namespace
 
 extern "C" int ymi_conv3x3_winograd_f32(const ymi_wino_desc *d, void *stream) {
-  if (!d || !d->x || !d->u || !d->V || !d->M) return YMI_ENULL;
+  if (!d || (!d->x && !d->x_up) || !d->u || !d->V || !d->M) return YMI_ENULL;
+  if (d->x_up && (d->m != 4 || (d->H & 1) || (d->W & 1) || (((uintptr_t)d->x_up) & 15))) return YMI_ESHAPE;   // fused 2x upsampling: F(4x4) only
   if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->Cout <= 0 || d->nseg < 0 || d->nseg > 3) return YMI_EARG;
   if (d->nseg == 0 && (!d->y || (d->Cout & 3) || d->act > YMI_ACT_LEAKY01 || d->act < 0)) return YMI_ESHAPE;
   for (int k = 0; k < d->nseg; ++k) if (!d->seg[k].ptr) return YMI_ENULL;
@@ -479,8 +535,11 @@ extern "C" int ymi_conv3x3_winograd_f32(const ymi_wino_desc *d, void *stream) {
   if (h2 && (!d->u_h2 || !d->uinv_h2 || !d->x_amax)) return YMI_ENULL;
   const bool planes = h2 && d->v_planes != 0;
   if (mt == 4) {
-    if (planes) hipLaunchKernelGGL(wino43_in_k<true>, dim3(grid_for(T * C4)), dim3(256), 0, s, d->x, d->V, d->H, d->W, C4, th, tw, T, T * C4, d->x_amax);
-    else hipLaunchKernelGGL(wino43_in_k<false>, dim3(grid_for(T * C4)), dim3(256), 0, s, d->x, d->V, d->H, d->W, C4, th, tw, T, T * C4, d->x_amax);
+    if (d->x_up) {
+      if (planes) hipLaunchKernelGGL((wino43_in_k<true, true>), dim3(grid_for(T * C4)), dim3(256), 0, s, d->x_up, d->V, d->H, d->W, C4, th, tw, T, T * C4, d->x_amax, d->up_relu);
+      else hipLaunchKernelGGL((wino43_in_k<false, true>), dim3(grid_for(T * C4)), dim3(256), 0, s, d->x_up, d->V, d->H, d->W, C4, th, tw, T, T * C4, d->x_amax, d->up_relu);
+    } else if (planes) hipLaunchKernelGGL((wino43_in_k<true, false>), dim3(grid_for(T * C4)), dim3(256), 0, s, d->x, d->V, d->H, d->W, C4, th, tw, T, T * C4, d->x_amax, 0);
+    else hipLaunchKernelGGL((wino43_in_k<false, false>), dim3(grid_for(T * C4)), dim3(256), 0, s, d->x, d->V, d->H, d->W, C4, th, tw, T, T * C4, d->x_amax, 0);
   } else {
     if (planes) hipLaunchKernelGGL(wino_in_k<true>, dim3(grid_for(T * C4)), dim3(256), 0, s, d->x, d->V, d->H, d->W, C4, th, tw, T, T * C4, d->x_amax);
     else hipLaunchKernelGGL(wino_in_k<false>, dim3(grid_for(T * C4)), dim3(256), 0, s, d->x, d->V, d->H, d->W, C4, th, tw, T, T * C4, d->x_amax);

@@ -310,13 +310,14 @@ class Plan:
         self._sk_ws = {}
         self.down_on_side_stream = os.environ.get('YOLACT_AMD_DOWN_STREAM', 'B') == 'B'      # measured +1 %
         self.wino_alt, self._wino_packed, self._wino_ws = {}, {}, {}
+        self._upsrc, self.wino_up = {}, {}     # 2x bilinear upsampling feeding a 3x3 conv: fused into its F(4x4) input transform
         self._done_event = None
         self._priors_timed = False
         self.param_stamp = None
         self.tune_misses = 0
         self._build()
         self._bind_wino_workspaces()
-        self.sections = [None if op[0] in ('record', 'wait', 'detect') else self.section_of(op[2]) for op in self.ops]
+        self.sections = [None if op[0] in ('record', 'wait', 'detect', 'nop') else self.section_of(op[2]) for op in self.ops]
 
     # ---- op emitters ---------------------------------------------------------------------------
     def _arena(self):
@@ -408,6 +409,8 @@ class Plan:
             self.conv_meta.append((name, d))
             if wino is not None:
                 self.wino_alt[len(self.ops) - 1] = wino      # op index -> alternative; autotune picks the faster one
+                if id(x) in self._upsrc:
+                    self.wino_up[len(self.ops) - 1] = self._upsrc[id(x)]
         return y
 
     def _wino_op(self, x: T, pk: Packed, act, y: Optional[T], name, segs=None, m=2):
@@ -676,6 +679,9 @@ class Plan:
                 y = self._new(t.B, t.H * s, t.W * s, t.C, slot=t.slot)   # convex interpolation: the input's bound holds
                 self.call(lib.ymi_bilinear_nhwc_f32, t.ptr, y.ptr, t.B, t.H, t.W, t.C, y.H, y.W,
                           C.c_float(1.0 / s), C.c_float(1.0 / s), 1 if has_relu else 0, name='proto.interp')
+                if s == 2 and os.environ.get('YOLACT_AMD_FUSED_UPSAMPLE', '1') == '1':
+                    # (the tuner drops this launch when the consuming conv runs as F(4x4,3x3): csrc/winograd.hip UPS)
+                    self._upsrc[id(y)] = (len(self.ops) - 1, t.ptr, 1 if has_relu else 0)
                 self.free(t)
                 t = y
         assert self.proto_patch is not None
@@ -856,6 +862,8 @@ class Plan:
                     rc = lib.ymi_nchw_to_nhwc4_amax_f32(x.data_ptr(), a[1], a[2], a[3], a[4], a[5], self.in_amax[2], s)
                 else:
                     rc = lib.ymi_nchw_to_nhwc4_f32(x.data_ptr(), a[1], a[2], a[3], a[4], a[5], s)
+            elif fn == 'nop':
+                continue
             elif fn == 'stem':
                 args.x = x.data_ptr()
                 rc = lib.ymi_stem_pool_f32(C.byref(args), s)
@@ -1093,6 +1101,12 @@ class Plan:
                 wd = [a for a in alts if a.m == best_m][0]
                 wd.tile, wd.v_planes = int(best_t) & 255, 1 if int(best_t) & L.WINO_PLANES else 0
                 self.ops[idx] = (lib.ymi_conv3x3_winograd_f32, C.pointer(wd), name + '[wino]', where)
+                up = self.wino_up.get(idx)
+                if up is not None and best_m == 4 and wd.H % 2 == 0 and wd.W % 2 == 0:
+                    bidx, lo_ptr, relu = up        # the upsampled tensor is never materialised: the input transform interpolates
+                    wd.x_up, wd.up_relu = lo_ptr, relu
+                    bfn, bargs, bname, bwhere = self.ops[bidx]
+                    self.ops[bidx] = ('nop', None, bname + '[fused into ' + name + ']', bwhere)
 
     def conv_flops(self):
         return sum(self.lib.ymi_conv_flops(C.byref(d)) for _, d in self.conv_meta)
