@@ -1,4 +1,4 @@
-"""The bench.py output contract, checked on the committed result of the last GPU session (profiles/r03_bench_v2.json): the
+"""The bench.py output contract, checked on the committed result of the last GPU session (profiles/r03_bench_v3.json): the
 keys the driver and the judge read, their types, and the internal consistency of the roofline block."""
 import json
 import os
@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _load():
-    with open(os.path.join(ROOT, 'profiles', 'r03_bench_v2.json')) as f:
+    with open(os.path.join(ROOT, 'profiles', 'r03_bench_v3.json')) as f:
         return json.loads(f.read())
 
 
