@@ -5,7 +5,7 @@
 # Results go to gpurun_out/<name>/ (merged back by gpurun).  Stages (run in the order given):
 #   build        make -C yolact_amd/csrc (the .so normally travels with the snapshot; this is for probes built on the box)
 #   tune         re-measure the shipped tile table (all plans);   tune1 = configs[1] + batch 1/2 only
-#   pytest       full `-m gpu` suite;   pytest:<expr> = `-k <expr>`;   pytestf:<file> = one test file
+#   pytest       full `-m gpu` suite;   pytest:<expr> = `-k <expr>` (+ for spaces: pytest:stem+or+detect);   pytestf:<file> = one test file
 #   smoke        __graft_entry__.smoke()
 #   bench        driver-style bench line + per-layer table;   bench:<extra args> (use _ for spaces)
 #   configs      the other BASELINE configs (R101 B16, im700 B8, R50++ B8, Darknet53 B8), batch 1, exact-fp32-only
@@ -22,7 +22,8 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 BENCH="python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary"
 for st in "$@"; do
   arg="${st#*:}"; [ "$arg" = "$st" ] && arg=""
-  case "${st%%:*}" in pytestf|py) arg="${arg//+/ }" ;; *) arg="${arg//_/ }" ;; esac      # (_ stands for a space; + where names contain _)
+  case "${st%%:*}" in pytest|pytestf|py) arg="${arg//+/ }" ;; *) arg="${arg//_/ }" ;; esac      # (+ stands for a space in pytest / pytestf / py
+                                                                                                  #  arguments, whose names contain _; _ elsewhere)
   case "${st%%:*}" in
     build) make -C yolact_amd/csrc -j16 > $O/build.log 2>&1; tail -2 $O/build.log ;;
     tune) timeout 1500 python tools/make_tune_table.py --fresh > $O/tune.log 2>&1      # default arithmetic (fp16x2), every plan
