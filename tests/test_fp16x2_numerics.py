@@ -105,3 +105,23 @@ def test_h2_scale_helper(tmp_path):
                 assert a * s < 2.0 ** 14         # clamped scale: never above the window
         else:
             assert s == 1.0, (a, s)
+
+
+def test_split_is_invariant_under_the_power_of_two_scale():
+    """Why the per-tile scales of csrc/stem.hip / csrc/bottleneck.hip reproduce the per-tensor scale of the conv engine bit for
+    bit: a power of two only shifts exponents, so h and l keep the same mantissa bits as long as neither leaves the normal fp16
+    range — the pieces of two scales differ by exactly that power of two, the represented value not at all."""
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(200000).astype(np.float32)
+    x = x[np.abs(x) > 2.0 ** -6]                                  # 6 binades of dynamic range below ~4
+    h1, l1 = _split(x, np.float32(2.0 ** 11))                     # |x| s in [2^5, 2^13]: both pieces normal
+    h2, l2 = _split(x, np.float32(2.0 ** 8))                      # a tile whose maximum is 8x larger
+    assert np.array_equal(h1.astype(np.float32), h2.astype(np.float32) * np.float32(8))
+    assert np.array_equal(l1.astype(np.float32), l2.astype(np.float32) * np.float32(8))
+    # ... and where the low piece does go subnormal the coarser scale loses bits (the hot-patch case of the stem test)
+    small = (rng.standard_normal(20000) * 2.0 ** -16).astype(np.float32)
+    ha, la = _split(small, np.float32(2.0 ** 11))
+    hb, lb = _split(small, np.float32(2.0 ** 4))
+    ra = (ha.astype(np.float64) + la.astype(np.float64)) / 2.0 ** 11
+    rb = (hb.astype(np.float64) + lb.astype(np.float64)) / 2.0 ** 4
+    assert np.abs(ra - small).max() <= np.abs(rb - small).max() and np.abs(rb - small).max() > 0
