@@ -144,3 +144,34 @@ def test_single_stream_plan_has_no_markers():
     from yolact_amd.engine import Plan
     plan = Plan(_make_net('yolact_resnet50_config'), 1, 550, 550, torch.device('cpu'))
     assert all(op[0] not in ('record', 'wait') and op[3] == 'A' for op in plan.ops)
+
+
+def test_fused_stem_and_upsample_hooks_in_the_plan(monkeypatch):
+    """fp16x2 ResNet plans start with ONE 'stem' op (image -> stem -> max-pool, csrc/stem.hip) instead of the layout change, the
+    7x7 conv and the max-pool, with unchanged FLOP accounting; the protonet's 2x upsampling is registered for fusion into the
+    consuming conv's Winograd input transform; Darknet plans and YOLACT_AMD_FUSED_STEM=0 keep the separate launches."""
+    from yolact_amd.engine import Plan
+    dev = torch.device('cpu')
+    plan = Plan(_make_net('yolact_resnet50_config'), 2, 550, 550, dev)
+    names = [op[2] for op in plan.ops]
+    assert plan.fused_stem and plan.ops[0][0] == 'stem' and 'maxpool' not in names
+    assert all(op[0] != 'input' for op in plan.ops)
+    sd = plan.ops[0][1]
+    assert (sd.B, sd.H, sd.W, sd.kpad) == (2, 550, 550, 224)
+    assert plan.conv_meta[0][0] == 'stem'
+    flops_fused = plan.conv_flops()
+    # the upsampling in front of proto.8: one registered (bilinear op, low-res tensor, relu) for the conv that consumes it
+    assert len(plan._upsrc) == 1
+    (bidx, lo_ptr, relu), = plan._upsrc.values()
+    assert plan.ops[bidx][2] == 'proto.interp' and lo_ptr and relu == 1
+    if plan.wino_alt:                                  # (Winograd alternatives are only built on a GPU)
+        (cidx, up), = plan.wino_up.items()
+        assert up == (bidx, lo_ptr, relu) and plan.ops[cidx][2].startswith('proto.')
+    monkeypatch.setenv('YOLACT_AMD_FUSED_STEM', '0')
+    plain = Plan(_make_net('yolact_resnet50_config'), 2, 550, 550, dev)
+    pn = [op[2] for op in plain.ops]
+    assert not plain.fused_stem and plain.ops[0][0] == 'input' and 'maxpool' in pn and pn[1] == 'stem'
+    assert plain.conv_flops() == flops_fused
+    monkeypatch.delenv('YOLACT_AMD_FUSED_STEM')
+    dk = Plan(_make_net('yolact_darknet53_config'), 1, 550, 550, dev)
+    assert not dk.fused_stem and dk.ops[0][0] == 'input'
