@@ -62,7 +62,8 @@ def kernel_peak(name):
     bounded by the fp32 MFMA peak, the `...x3` tiles (fp32-class products as 6 bf16 MFMAs) by bf16 peak / 6, the `...h2`
     tiles (3 fp16 MFMAs) by fp16 peak / 3."""
     tile = name.split('<', 1)[1].split(',', 1)[0] if '<' in name else ''
-    return X3_PEAK_TFLOPS if tile.endswith('x3') else H2_PEAK_TFLOPS if tile.endswith('h2') else FP32_MFMA_PEAK_TFLOPS
+    return X3_PEAK_TFLOPS if tile.endswith('x3') else H2_PEAK_TFLOPS if (tile.endswith('h2') or tile.startswith('dcnp')) \
+        else FP32_MFMA_PEAK_TFLOPS
 
 
 def conv_alg_bytes(d):
@@ -125,6 +126,7 @@ def roofline(net, x, reps=3):
     # record kinds: 0/1/2 = one direct conv launch (loader id), 7 = a direct 1x1 launch on the pointwise loader (kernel
     # template LOADER 3); 3 / 4 = a whole Winograd F(2x2) / F(4x4) layer (input transform + 16- / 36-group GEMM + output
     # transform, ALGORITHMIC conv FLOPs); 5 / 6 = the Winograd GEMM launch alone (the FLOPs it executes).
+    # 9 = the pipelined DCNv2 gather-GEMM (csrc/dcn.hip).
     # 8 = the fused ResNet stem launch (layout change + 7x7 conv + BN + ReLU + max-pool; the conv's algorithmic FLOPs).
     # Layer table / all_conv: kinds 0-4, 7 and 8.  Single-kernel roofline: kinds 0-2, 7, 8, 5 and 6.
     by_kernel, layers = {}, {}
@@ -148,8 +150,12 @@ def roofline(net, x, reps=3):
             nbytes = 4.0 * (d8.B * d8.H * d8.W * 3 + 64 * 147 + d8.B * ((d8.Ho - 1) // 2 + 1) * ((d8.Wo - 1) // 2 + 1) * 64)
         else:
             nbytes = conv_alg_bytes(descs[(li + 1) % nl])
+            if kind.value in (2, 9):                 # DCNv2: + the 27-channel offset / mask-logit tensor the gather reads
+                dd_ = descs[(li + 1) % nl]
+                nbytes += 4.0 * dd_.B * dd_.Ho * dd_.Wo * 27
         if kind.value not in (3, 4):
-            pk_ = (X3_PEAK_TFLOPS if tname.endswith('x3') else H2_PEAK_TFLOPS if tname.endswith('h2') else FP32_MFMA_PEAK_TFLOPS)
+            pk_ = (X3_PEAK_TFLOPS if tname.endswith('x3') else H2_PEAK_TFLOPS if (tname.endswith('h2') or tname.startswith('dcnp'))
+                   else FP32_MFMA_PEAK_TFLOPS)
             t_m, t_h = fl.value / (pk_ * 1e12) * 1e3, nbytes / (HBM_PEAK_GBPS * 1e9) * 1e3
             bound_ms['mfma' if t_m >= t_h else 'hbm'] += max(t_m, t_h) / reps
             if kind.value in (5, 6):                 # + the two transform launches of that layer: pure HBM streams
@@ -158,6 +164,7 @@ def roofline(net, x, reps=3):
             li += 1
             lkey = ('winograd F(%dx%d,3x3) <gemm %s> (3 launches)' % (2 * kind.value - 4, 2 * kind.value - 4, tname)) \
                 if kind.value in (3, 4) else 'stem_pool_k<%s,conv 7x7/2 + BN + ReLU + max-pool 3x3/2 fused>' % tname if kind.value == 8 \
+                else 'dcn_h2_k<%s,pipelined gather>' % tname if kind.value == 9 \
                 else 'conv_igemm_f32<%s,loader%d>' % (tname, 3 if kind.value == 7 else kind.value)
             la = layers.setdefault(names[li % nl], [0.0, fl.value, lkey])
             la[0] += ms.value / reps
@@ -166,6 +173,7 @@ def roofline(net, x, reps=3):
         if kind.value not in (3, 4):
             key = ('conv_igemm_f32<%s,winograd grouped GEMM>' % tname) if kind.value in (5, 6) else \
                 ('stem_pool_k<%s,fused stem>' % tname) if kind.value == 8 else \
+                ('dcn_h2_k<%s,pipelined gather>' % tname) if kind.value == 9 else \
                 'conv_igemm_f32<%s,loader%d>' % (tname, 3 if kind.value == 7 else kind.value)
             a = by_kernel.setdefault(key, [0.0, 0.0, 0, 0.0, 0.0, 0.0])
             a[0] += ms.value; a[1] += fl.value; a[2] += 1; a[3] += nbytes

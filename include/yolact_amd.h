@@ -124,7 +124,15 @@ enum { YMI_TILE_AUTO = 0, YMI_TILE_128x128 = 1, YMI_TILE_128x64 = 2, YMI_TILE_64
         * 3 of the 4 piece products (h*l, l*h, h*h) on v_mfma_f32_32x32x16_f16 with fp32 accumulation; the dropped l*l term is
         * <= 2^-22 |a b|, unbiased.  Half the matrix-pipe work of X3 and no byte permutes in the split.  Needs w_h2, scale_h2,
         * x_amax.  Same base tiles as X3. */
-       YMI_TILE_H2 = 64 };
+       YMI_TILE_H2 = 64,
+       /* YMI_TILE_H2 | YMI_TILE_DCNP | YMI_DCNP_* (ymi_dcn_v2_forward_f32 only): the software-pipelined gather-GEMM of
+        * csrc/dcn.hip — corner loads three K chunks ahead in a register ring, every sample formed once per row block and stored
+        * to LDS as the two fp16 planes, no operand split in the MFMA loop.  The low five bits select ITS block tile (enum
+        * below), not a YMI_TILE_* of the conv engine.  One dense output, activation none / ReLU / LeakyReLU, no residual. */
+       YMI_TILE_DCNP = 128 };
+/* block tiles of the pipelined DCN kernel (BM x BN, _W8 = 512-thread blocks) */
+enum { YMI_DCNP_64x128 = 1, YMI_DCNP_64x128_W8 = 2, YMI_DCNP_64x64 = 3, YMI_DCNP_128x128_W8 = 4, YMI_DCNP_128x64_W8 = 5,
+       YMI_DCNP_32x128 = 6 };
 
 int ymi_abi_version(void);
 const char *ymi_strerror(int code);
@@ -361,6 +369,9 @@ typedef struct {
   ymi_conv_desc conv;    /* main 3x3 conv: x, packed w, bias, epilogue, outputs (kh=kw=3, pad=1) */
   const float *offmask;  /* [B,Ho,Wo,ldo] NHWC output of conv_offset_mask: ch 2k=dh_k, 2k+1=dw_k, 18+k=mask logit */
   int32_t ldo;           /* channel stride of offmask pixels (>= 27) */
+  int32_t mask_is_prob;  /* 0: channels 18.. are mask LOGITS, the kernel applies the sigmoid (DCN.forward, dcn_v2.py:118-128 — the
+                          * engine's plans); 1: they are the modulation itself, already in [0,1] (dcn_v2_conv / DCNv2.forward,
+                          * dcn_v2.py:16-33,85-96, whose callers pass torch.sigmoid(mask)).  Occupies what was tail padding. */
 } ymi_dcn_desc;
 int ymi_dcn_v2_forward_f32(const ymi_dcn_desc *d, void *stream);
 

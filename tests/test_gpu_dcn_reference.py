@@ -81,6 +81,14 @@ def test_dcn_hip_and_oracle_match_reference_kernel(shape, stride):
     # (3) the same launch on the fp16x2 tiles (what the default plan runs for the DCN layers)
     hip2 = run_conv(x, w, b, None, stride, 1, dcn_offmask=om, tile=L.TILE_64x64 | L.TILE_H2)
     e_h2 = (hip2.double() - ref).abs().max().item()
+    # (4) the pipelined gather-GEMM of csrc/dcn.hip (round 4: what the default plan runs for the DCN layers), every block tile
+    e_p = {}
+    if Co % 4 == 0:
+        for t in sorted(L.DCNP_TILES):
+            hp = run_conv(x, w, b, None, stride, 1, dcn_offmask=om, tile=t | L.TILE_H2 | L.TILE_DCNP)
+            e_p[L.DCNP_TILES[t]] = (hp.double() - ref).abs().max().item()
+        print('    pipelined: ' + '  '.join('%s %.2e' % kv for kv in e_p.items()))
+        assert max(e_p.values()) <= 1e-4 * max(1.0, scale), e_p
     print('DCN %s stride %d: %.1f%% zero columns, |ref|max %.3f, oracle err %.2e, HIP err %.2e (exact-fp32 tile) %.2e (fp16x2 tile)' % (
         shape[:5], stride, 100 * outside, scale, e_or, e_hip, e_h2))
     assert e_or <= 2e-5 * max(1.0, scale), e_or

@@ -220,6 +220,90 @@ def test_dcn_matches_oracle(stride, tile):
     assert rel_err(y, ref) < 2e-5
 
 
+DCNP_ALL = [t | L.TILE_H2 | L.TILE_DCNP for t in sorted(L.DCNP_TILES)]
+
+
+@pytest.mark.parametrize('tile', DCNP_ALL)
+@pytest.mark.parametrize('case', [(2, 32, 9, 8, 48, 1), (2, 32, 9, 8, 48, 2), (1, 64, 23, 19, 132, 1), (3, 128, 13, 11, 128, 2),
+                                  (1, 96, 37, 41, 256, 1)])
+def test_dcn_pipelined_matches_oracle(case, tile):
+    """csrc/dcn.hip (the software-pipelined gather-GEMM: corner loads three chunks ahead in a register ring, samples stored to LDS as
+    fp16x2 planes) against the CPU oracle: odd chunk counts (Cin = 32, 96), ragged row / column tiles, stride 2, batch > 1."""
+    from gpu_utils import run_conv, rel_err
+    from oracle.yolact_oracle import dcn_v2_forward
+    B, Cc, H, W, Co, stride = case
+    x, w, b, om = _dcn_inputs(41 + Cc + stride, B, Cc, H, W, Co, stride)
+    om[:, :18] *= 2.0                       # |offsets| of several pixels: sample points leave the image
+    y = run_conv(x, w, b, None, stride, 1, dcn_offmask=om, tile=tile, act=L.ACT_RELU)
+    ref = torch.relu(dcn_v2_forward(x, om[:, :18], torch.sigmoid(om[:, 18:]), w, b, stride, 1, 1))
+    assert rel_err(y, ref) < 2e-5
+    assert abs(run_conv.last_amax[1] - ref.abs().max().item()) <= 2e-5 * ref.abs().max().item()     # the bound it reports for y
+
+
+def test_dcn_pipelined_rejects_what_it_cannot_run():
+    """An explicit YMI_TILE_DCNP request outside the kernel's envelope is an error code, never a silent other kernel."""
+    from gpu_utils import run_conv
+    x, w, b, om = _dcn_inputs(5, Co=50)                                  # Cout % 4 != 0
+    with pytest.raises(RuntimeError):
+        run_conv(x, w, b, None, 1, 1, dcn_offmask=om, tile=L.TILE_H2 | L.TILE_DCNP | L.DCNP_64x128)
+    x, w, b, om = _dcn_inputs(5)
+    with pytest.raises(RuntimeError):                                     # no fp16x2 flag
+        run_conv(x, w, b, None, 1, 1, dcn_offmask=om, tile=L.TILE_DCNP | L.DCNP_64x128)
+    with pytest.raises(RuntimeError):                                     # unknown block tile
+        run_conv(x, w, b, None, 1, 1, dcn_offmask=om, tile=L.TILE_H2 | L.TILE_DCNP | 9)
+
+
+def test_dcn_v2_module_reference_kat_through_the_shim():
+    """The reference's own known-answer test (external/DCNv2/test.py:32-67 check_zero_offset), restated line by line against the
+    module the reference imports (`from dcn_v2 import dcn_v2_conv, DCNv2, DCN` resolves to shim/dcn_v2.py): zero offset conv,
+    mask = sigmoid(0), identity centre-tap weights => 2 * dcn_v2(input, offset, mask) == input.  Then DCN.forward(input) and
+    dcn_v2_conv with random offsets against the CPU oracle."""
+    import importlib
+    import os
+    import sys
+    import torch.nn as nn
+    from oracle.yolact_oracle import dcn_v2_forward
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'shim'))
+    try:
+        dcn_v2 = importlib.import_module('dcn_v2')
+    finally:
+        sys.path.pop(0)
+    assert dcn_v2.__file__.replace(os.sep, '/').endswith('shim/dcn_v2.py')
+    N, inC, inH, inW, outC, kH, kW, dg = 2, 2, 4, 4, 2, 3, 3, 1             # test.py:14-18
+    dev = 'cuda:0'
+    conv_offset = nn.Conv2d(inC, dg * 2 * kH * kW, (kH, kW), (1, 1), (1, 1), bias=True).to(dev)
+    conv_mask = nn.Conv2d(inC, dg * kH * kW, (kH, kW), (1, 1), (1, 1), bias=True).to(dev)
+    m = dcn_v2.DCNv2(inC, outC, (kH, kW), stride=1, padding=1, dilation=1, deformable_groups=dg).to(dev)
+    for c in (conv_offset, conv_mask):
+        c.weight.data.zero_(); c.bias.data.zero_()
+    m.weight.data.zero_(); m.bias.data.zero_()
+    for q in range(outC):                                                     # conv_identify, test.py:21-30
+        m.weight.data[q, q, kH // 2, kW // 2] = 1.0
+    inp = torch.randn(N, inC, inH, inW, generator=_g(77)).to(dev)
+    with torch.no_grad():
+        offset, mask = conv_offset(inp), torch.sigmoid(conv_mask(inp))
+    out = m(inp, offset, mask) * 2
+    assert (inp - out).abs().max().item() < 1e-6                              # (the reference asserts 1e-10 on exact 0.5 products)
+    # DCN.forward: conv_offset_mask + sigmoid + gather-GEMM, non-trivial offsets, both kernel families (Cout % 4 == 0 -> pipelined)
+    for Cin, Cout, stride in ((48, 64, 1), (32, 18, 2)):
+        g = _g(100 + Cin)
+        d = dcn_v2.DCN(Cin, Cout, 3, stride=stride, padding=1).to(dev)
+        with torch.no_grad():
+            d.conv_offset_mask.weight.copy_(torch.randn(27, Cin, 3, 3, generator=g) * 0.05)
+            d.conv_offset_mask.bias.copy_(torch.randn(27, generator=g) * 0.5)
+            d.bias.copy_(torch.randn(Cout, generator=g) * 0.1)
+        x = torch.randn(2, Cin, 17, 13, generator=g)
+        y = d(x.to(dev)).cpu()
+        om = F.conv2d(x, d.conv_offset_mask.weight.cpu(), d.conv_offset_mask.bias.cpu(), stride, 1)
+        ref = dcn_v2_forward(x, om[:, :18], torch.sigmoid(om[:, 18:]), d.weight.detach().cpu(), d.bias.detach().cpu(), stride, 1, 1)
+        assert y.shape == ref.shape and (y - ref).abs().max().item() < 5e-5 * max(1.0, ref.abs().max().item())
+        y2 = dcn_v2.dcn_v2_conv(x.to(dev), om[:, :18].contiguous().to(dev), torch.sigmoid(om[:, 18:]).to(dev), d.weight, d.bias,
+                                stride, 1, 1, 1).cpu()
+        assert (y2 - ref).abs().max().item() < 5e-5 * max(1.0, ref.abs().max().item())
+    with pytest.raises(NotImplementedError):
+        dcn_v2.DCN(8, 8, 5, stride=1, padding=2)
+
+
 def test_dcn_known_answers():
     """external/DCNv2/test.py:32-67: zero offsets, mask logit 0 (sigmoid = 0.5), identity 3x3 centre weights
     => 2*DCN(x) == x; and offset 0 with mask -> 1 reduces DCN to F.conv2d."""

@@ -1,0 +1,95 @@
+#!/usr/bin/env python
+"""Every DCNv2 launch of the YOLACT++ plan (BASELINE configs[3]: yolact_plus_resnet50_config, 550x550), every candidate tile:
+the register-staged loader of csrc/conv_igemm.hip (exact-fp32 and fp16x2 tiles) against the pipelined gather-GEMM of
+csrc/dcn.hip, on the plan's own tensors (offsets / mask logits as the network produces them from the synthetic weights).
+
+    python tools/dcn_probe.py [--batch 8] [--reps 5]
+
+Per layer: ms and TFLOP/s per tile, the maximum deviation of every pipelined tile from the old fp16x2 launch (both fp32-class:
+they differ by rounding only), then the sum over the 13 layers of the best old tile and of the best pipelined tile.
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=8)
+    ap.add_argument('--reps', type=int, default=5)
+    ap.add_argument('--config', default='yolact_plus_resnet50_config')
+    args = ap.parse_args()
+    os.environ.setdefault('YOLACT_AMD_AUTOTUNE', 'table')
+    import yolact_amd
+    from yolact_amd import _lib as L
+    from yolact_amd.utils.synth import synth_images, synth_state_dict
+    yolact_amd.set_cfg(args.config)
+    from yolact_amd.yolact import Yolact
+    dev = torch.device('cuda', 0)
+    net = Yolact()
+    net.load_state_dict_compat(synth_state_dict([(k, tuple(v.shape)) for k, v in net.state_dict().items()], seed=0, conf_gain=0.04))
+    net.detect.use_fast_nms = True
+    net = net.to(dev)
+    size = int(yolact_amd.CONFIGS[args.config].max_size)
+    x = synth_images(args.batch, size, size, seed=1234).to(dev)
+    with torch.no_grad():
+        plan = net.plan_for(x)
+        plan.run(x)
+    torch.cuda.synchronize()
+    lib = L.lib()
+    s = L.stream_ptr()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    old = [t for t in L.BASIC_TILES if t != L.TILE_128x32]
+    old = old + [t | L.TILE_H2 for t in old]
+    new = [t | L.TILE_H2 | L.TILE_DCNP for t in sorted(L.DCNP_TILES)]
+    tot_old = tot_new = tot_fl = 0.0
+    for fn, dptr, name, where in plan.ops:
+        if fn is not lib.ymi_dcn_v2_forward_f32:
+            continue
+        dd = dptr.contents
+        d = dd.conv
+        fl = lib.ymi_conv_flops(C.byref(d))
+        tile0 = d.tile
+        M = d.B * d.Ho * d.Wo
+        y = torch.empty(M * d.Cout, device=dev)
+        yptr0 = d.seg[0].ptr
+        d.seg[0].ptr = y.data_ptr()
+        times, ref, dev_max = {}, None, {}
+        for t in old + new:
+            d.tile = t
+            if fn(dptr, s) != 0:
+                continue
+            torch.cuda.synchronize()
+            if t == (L.TILE_64x64 | L.TILE_H2):
+                ref = y.clone()
+            elif t & L.TILE_DCNP and ref is not None:
+                dev_max[t] = ((y - ref).abs().max() / ref.abs().max()).item()
+            best = 1e30
+            for _ in range(2):
+                e0.record()
+                for _ in range(args.reps):
+                    fn(dptr, s)
+                e1.record()
+                e1.synchronize()
+                best = min(best, e0.elapsed_time(e1) / args.reps)
+            times[t] = best
+        d.tile, d.seg[0].ptr = tile0, yptr0
+        bo = min((times[t], t) for t in old if t in times)
+        bn = min((times[t], t) for t in new if t in times) if any(t in times for t in new) else (float('nan'), 0)
+        tot_old += bo[0]; tot_new += bn[0]; tot_fl += fl
+        print('%-16s B%d %dx%d s%d %d>%d  %.2f GFLOP  | old best %-10s %.4f ms %6.1f TF/s | pipelined best %-14s %.4f ms %6.1f TF/s' % (
+            name, d.B, d.H, d.W, d.stride, d.Cin, d.Cout, fl / 1e9, L.TILE_NAMES[bo[1]], bo[0], fl / bo[0] / 1e9,
+            L.TILE_NAMES.get(bn[1], '-'), bn[0], fl / bn[0] / 1e9))
+        print('    ' + '  '.join('%s %.4f' % (L.TILE_NAMES[t], times[t]) for t in old + new if t in times))
+        print('    max |pipelined - old fp16x2| / max|y|: ' + '  '.join('%s %.1e' % (L.TILE_NAMES[t], v) for t, v in dev_max.items()))
+    print('TOTAL %d DCN layers: old %.3f ms (%.1f TF/s), pipelined %.3f ms (%.1f TF/s)' % (
+        sum(1 for op in plan.ops if op[0] is lib.ymi_dcn_v2_forward_f32), tot_old, tot_fl / tot_old / 1e9, tot_new, tot_fl / tot_new / 1e9))
+
+
+if __name__ == '__main__':
+    main()

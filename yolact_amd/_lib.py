@@ -33,6 +33,11 @@ H2_BASE_TILES = X3_BASE_TILES + (18, 13, 14, 15)   # + 128x256w8: one column blo
                                                   # + the deeper-pipelined K-split tiles (batch 1: ~23 % of the kernel time sat in 32x32k4)
 for _t in H2_BASE_TILES:
     TILE_NAMES[_t | TILE_H2] = TILE_NAMES[_t] + 'h2'
+TILE_DCNP = 128                     # TILE_H2 | TILE_DCNP | DCNP_*: the pipelined DCNv2 gather-GEMM (csrc/dcn.hip); the low bits are ITS tile enum
+DCNP_64x128, DCNP_64x128_W8, DCNP_64x64, DCNP_128x128_W8, DCNP_128x64_W8, DCNP_32x128 = 1, 2, 3, 4, 5, 6
+DCNP_TILES = {1: 'dcnp64x128', 2: 'dcnp64x128w8', 3: 'dcnp64x64', 4: 'dcnp128x128w8', 5: 'dcnp128x64w8', 6: 'dcnp32x128'}
+for _t, _n in DCNP_TILES.items():
+    TILE_NAMES[_t | TILE_H2 | TILE_DCNP] = _n
 WINO_PLANES = 1024                  # tune-table flag on a Winograd GEMM tile id: V written as fp16x2 planes (ymi_wino_desc.v_planes)
 KSPLIT_TILES = (6, 7, 8, 13, 14, 15, 6 | 32, 7 | 32, 8 | 32, 6 | 64, 7 | 64, 8 | 64, 13 | 64, 14 | 64, 15 | 64)   # different (still deterministic) fp32 summation order than the unsplit tiles
 
@@ -68,7 +73,7 @@ class WinoDesc(C.Structure):
 
 
 class DcnDesc(C.Structure):
-    _fields_ = [('conv', ConvDesc), ('offmask', C.c_void_p), ('ldo', C.c_int32)]
+    _fields_ = [('conv', ConvDesc), ('offmask', C.c_void_p), ('ldo', C.c_int32), ('mask_is_prob', C.c_int32)]
 
 
 class DetectDesc(C.Structure):

@@ -103,7 +103,7 @@ struct KParams {
   int M, HoWo, tiles_n, nk;
   unsigned x_bytes, w_bytes;      // buffer-resource sizes
   const float *offmask;           // DCN only
-  int ldo;
+  int ldo, mask_is_prob;
   long x_gs, w_gs, y_gs;          // grouped GEMM (gridDim.y groups, Winograd): element strides of x / w / seg[0].ptr per group
   const void *w3;                 // PREC == 2: filters pre-split into three bf16 planes [groups][3][CoutPad][Kpad]
   unsigned w3_plane;              // PREC == 2: bytes between planes (CoutPad * Kpad * 2)
@@ -501,7 +501,7 @@ void conv_igemm_f32(const KParams p) {
               const int m = a_base[i];
               const float *om = p.offmask + (size_t)m * p.ldo;
               const float dh = om[2 * tap], dw = om[2 * tap + 1];
-              mk = 1.f / (1.f + expf(-om[18 + tap]));
+              mk = p.mask_is_prob ? om[18 + tap] : 1.f / (1.f + expf(-om[18 + tap]));
               const float h = (float)(a_iy0[i] + nx_ky[j]) + dh, w = (float)(a_ix0[i] + nx_kx[j]) + dw;
               if (h > -1.f && w > -1.f && h < (float)d.H && w < (float)d.W) {
                 const int hl = (int)floorf(h), wl = (int)floorf(w);
@@ -1268,7 +1268,7 @@ struct H2Group { const void *a2 = nullptr; unsigned a2_plane = 0; long a2_gs = 0
 
 int run_conv(const ymi_conv_desc *d, int loader, const float *offmask, int ldo, hipStream_t s, int groups = 1, long x_gs = 0,
              long w_gs = 0, long y_gs = 0, double prof_flops = -1.0, int prof_kind = -1, int split_k = 1,
-             const H2Group &h2g = H2Group()) {
+             const H2Group &h2g = H2Group(), int mask_is_prob = 0) {
   int rc = validate(d, loader);
   // grouped launches take the fast-path epilogue only (it applies the group's output offset)
   if (rc == YMI_OK && groups > 1 &&
@@ -1290,6 +1290,7 @@ int run_conv(const ymi_conv_desc *d, int loader, const float *offmask, int ldo, 
   }
   kp.offmask = offmask;
   kp.ldo = ldo;
+  kp.mask_is_prob = mask_is_prob;
   kp.x_gs = x_gs; kp.w_gs = w_gs; kp.y_gs = y_gs;
   const bool h2 = (d->tile & YMI_TILE_H2) != 0;
   if (h2 && (d->tile & YMI_TILE_X3)) return YMI_EARG;
@@ -1437,6 +1438,8 @@ int ymi_internal_grouped_gemm(const ymi_conv_desc *d, int groups, long x_gs, lon
   return run_conv(d, 0, nullptr, 0, s, groups, x_gs, w_gs, y_gs, prof_flops, prof_kind, 1, g);
 }
 
+int ymi_internal_dcn_h2(const ymi_dcn_desc *dd, int base_tile, hipStream_t s);   // csrc/dcn.hip (C++ linkage: internal)
+
 extern "C" {
 
 double ymi_conv_flops(const ymi_conv_desc *d) {
@@ -1455,7 +1458,13 @@ int ymi_conv2d_nhwc_f32(const ymi_conv_desc *d, void *stream) {
 int ymi_dcn_v2_forward_f32(const ymi_dcn_desc *d, void *stream) {
   if (!d || !d->offmask) return YMI_ENULL;
   if (d->ldo < 27) return YMI_ESHAPE;
-  return run_conv(&d->conv, 2, d->offmask, d->ldo, (hipStream_t)stream);
+  if (d->conv.tile & YMI_TILE_DCNP) {        // the pipelined gather-GEMM (fp16x2 only); an explicit request it cannot honour fails
+    if (!(d->conv.tile & YMI_TILE_H2) || (d->conv.tile & YMI_TILE_X3)) return YMI_EARG;
+    const int rc = validate(&d->conv, 2);
+    if (rc) return rc;
+    return ymi_internal_dcn_h2(d, d->conv.tile & 31, (hipStream_t)stream);
+  }
+  return run_conv(&d->conv, 2, d->offmask, d->ldo, (hipStream_t)stream, 1, 0, 0, 0, -1.0, -1, 1, H2Group(), d->mask_is_prob);
 }
 
 int ymi_debug_set_trace(void *buf, long cap_blocks) {

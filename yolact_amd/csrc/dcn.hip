@@ -1,0 +1,442 @@
+// DCNv2 forward (external/DCNv2/src/cuda/dcn_v2_cuda.cu:42-172, dcn_v2_im2col_cuda.cu:25-54,125-195) as ONE software-pipelined
+// gather-GEMM on the fp16x2 matrix path of gfx950 — round 4's replacement for the register-staged `LOADER 2` of
+// csrc/conv_igemm.hip on the fp16x2 plans (that loader stays for the exact-fp32 plans and for descriptors this kernel does
+// not take).
+//
+// What was wrong with the old loader (profiles/r03_bench_v3_plus_b8.json: 93 TFLOP/s, 0.11 of the fp16x2 peak, 125 us per layer
+// against 53 us for the plain 3x3 of the same shape): every 32-deep K chunk was ONE serial round trip — issue the four bilinear
+// corner loads of the next chunk, 12 MFMAs (0.16 us), wait for the loads (vmcnt(0): 1 - 1.7 us under load), ds_write, barrier —
+// and the first chunk of every tap added a second dependent round trip (offset / mask logits -> addresses -> data).
+//
+// This kernel keeps the idea (no `columns` tensor: the modulated bilinear sample is formed in registers and goes straight into
+// the A tile) and rebuilds the schedule around the latency:
+//   * the corner loads of chunk c+3 are issued while chunk c is multiplied: a two-slot register ring, i.e. two to three K
+//     steps of latency cover; a sample is `buffer_load_dwordx4` x 4 corners, 8 lanes = 128 contiguous bytes (32 channels) per
+//     corner, the only per-chunk address work is ONE scalar offset (the channel chunk) — corner offsets live in registers per tap;
+//   * the offset / mask logits of tap t+1 are fetched when tap t starts, so a tap change costs arithmetic, not a round trip;
+//   * every (pixel, tap, channel) sample is formed ONCE per row block and written to LDS already split into the two fp16 planes
+//     of the fp16x2 arithmetic (scaled by the tensor's power-of-two scale: |sample| <= max|x| because the bilinear weights are
+//     convex and the modulation is a sigmoid) — the consuming waves run the MFMA loop with NO operand split, like the
+//     pre-split Winograd GEMM (PREC 4 of conv_igemm.hip);
+//   * filters arrive as fp16 planes by LDS-DMA three chunks ahead (four B stages), the A planes are double-buffered; vmcnt is
+//     in-order, so the filter DMA has to run as far ahead as the gather or waiting for it would drain the gather too;
+//   * counted `s_waitcnt vmcnt(N)` + one raw `s_barrier` per chunk; the loop body is ONE straight-line step (requests past the
+//     end of K are out-of-bounds buffer loads, i.e. zeros without a memory access) so its vmcnt is a constant.
+// K order, LDS images, fragment layout, MFMA order (h*l, l*h, h*h) and the fast-path epilogue are those of the fp16x2 tiles of
+// conv_igemm.hip, so the filter planes / scale_h2 of engine.Packed.h2() are used unchanged.
+#include "common.h"
+#include <type_traits>
+#include "../../include/yolact_amd.h"
+
+int ymi_internal_prof_begin(double flops, int tile, int kind, hipStream_t s);
+void ymi_internal_prof_end(int idx, hipStream_t s);
+
+namespace {
+
+constexpr int BK = 32;
+constexpr unsigned OOB = 0x80000000u;   // buffer offset >= num_records: the load returns zeros
+
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+struct Split2 { f16x8 h, l; };
+
+struct DcnParams {
+  const float *x, *offmask, *scale_h2, *bias, *x_amax;
+  const void *w_h2;
+  float *y, *y_amax;
+  int B, H, W, Cin, ldx, Ho, Wo, Cout, stride, Kpad, ldo, ldy, act, mask_is_prob;
+  int M, HoWo, tiles_n, nk;
+  unsigned x_bytes, om_bytes, w_plane;
+};
+
+template <int WM, int WN, int TM, int TN>
+constexpr int dcn_lds_floats() {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int pipe = 2 * (2 * BM * 16) + 4 * (2 * BN * 16), epi = BM * (BN + 4);
+  return pipe > epi ? pipe : epi;
+}
+template <int WM, int WN, int TM, int TN>
+constexpr int dcn_occupancy() {     // blocks per CU: LDS-limited, and capped by the register ring of the gather (32 registers per
+                                    // row a thread gathers): 4-wave blocks and 8-wave blocks with one row per thread run two per CU
+  constexpr int occ = (160 * 1024) / (dcn_lds_floats<WM, WN, TM, TN>() * 4);
+  constexpr int ra = (WM * TM * 32) / (8 * WM * WN), cap = (WM * WN == 8 && ra > 1) ? 1 : 2;
+  return occ > cap ? cap : (occ < 1 ? 1 : occ);
+}
+
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(64 * WM * WN, (dcn_occupancy<WM, WN, TM, TN>() * (WM * WN) / 4))
+void dcn_h2_k(const DcnParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // (host pass: empty body, see conv_igemm.hip)
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NW = WM * WN, NT = 64 * NW;
+  constexpr int RPP = NT / 8, RA = BM / RPP;            // gather: 8 lanes (32 channels) per row, RA rows per thread per chunk
+  constexpr int RB = (2 * BN) / (16 * NW);              // filter-plane DMA pieces (16 rows x 64 bytes) per wave per chunk
+  static_assert(BM % RPP == 0 && RA >= 1 && (2 * BN) % (16 * NW) == 0, "tile rows vs staging passes");
+  constexpr int A_STAGE = 2 * BM * 16, B_STAGE = 2 * BN * 16;    // floats: two fp16 planes of 64-byte rows
+  constexpr int NG = 4 * RA, NB = RB;                   // VMEM operations of one chunk: corner loads, filter DMAs
+  constexpr int N_STEADY = 2 * (NG + NB);               // operations issued behind the filter DMA of chunk st+1 at the end of step st
+  static_assert(N_STEADY <= 63, "vmcnt is a 6-bit counter");
+  constexpr int ELD = BN + 4;
+  constexpr int LDS_FLOATS = dcn_lds_floats<WM, WN, TM, TN>();
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+  float *const Abase = lds, *const Bbase = lds + 2 * A_STAGE;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int kq = t & 7, r0 = t >> 3;
+
+  const int logical = ymi_xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = logical % p.tiles_n, tile_m = logical / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void *)p.offmask, 0, (int)p.om_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.w_h2, 0, (int)(2 * p.w_plane), 0x00020000);
+
+  float sA, invA;
+  ymi_h2_scale(ymi_amax_read(p.x_amax), sA, invA);
+  const ymi_amax_pre apre = ymi_amax_prefetch(p.y_amax);
+
+  // ---- epilogue mapping (conv_igemm.hip's fast path) ------------------------------------------------------------------------
+  constexpr int C4 = BN / 4, RSTEP = NT / C4, RPT = BM / RSTEP;
+  const int c4 = t % C4, rbase = t / C4;
+  const int n = n0 + 4 * c4;
+  // ---- gather bookkeeping: rows r0 + RPP*i of the tile, channels 4*kq .. 4*kq+3 of the chunk ------------------------------
+  int g_iy0[RA], g_ix0[RA], g_ib[RA];
+  unsigned g_om[RA];                                    // byte offset of the row's offset / mask-logit vector (OOB past M)
+  int a_st[RA];                                         // byte offset of this thread's 8-byte piece inside an A plane
+#pragma unroll
+  for (int i = 0; i < RA; ++i) {
+    const int row = r0 + RPP * i, m = m0 + row;
+    a_st[i] = row * 64 + (((kq >> 1) ^ ((row >> 2) & 3)) * 16) + (kq & 1) * 8;
+    if (m < p.M) {
+      const int b = m / p.HoWo, pix = m - b * p.HoWo;
+      const int oy = pix / p.Wo, ox = pix - oy * p.Wo;
+      g_iy0[i] = oy * p.stride - 1;
+      g_ix0[i] = ox * p.stride - 1;
+      g_ib[i] = b * p.H * p.W;
+      g_om[i] = (unsigned)m * (unsigned)p.ldo * 4u;
+    } else {
+      g_iy0[i] = 0; g_ix0[i] = 0; g_ib[i] = 0;
+      g_om[i] = OOB;
+    }
+  }
+  unsigned b_off[RB];
+  int b_lds[RB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i) {
+    const int u = wave + NW * i, plane = u / (BN / 16), rg = u - plane * (BN / 16);
+    const int row = rg * 16 + (lane >> 2), lsl = (lane & 3) ^ ((row >> 2) & 3);
+    b_off[i] = (unsigned)plane * p.w_plane + (unsigned)(((n0 + row) * p.Kpad + 8 * lsl) * 2);
+    b_lds[i] = plane * (BN * 16) + rg * 256;
+  }
+
+  // per-tap sampling geometry of this thread's rows (dcn_v2_im2col_cuda.cu:143-193): byte offsets of the four corners (+ the
+  // thread's channel slot; OOB where the corner contributes nothing) and the bilinear weights + the modulation.  Branch-free
+  // (selects): the code is expanded once per ring slot.  tap >= 9 (requests past the end of K, see the main loop): all OOB.
+  unsigned gq[RA][4];
+  float gwt[RA][5];
+  float raw[RA][3];                                     // dh, dw, mask logit of the next tap to resolve (fetched one tap ahead)
+  auto raw_fetch = [&](int tap) {
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const unsigned o = g_om[i] != OOB ? g_om[i] + 8u * tap : OOB;
+      raw[i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ors, o, 0, 0));
+      raw[i][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ors, o, 4, 0));
+      raw[i][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ors, o, 4 * 18 - 4 * tap, 0));
+    }
+  };
+  auto geom = [&](int tap) {
+    const int ky = tap / 3, kx = tap - 3 * ky;
+    const bool live = tap < 9;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const float dh = raw[i][0], dw = raw[i][1];
+      const float mk = p.mask_is_prob ? raw[i][2] : 1.f / (1.f + expf(-raw[i][2]));
+      const float h = (float)(g_iy0[i] + ky) + dh, w = (float)(g_ix0[i] + kx) + dw;
+      const bool in = live && g_om[i] != OOB && h > -1.f && w > -1.f && h < (float)p.H && w < (float)p.W;
+      const int hl = (int)floorf(h), wl = (int)floorf(w);
+      const int hh = hl + 1, wh = wl + 1;
+      const float lh = h - (float)hl, lw = w - (float)wl, uh = 1.f - lh, uw = 1.f - lw;
+      const unsigned o1 = (unsigned)(((g_ib[i] + hl * p.W + wl) * p.ldx + 4 * kq) * 4);
+      const unsigned dx = (unsigned)(p.ldx * 4), dy = (unsigned)(p.W * p.ldx * 4);
+      // an out-of-range corner contributes 0 (dmcn_im2col_bilinear): no read at all (the buffer bounds check returns zeros)
+      const bool t_ = in && hl >= 0, b_ = in && hh <= p.H - 1, l_ = wl >= 0, r_ = wh <= p.W - 1;
+      gq[i][0] = (t_ && l_) ? o1 : OOB;
+      gq[i][1] = (t_ && r_) ? o1 + dx : OOB;
+      gq[i][2] = (b_ && l_) ? o1 + dy : OOB;
+      gq[i][3] = (b_ && r_) ? o1 + dy + dx : OOB;
+      gwt[i][0] = (t_ && l_) ? uh * uw : 0.f;
+      gwt[i][1] = (t_ && r_) ? uh * lw : 0.f;
+      gwt[i][2] = (b_ && l_) ? lh * uw : 0.f;
+      gwt[i][3] = (b_ && r_) ? lh * lw : 0.f;
+      gwt[i][4] = mk;
+    }
+  };
+
+  // ---- the register ring of the gather: two chunks in flight ---------------------------------------------------------------
+  f32x4 ring[2][RA][4];
+  float ringw[2][RA][5];
+  int g_tap = 0, g_c = 0;                               // (tap, first channel) of the next chunk to request
+  auto tap_step = [&]() {                               // start of a chunk's requests: resolve the geometry at a tap boundary
+    if (g_c == 0) {
+      geom(g_tap);
+      if (g_tap + 1 < 9) raw_fetch(g_tap + 1);
+    }
+  };
+  auto gather_row = [&](auto slot_c, int i) {           // the four corner loads of row i of the chunk at (g_tap, g_c)
+    constexpr int S = decltype(slot_c)::value;
+    const int so = g_c * 4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      ring[S][i][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, gq[i][c], so, 0));
+#pragma unroll
+    for (int e = 0; e < 5; ++e) ringw[S][i][e] = gwt[i][e];
+  };
+  auto chunk_advance = [&]() {
+    g_c += BK;
+    if (g_c == p.Cin) { g_c = 0; ++g_tap; }
+  };
+  // sample -> two fp16 planes -> LDS (row i of the chunk held in ring slot S)
+  auto combine_row = [&](auto slot_c, int i, float *As) {
+    constexpr int S = decltype(slot_c)::value;
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a = ringw[S][i][0] * ring[S][i][0][e];
+      a = __builtin_fmaf(ringw[S][i][1], ring[S][i][1][e], a);
+      a = __builtin_fmaf(ringw[S][i][2], ring[S][i][2][e], a);
+      a = __builtin_fmaf(ringw[S][i][3], ring[S][i][3][e], a);
+      v[e] = (a * ringw[S][i][4]) * sA;
+    }
+    f16x4 h4, l4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const _Float16 h = (_Float16)v[e];
+      h4[e] = h;
+      l4[e] = (_Float16)(v[e] - (float)h);
+    }
+    char *dst = reinterpret_cast<char *>(As) + a_st[i];
+    *reinterpret_cast<f16x4 *>(dst) = h4;
+    *reinterpret_cast<f16x4 *>(dst + BM * 64) = l4;
+  };
+  // (a chunk index past the end of K reads the following filter rows — or zeros past the buffer — into a stage nobody multiplies)
+  auto issue_b_piece = [&](int kc, int stage, int i) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(Bbase + stage * B_STAGE + b_lds[i]), 16, b_off[i], kc * (BK * 2), 0, 0);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragments: plane images of 64-byte rows, 16-byte slot s of row r at s ^ ((r >> 2) & 3); lane half h of step s2 holds
+  // k = 16 s2 + 8 h .. + 7 of row lane & 31
+  Split2 pa[TM], pb[TN];
+  const int psw = ((lane & 31) >> 2) & 3, hh_ = lane >> 5;
+  const int fro[2] = {(lane & 31) * 16 + 4 * ((0 + hh_) ^ psw), (lane & 31) * 16 + 4 * ((2 + hh_) ^ psw)};
+  auto load_frag = [&](const float *As, const float *Bs, int s2) {
+    const float *Ap = As + (wm * TM * 32) * 16 + fro[s2];
+    const float *Bp = Bs + (wn * TN * 32) * 16 + fro[s2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      pa[i].h = *reinterpret_cast<const f16x8 *>(Ap + i * 32 * 16);
+      pa[i].l = *reinterpret_cast<const f16x8 *>(Ap + i * 32 * 16 + BM * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      pb[j].h = *reinterpret_cast<const f16x8 *>(Bp + j * 32 * 16);
+      pb[j].l = *reinterpret_cast<const f16x8 *>(Bp + j * 32 * 16 + BN * 16);
+    }
+  };
+
+#define YMI_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+#define YMI_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+  // One K step: the MFMAs of chunk st, and between them the pieces of the producer side — combine row q of chunk st+1 (ring
+  // slot SLOT), request the same row of chunk st+3 into the registers just freed, one filter DMA of chunk st+3.  EVERY step does
+  // all of it: the requests of the last three steps go past the end of K (tap >= 9: all-OOB corner loads, i.e. zeros without a
+  // memory access; filter DMAs into stages nobody multiplies), which keeps the step a single straight-line body with one
+  // constant vmcnt.
+  constexpr int NPIECE = RA + RB, NPOS = 6 * TM * TN;
+  auto step = [&](int st, auto slot_c) {
+    const float *As = Abase + (st & 1) * A_STAGE, *Bs = Bbase + (st & 3) * B_STAGE;
+    float *An = Abase + ((st + 1) & 1) * A_STAGE;
+    load_frag(As, Bs, 0);
+    tap_step();
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      if (s2 == 1) load_frag(As, Bs, 1);
+#pragma unroll
+      for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const f16x8 fa_ = pr == 1 ? pa[i].l : pa[i].h;
+            const f16x8 fb_ = pr == 0 ? pb[j].l : pb[j].h;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_, fb_, acc[i][j], 0, 0, 0);
+            const int pos = ((s2 * 3 + pr) * TM + i) * TN + j;
+#pragma unroll
+            for (int q = 0; q < NPIECE; ++q) {
+              if ((NPOS * q) / NPIECE == pos) {
+                if (q < RA) {
+                  combine_row(slot_c, q, An);
+                  gather_row(slot_c, q);
+                } else {
+                  issue_b_piece(st + 3, (st + 3) & 3, q - RA);
+                }
+              }
+            }
+          }
+    }
+    chunk_advance();
+    YMI_WAIT_VM(N_STEADY);        // the filter DMA of chunk st+1 has the 2 * (NG + NB) operations of steps st-1 and st behind it
+    YMI_BARRIER();
+  };
+
+  // ---- prologue: chunks 0, 1, 2 requested, chunk 0 combined ------------------------------------------------------------------
+  raw_fetch(0);
+  tap_step();
+#pragma unroll
+  for (int i = 0; i < RA; ++i) gather_row(std::integral_constant<int, 0>{}, i);
+#pragma unroll
+  for (int i = 0; i < RB; ++i) issue_b_piece(0, 0, i);
+  chunk_advance();
+  tap_step();
+#pragma unroll
+  for (int i = 0; i < RA; ++i) gather_row(std::integral_constant<int, 1>{}, i);
+#pragma unroll
+  for (int i = 0; i < RB; ++i) issue_b_piece(1, 1, i);
+  chunk_advance();
+#pragma unroll
+  for (int i = 0; i < RA; ++i) combine_row(std::integral_constant<int, 0>{}, i, Abase);
+  tap_step();
+#pragma unroll
+  for (int i = 0; i < RA; ++i) gather_row(std::integral_constant<int, 0>{}, i);
+#pragma unroll
+  for (int i = 0; i < RB; ++i) issue_b_piece(2, 2, i);
+  chunk_advance();
+  YMI_WAIT_VM(N_STEADY);        // the filter DMA of chunk 0 has 2 * (NG + NB) younger operations behind it
+  YMI_BARRIER();
+
+  // ---- main loop: two steps per trip (the ring slot is a compile-time index) ------------------------------------------------
+  // (both steps unconditionally inside the trip: with `if (st + 1 < nk)` around the second one the CFG has a path from the first
+  // step straight back to itself, and the compiler's vmcnt for the ring registers drops from ~16 to 3 — measured in the ISA)
+  const int nk = p.nk;
+  int st = 0;
+  for (; st + 1 < nk; st += 2) {
+    step(st, std::integral_constant<int, 1>{});
+    step(st + 1, std::integral_constant<int, 0>{});
+  }
+  if (st < nk) step(st, std::integral_constant<int, 1>{});      // odd number of chunks (Cin = 32 * odd)
+  YMI_WAIT_VM(0);               // the run-ahead filter DMAs target LDS the epilogue is about to reuse
+  YMI_BARRIER();
+#undef YMI_WAIT_VM
+#undef YMI_BARRIER
+
+  // ---- epilogue: accumulators -> LDS tile -> 16-byte stores (the fast path of conv_igemm.hip) -------------------------------
+  // folded-BN scale (times the filter row's inverse scale) and bias: requested before the transposition, consumed (scale * the
+  // exact power of two 1 / sA) before the row loop — a pending load inside the per-row branches would make the compiler wait
+  // vmcnt(0), i.e. for the previous row's STORE, in every row
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+  if (n < p.Cout) {                                     // Cout % 4 == 0 (host check): the four channels exist together
+    if (((((uintptr_t)p.scale_h2) | ((uintptr_t)p.bias)) & 15) == 0) {
+      sc = *reinterpret_cast<const f32x4 *>(p.scale_h2 + n);
+      if (p.bias) bi = *reinterpret_cast<const f32x4 *>(p.bias + n);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { sc[e] = p.scale_h2[n + e]; if (p.bias) bi[e] = p.bias[n + e]; }
+    }
+  }
+  float *es = lds;
+  {
+    const int ncol = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          es[((wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * ELD + (wn * TN + j) * 32 + ncol] = acc[i][j][r];
+  }
+  sc = sc * invA;               // exact (a power of two); (v * invA) * sc == v * (invA * sc)
+  __syncthreads();
+  const float slope = p.act == YMI_ACT_RELU ? 0.f : (p.act == YMI_ACT_LEAKY01 ? 0.1f : 1.f);
+  float am = 0.f;
+  f32x4 o[RPT];
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    f32x4 v = *reinterpret_cast<const f32x4 *>(es + (rbase + RSTEP * i) * ELD + 4 * c4);
+    v = v * sc + bi;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], slope * v[e]);
+    o[i] = v;
+  }
+  if (n < p.Cout) {
+    float *base = p.y + (size_t)(m0 + rbase) * p.ldy + n;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i)
+      if (m0 + rbase + RSTEP * i < p.M) {
+        am = fmaxf(am, ymi_absmax4(o[i]));
+        *reinterpret_cast<f32x4 *>(base + (size_t)(RSTEP * i) * p.ldy) = o[i];
+      }
+  }
+  if (p.y_amax) ymi_amax_finish(apre, am);
+#endif
+}
+
+template <int WM, int WN, int TM, int TN>
+int launch_dcn(DcnParams p, hipStream_t s) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  p.tiles_n = (p.Cout + BN - 1) / BN;
+  const int grid = ((p.M + BM - 1) / BM) * p.tiles_n;
+  hipLaunchKernelGGL((dcn_h2_k<WM, WN, TM, TN>), dim3(grid), dim3(64 * WM * WN), 0, s, p);
+  return ymi_launch_status();
+}
+
+}  // namespace
+
+// internal (not part of the C ABI; called by ymi_dcn_v2_forward_f32 in csrc/conv_igemm.hip): the pipelined gather-GEMM for a
+// validated descriptor whose tile is YMI_TILE_H2 | YMI_TILE_DCNP | YMI_DCNP_* (base_tile = the YMI_DCNP_* part).  Returns YMI_EARG when the descriptor is outside what
+// the kernel takes (the caller then runs the general loader).
+int ymi_internal_dcn_h2(const ymi_dcn_desc *dd, int base_tile, hipStream_t s) {
+  const ymi_conv_desc *d = &dd->conv;
+  const ymi_conv_seg &g0 = d->seg[0];
+  const long HoWo = (long)d->Ho * d->Wo, M = (long)d->B * HoWo;
+  if (d->kh != 3 || d->kw != 3 || d->pad != 1 || d->Cin % 32 != 0 || d->Kpad != 9 * d->Cin) return YMI_EARG;
+  if (d->nseg != 1 || g0.n0 != 0 || g0.n1 < d->Cout || (d->Cout & 3) || (g0.row_stride & 3) || (((uintptr_t)g0.ptr) & 15) ||
+      g0.batch_stride != HoWo * g0.row_stride || g0.act > YMI_ACT_LEAKY01 || g0.act < 0 || d->res_mode != YMI_RES_NONE)
+    return YMI_EARG;
+  if (!d->w_h2 || !d->scale_h2 || !d->x_amax || (((uintptr_t)d->w_h2) & 15)) return YMI_ENULL;
+  if (M * (long)dd->ldo >= (1L << 29) || M * (long)g0.row_stride >= (1L << 31)) return YMI_ESHAPE;
+  DcnParams p;
+  p.x = d->x; p.offmask = dd->offmask; p.scale_h2 = d->scale_h2; p.bias = d->bias; p.x_amax = d->x_amax;
+  p.w_h2 = d->w_h2; p.y = g0.ptr; p.y_amax = d->y_amax;
+  p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.ldx = d->ldx; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
+  p.stride = d->stride; p.Kpad = d->Kpad; p.ldo = dd->ldo; p.ldy = g0.row_stride; p.act = g0.act; p.mask_is_prob = dd->mask_is_prob;
+  p.M = (int)M; p.HoWo = (int)HoWo; p.tiles_n = 0; p.nk = d->Kpad / BK;
+  p.x_bytes = (unsigned)((size_t)d->B * d->H * d->W * d->ldx * sizeof(float));
+  p.om_bytes = (unsigned)((size_t)M * dd->ldo * sizeof(float));
+  p.w_plane = (unsigned)((((long)d->Cout + 127) / 128 * 128) * d->Kpad * 2L);
+  const int tile_id = base_tile | YMI_TILE_H2 | YMI_TILE_DCNP;
+  const double flops = 2.0 * (double)M * (double)(d->cout_alg > 0 ? d->cout_alg : d->Cout) * 9.0 * (double)(d->cin_alg > 0 ? d->cin_alg : d->Cin);
+  if (base_tile < YMI_DCNP_64x128 || base_tile > YMI_DCNP_32x128) return YMI_EARG;
+  int rc;
+  const int pr = ymi_internal_prof_begin(flops, tile_id, 9, s);
+  switch (base_tile) {                                   // <waves along M, waves along N, 32x32 tiles per wave along M, along N>
+    case YMI_DCNP_64x128: rc = launch_dcn<2, 2, 1, 2>(p, s); break;
+    case YMI_DCNP_64x128_W8: rc = launch_dcn<2, 4, 1, 1>(p, s); break;
+    case YMI_DCNP_64x64: rc = launch_dcn<2, 2, 1, 1>(p, s); break;
+    case YMI_DCNP_128x128_W8: rc = launch_dcn<4, 2, 1, 2>(p, s); break;
+    case YMI_DCNP_128x64_W8: rc = launch_dcn<4, 2, 1, 1>(p, s); break;
+    default: rc = launch_dcn<1, 4, 1, 1>(p, s); break;   // YMI_DCNP_32x128
+  }
+  ymi_internal_prof_end(pr, s);
+  return rc;
+}

@@ -732,7 +732,7 @@ class Plan:
                 if blk.use_dcn:
                     dcn = blk.conv2
                     om = self.conv(nm + '.offmask', o1, pack_module(dcn.conv_offset_mask, None, dev))
-                    pk = Packed(dcn.weight, dcn.bias, blk.bn2, dcn.stride, 1, None, dev)
+                    pk = Packed(dcn.weight, dcn.bias, blk.bn2, dcn.stride[0], 1, None, dev)     # (stride is a pair, dcn_v2.py:62)
                     o2 = self.conv(nm + '.dcn', o1, pk, act=L.ACT_RELU, dcn_offmask=om)
                     ar.free(om)
                 else:
@@ -994,6 +994,8 @@ class Plan:
                     base_ok = L.H2_BASE_TILES if spflag == L.TILE_H2 else L.X3_BASE_TILES
                     cands = cands + [t | spflag for t in cands if t in base_ok
                                      and (d.Cin % 32 == 0 or t in L.BASIC_TILES)]
+                if is_dcn and self.h2:       # the pipelined gather-GEMM of csrc/dcn.hip (fp16x2 plans)
+                    cands = cands + [t | L.TILE_H2 | L.TILE_DCNP for t in sorted(L.DCNP_TILES)]
                 if not is_dcn and self._splitk_ok(d) and self.splitk:
                     # split-K candidates: big tiles whose grid alone cannot fill the chip, K cut 2 / 4 ways
                     x3 = spflag

@@ -26,22 +26,9 @@ class InterpolateModule(_NoCompute):
         self.scale_factor = scale_factor
 
 
-class DCN(_NoCompute):
-    """Holds weight, bias and conv_offset_mask like external/DCNv2/dcn_v2.py:97-116."""
-
-    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=1, dilation=1, deformable_groups=1):
-        super().__init__()
-        if kernel_size != 3 or padding != 1 or dilation != 1 or deformable_groups != 1:
-            raise NotImplementedError('only the 3x3 / pad 1 / one-group DCN that YOLACT++ constructs (backbone.py:22-26)')
-        self.in_channels, self.out_channels, self.stride = in_channels, out_channels, stride
-        self.weight = nn.Parameter(torch.zeros(out_channels, in_channels, 3, 3))
-        self.bias = nn.Parameter(torch.zeros(out_channels))
-        self.conv_offset_mask = nn.Conv2d(in_channels, 27, 3, stride=stride, padding=1, bias=True)
-        n = in_channels * 9
-        with torch.no_grad():
-            self.weight.uniform_(-1.0 / n ** 0.5, 1.0 / n ** 0.5)
-            self.conv_offset_mask.weight.zero_()
-            self.conv_offset_mask.bias.zero_()
+# external/DCNv2/dcn_v2.py:97-128.  Unlike the other containers this one computes when called on its own (the reference's DCNv2
+# known-answer test does that): yolact_amd/dcn_v2.py runs the HIP kernels behind the reference's module API.
+from .dcn_v2 import DCN          # noqa: E402,F401
 
 
 class Bottleneck(_NoCompute):
