@@ -132,7 +132,9 @@ enum { YMI_TILE_AUTO = 0, YMI_TILE_128x128 = 1, YMI_TILE_128x64 = 2, YMI_TILE_64
        YMI_TILE_DCNP = 128 };
 /* block tiles of the pipelined DCN kernel (BM x BN, _W8 = 512-thread blocks) */
 enum { YMI_DCNP_64x128 = 1, YMI_DCNP_64x128_W8 = 2, YMI_DCNP_64x64 = 3, YMI_DCNP_128x128_W8 = 4, YMI_DCNP_128x64_W8 = 5,
-       YMI_DCNP_32x128 = 6 };
+       YMI_DCNP_32x128 = 6,
+       /* 6 / 8 / 10 / 12 waves of 32 x 64, corner loads two chunks ahead (one register slot): one block per CU, rows sized to M / 256 */
+       YMI_DCNP_96x128_W6 = 7, YMI_DCNP_128x128_W8_R1 = 8, YMI_DCNP_160x128_W10 = 9, YMI_DCNP_192x128_W12 = 10 };
 
 int ymi_abi_version(void);
 const char *ymi_strerror(int code);

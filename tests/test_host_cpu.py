@@ -230,6 +230,37 @@ def _gloo_worker(rank, world, port, q):
         raise SystemExit('size mismatch not detected')
     except RuntimeError as e:
         assert 'different numbers of records' in str(e)
+    # Yolact.forward_sharded's two halves with the persistent-buffer gatherer, two steps into the same receive buffer: the
+    # first step's results must survive the second (round-3 advisor: they used to be views of the buffer), local images carry
+    # their prototypes, remote ones an explicit None that postprocess() refuses
+    gat = parallel.RecordGatherer(0)
+    steps = []
+    for step in range(2):
+        gs = torch.Generator().manual_seed(7 + 10 * step + rank)
+        outs = dict(count=torch.tensor([2, 1], dtype=torch.int32), box=torch.rand(2, cap, 4, generator=gs),
+                    score=torch.rand(2, cap, generator=gs), cls=torch.randint(0, 80, (2, cap), generator=gs),
+                    coef=torch.rand(2, cap, D, generator=gs), proto=torch.rand(2, 6, 6, D, generator=gs))
+        allr = gat(parallel.pack_records(outs), 2, n_items=4, force_collective=True)
+        if rank == 0:
+            res = parallel.assemble_sharded(allr, outs, 0, 2, D, net='net')
+            steps.append((res, [r['detection']['box'].clone() for r in res], outs))
+    if rank == 0:
+        (res0, boxes0, outs0), (res1, _, _) = steps
+        buf = next(iter(gat._out.values()))
+        for r, b0 in zip(res0, boxes0):
+            assert torch.equal(r['detection']['box'], b0), 'step-0 results changed when step 1 reused the receive buffer'
+            assert r['detection']['box'].untyped_storage().data_ptr() != buf.untyped_storage().data_ptr()
+        assert torch.equal(res0[0]['detection']['box'], outs0['box'][0, :2])
+        assert res0[0]['detection']['proto'] is outs0['proto'][0] or torch.equal(res0[0]['detection']['proto'], outs0['proto'][0])
+        assert res0[2]['detection']['proto'] is None and res0[3]['detection']['proto'] is None and res0[2]['net'] == 'net'
+        from yolact_amd.layers.output_utils import postprocess
+        import yolact_amd
+        yolact_amd.set_cfg('yolact_resnet50_config')
+        try:
+            postprocess(res0, 50, 50, batch_idx=2)
+            raise SystemExit('postprocess accepted a detection without prototypes')
+        except RuntimeError as e:
+            assert 'another rank' in str(e)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -175,3 +175,29 @@ def test_fused_stem_and_upsample_hooks_in_the_plan(monkeypatch):
     monkeypatch.delenv('YOLACT_AMD_FUSED_STEM')
     dk = Plan(_make_net('yolact_darknet53_config'), 1, 550, 550, dev)
     assert not dk.fused_stem and dk.ops[0][0] == 'input'
+
+
+@pytest.mark.parametrize('config,size,B', [('yolact_resnet50_config', 550, 1), ('yolact_resnet50_config', 550, 8),
+                                           ('yolact_base_config', 550, 2), ('yolact_im700_config', 700, 1),
+                                           ('yolact_plus_resnet50_config', 550, 2), ('yolact_darknet53_config', 550, 2),
+                                           ('yolact_resnet50_config', 256, 3), ('yolact_resnet50_config', 1024, 1)])
+def test_fused_upsample_source_outlives_its_consumer(config, size, B):
+    """Round-3 advisor: the conv behind the protonet's 2x upsampling may read the LOW-RES tensor inside its Winograd input
+    transform (ymi_wino_desc.x_up) — so that buffer must stay untouched from the bilinear op up to and including the consuming
+    conv: no op in between may write it, and the conv's own output must not alias it (the arena used to free it right after
+    the bilinear op, and only the buffer sizes of the shipped shapes kept the best-fit pool from recycling it)."""
+    from yolact_amd.engine import Plan
+    plan = Plan(_make_net(config), B, size, size, torch.device('cpu'), dry_two_streams=True)
+    bufs = _buffers(plan)
+    assert len(plan._upsrc) == 1
+    (bidx, lo_ptr, _relu), = plan._upsrc.values()
+    lo = _owner(bufs, lo_ptr)
+    up_dst = plan.ops[bidx][1][1]                      # the bilinear op's destination = the consuming conv's input
+    cidx = next(i for i in range(bidx + 1, len(plan.ops))
+                if plan.ops[i][0] is plan.lib.ymi_conv2d_nhwc_f32 and plan.ops[i][1].contents.x == up_dst)
+    for i in range(bidx, cidx + 1):
+        op = plan.ops[i]
+        if op[0] in ('record', 'wait', 'detect', 'nop'):
+            continue
+        _r, w = _accesses(plan, op, bufs)
+        assert not any(_conflict(lo, x) for x in w), (plan.ops[i][2], 'writes the low-res source of the fused upsampling')

@@ -23,6 +23,9 @@ def main():
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--reps', type=int, default=5)
     ap.add_argument('--config', default='yolact_plus_resnet50_config')
+    ap.add_argument('--tiles', default='', help='comma list of pipelined tile names to time (default: all); old tiles are skipped when given')
+    ap.add_argument('--layers', default='', help='comma list of substrings of layer names (default: all DCN layers)')
+    ap.add_argument('--ablate', default='', help='comma list of YMI_DCN_ABLATE masks (diagnostics build only): each tile is re-timed per mask')
     args = ap.parse_args()
     os.environ.setdefault('YOLACT_AMD_AUTOTUNE', 'table')
     import yolact_amd
@@ -47,9 +50,13 @@ def main():
     old = [t for t in L.BASIC_TILES if t != L.TILE_128x32]
     old = old + [t | L.TILE_H2 for t in old]
     new = [t | L.TILE_H2 | L.TILE_DCNP for t in sorted(L.DCNP_TILES)]
+    if args.tiles:
+        new = [t for t in new if L.TILE_NAMES[t] in args.tiles.split(',')]
+        old = [L.TILE_64x64 | L.TILE_H2]
+    abls = [int(a) for a in args.ablate.split(',')] if args.ablate else []
     tot_old = tot_new = tot_fl = 0.0
     for fn, dptr, name, where in plan.ops:
-        if fn is not lib.ymi_dcn_v2_forward_f32:
+        if fn is not lib.ymi_dcn_v2_forward_f32 or (args.layers and not any(k in name for k in args.layers.split(','))):
             continue
         dd = dptr.contents
         d = dd.conv
@@ -78,6 +85,19 @@ def main():
                 e1.synchronize()
                 best = min(best, e0.elapsed_time(e1) / args.reps)
             times[t] = best
+            if t & L.TILE_DCNP and abls:
+                row = []
+                for a in abls:
+                    os.environ['YMI_DCN_ABLATE'] = str(a)
+                    fn(dptr, s)
+                    e0.record()
+                    for _ in range(args.reps):
+                        fn(dptr, s)
+                    e1.record()
+                    e1.synchronize()
+                    row.append('abl=%d %.4f' % (a, e0.elapsed_time(e1) / args.reps))
+                os.environ['YMI_DCN_ABLATE'] = '0'
+                print('    %-14s %s full %.4f | %s' % (L.TILE_NAMES[t], name, best, '  '.join(row)))
         d.tile, d.seg[0].ptr = tile0, yptr0
         bo = min((times[t], t) for t in old if t in times)
         bn = min((times[t], t) for t in new if t in times) if any(t in times for t in new) else (float('nan'), 0)

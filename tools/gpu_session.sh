@@ -77,6 +77,18 @@ PY
       (cd /tmp && YOLACT_AMD_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $R/$O/b1_1 -- bash -c "cd $R && python bench.py --batch 1 --steps 60 --warmup 5 --no-cpu-baseline --no-secondary" > $R/$O/b1_1.log 2>&1)
       for v in 2 1; do f=$(find $O/b1_$v -name "*kernel_trace.csv" | head -1); echo "streams=$v"; python tools/step_timeline.py $f 30; done > $O/b1_timeline.txt 2>&1; cat $O/b1_timeline.txt
       f=$(find $O/b1_1 -name "*kernel_stats.csv" | head -1); head -25 $f | cut -c1-150 > $O/b1_kernel_stats_head.txt; cat $O/b1_kernel_stats_head.txt ;;
+    avail) (cd /tmp && timeout 120 rocprofv3 --list-avail > $R/$O/avail.txt 2>&1); grep -cE "" $O/avail.txt; grep -oE "\b(TA_[A-Z_]+|TCP_[A-Z_0-9]+|TCC_(HIT|MISS|REQ|READ|EA0_RDREQ)[A-Z_0-9]*|SQ_(WAIT|ACTIVE|INSTS|BUSY|WAVE)[A-Z_0-9]*|SQ_LDS[A-Z_]*|FETCH_SIZE|WRITE_SIZE|L2CacheHit|MemUnitBusy|MemUnitStalled|TA_BUSY_avr|LDSBankConflict)\b" $O/avail.txt | sort -u | tr '\n' ' ' ;;
+    dcnpmc) # counters of the pipelined DCN kernel (csrc/dcn.hip) on three representative layers: wave states, then the memory pipe, then bytes
+      PCMD="python tools/dcn_probe.py --tiles ${arg:-dcnp64x128w8} --layers layer1.1,layer2.1,layer3.1 --reps 2"
+      (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-include-regex dcn_h2_k -f csv -d $R/$O/dcnpmc1 -- bash -c "cd $R && $PCMD" > $R/$O/dcnpmc1.log 2>&1)
+      (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-include-regex dcn_h2_k -f csv -d $R/$O/dcnpmc2 -- bash -c "cd $R && $PCMD" > $R/$O/dcnpmc2.log 2>&1)
+      (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TA_BUSY_avr TA_TA_BUSY_sum --kernel-include-regex dcn_h2_k -f csv -d $R/$O/dcnpmc3 -- bash -c "cd $R && $PCMD" > $R/$O/dcnpmc3.log 2>&1)
+      for k in 1 2 3; do python tools/pmc_summary.py $O/dcnpmc$k > $O/pmc_dcn_p$k.tsv 2> $O/dcnpmc$k.err; cat $O/pmc_dcn_p$k.tsv | cut -c1-420; tail -3 $O/dcnpmc$k.log | cut -c1-200; done
+      find $O -name "*counter_collection.csv" -size +4M -delete ;;
+    dcnabl) # diagnostics build of csrc/dcn.hip only (YMI_DCN_ABLATE switches), then the ablation table of tools/dcn_probe.py
+      (cd yolact_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-value -I../../include -DYMI_DIAGNOSTICS=1 -c dcn.hip -o /tmp/dcn_diag.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls *.o | grep -v '^dcn.o$') /tmp/dcn_diag.o -o ../libyolact_amd.so) > $O/dcnabl_build.log 2>&1; tail -2 $O/dcnabl_build.log
+      timeout 600 python tools/dcn_probe.py --tiles ${arg:-dcnp64x128w8,dcnp64x128,dcnp128x128w8} --layers layer1.1,layer2.1,layer3.1 --ablate 1,2,3,4,8,16,32,7,15 > $O/dcn_ablation.txt 2>&1; grep -E "abl=" $O/dcn_ablation.txt | cut -c1-300 ;;
+    upsample) for v in band rows rowsnt; do YOLACT_AMD_UPSAMPLE=$v timeout 120 python tools/upsample_probe.py; YOLACT_AMD_UPSAMPLE=$v timeout 120 python tools/upsample_probe.py --size 337 --width 401 --batch 2 --cap 37; done > $O/upsample_probe.txt 2>&1; cat $O/upsample_probe.txt | cut -c1-220 ;;
     dcnref) timeout 600 python -m pytest tests/test_gpu_dcn_reference.py -m gpu -q -rA -s > $O/dcnref.log 2>&1; tail -5 $O/dcnref.log ;;
     evalpy) timeout 1500 bash tools/run_reference_eval.sh $O > $O/evalpy.log 2>&1; tail -30 $O/evalpy.log ;;
     py) n=$(basename ${arg%% *} .py); k=0; while [ -e $O/$n$k.log ]; do k=$((k+1)); done

@@ -25,6 +25,7 @@
 // K order, LDS images, fragment layout, MFMA order (h*l, l*h, h*h) and the fast-path epilogue are those of the fp16x2 tiles of
 // conv_igemm.hip, so the filter planes / scale_h2 of engine.Packed.h2() are used unchanged.
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 #include "../../include/yolact_amd.h"
 
@@ -49,36 +50,46 @@ struct DcnParams {
   int B, H, W, Cin, ldx, Ho, Wo, Cout, stride, Kpad, ldo, ldy, act, mask_is_prob;
   int M, HoWo, tiles_n, nk;
   unsigned x_bytes, om_bytes, w_plane;
+  int abl;      // diagnostics build only (env YMI_DCN_ABLATE): bit0 corner loads -> OOB (no memory access), bit1 filter DMAs -> OOB,
+                // bit2 no combine / LDS store, bit3 no MFMAs, bit4 no barrier, bit5 no vmcnt wait — wrong results by design
 };
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int RING>
 constexpr int dcn_lds_floats() {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr int pipe = 2 * (2 * BM * 16) + 4 * (2 * BN * 16), epi = BM * (BN + 4);
+  constexpr int pipe = 2 * (2 * BM * 16) + (RING + 2) * (2 * BN * 16), epi = BM * (BN + 4);
   return pipe > epi ? pipe : epi;
 }
-template <int WM, int WN, int TM, int TN>
-constexpr int dcn_occupancy() {     // blocks per CU: LDS-limited, and capped by the register ring of the gather (32 registers per
-                                    // row a thread gathers): 4-wave blocks and 8-wave blocks with one row per thread run two per CU
-  constexpr int occ = (160 * 1024) / (dcn_lds_floats<WM, WN, TM, TN>() * 4);
-  constexpr int ra = (WM * TM * 32) / (8 * WM * WN), cap = (WM * WN == 8 && ra > 1) ? 1 : 2;
+template <int WM, int WN, int TM, int TN, int RING>
+constexpr int dcn_occupancy() {     // blocks per CU: LDS-limited, and capped by the register ring of the gather (16 registers per
+                                    // row and ring slot): 4-wave blocks and 8-wave blocks with one row per thread run two per CU,
+                                    // anything larger one
+  constexpr int occ = (160 * 1024) / (dcn_lds_floats<WM, WN, TM, TN, RING>() * 4);
+  constexpr int nw = WM * WN, ra = (WM * TM * 32) / (8 * nw), cap = (nw > 8 || (nw == 8 && ra > 1)) ? 1 : 2;
   return occ > cap ? cap : (occ < 1 ? 1 : occ);
 }
 
-template <int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(64 * WM * WN, (dcn_occupancy<WM, WN, TM, TN>() * (WM * WN) / 4))
+// RING: corner loads run RING + 1 chunks ahead of the MFMAs in a ring of RING register slots (RING + 2 filter stages).  2 for the
+// small tiles (a step is shorter than a load round trip); 1 for the 96 .. 192-row tiles, whose step is >= 1000 TA cycles.
+template <int WM, int WN, int TM, int TN, int RING>
+__global__ __launch_bounds__(64 * WM * WN, (dcn_occupancy<WM, WN, TM, TN, RING>() * (WM * WN) + 3) / 4)
 void dcn_h2_k(const DcnParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // (host pass: empty body, see conv_igemm.hip)
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NW = WM * WN, NT = 64 * NW;
   constexpr int RPP = NT / 8, RA = BM / RPP;            // gather: 8 lanes (32 channels) per row, RA rows per thread per chunk
-  constexpr int RB = (2 * BN) / (16 * NW);              // filter-plane DMA pieces (16 rows x 64 bytes) per wave per chunk
-  static_assert(BM % RPP == 0 && RA >= 1 && (2 * BN) % (16 * NW) == 0, "tile rows vs staging passes");
+  constexpr int BUNITS = (2 * BN) / 16;                 // filter-plane DMA pieces of a chunk: (plane, 16-row group), 16 rows x 64 bytes each
+  constexpr int RB = (BUNITS + NW - 1) / NW;            // pieces per wave per chunk; when NW does not divide BUNITS the surplus pieces
+                                                        // repeat the last unit (same bytes to the same place: every wave issues the
+                                                        // same number of DMAs, so the vmcnt below is one constant)
+  static_assert(BM % RPP == 0 && RA >= 1, "tile rows vs gather passes");
+  static_assert(RING == 1 || RING == 2, "ring depth");
+  constexpr int NSB = RING + 2;                         // filter stages: chunk st (multiplied), st+1 .. st+RING (landed / in flight), st+RING+1 (requested)
   constexpr int A_STAGE = 2 * BM * 16, B_STAGE = 2 * BN * 16;    // floats: two fp16 planes of 64-byte rows
   constexpr int NG = 4 * RA, NB = RB;                   // VMEM operations of one chunk: corner loads, filter DMAs
-  constexpr int N_STEADY = 2 * (NG + NB);               // operations issued behind the filter DMA of chunk st+1 at the end of step st
+  constexpr int N_STEADY = RING * (NG + NB);            // operations issued behind the filter DMA of chunk st+1 at the end of step st
   static_assert(N_STEADY <= 63, "vmcnt is a 6-bit counter");
   constexpr int ELD = BN + 4;
-  constexpr int LDS_FLOATS = dcn_lds_floats<WM, WN, TM, TN>();
+  constexpr int LDS_FLOATS = dcn_lds_floats<WM, WN, TM, TN, RING>();
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
   float *const Abase = lds, *const Bbase = lds + 2 * A_STAGE;
 
@@ -127,7 +138,8 @@ void dcn_h2_k(const DcnParams p) {
   int b_lds[RB];
 #pragma unroll
   for (int i = 0; i < RB; ++i) {
-    const int u = wave + NW * i, plane = u / (BN / 16), rg = u - plane * (BN / 16);
+    const int u0 = wave + NW * i, u = u0 < BUNITS ? u0 : BUNITS - 1;
+    const int plane = u / (BN / 16), rg = u - plane * (BN / 16);
     const int row = rg * 16 + (lane >> 2), lsl = (lane & 3) ^ ((row >> 2) & 3);
     b_off[i] = (unsigned)plane * p.w_plane + (unsigned)(((n0 + row) * p.Kpad + 8 * lsl) * 2);
     b_lds[i] = plane * (BN * 16) + rg * 256;
@@ -177,8 +189,8 @@ void dcn_h2_k(const DcnParams p) {
   };
 
   // ---- the register ring of the gather: two chunks in flight ---------------------------------------------------------------
-  f32x4 ring[2][RA][4];
-  float ringw[2][RA][5];
+  f32x4 ring[RING][RA][4];
+  float ringw[RING][RA][5];
   int g_tap = 0, g_c = 0;                               // (tap, first channel) of the next chunk to request
   auto tap_step = [&]() {                               // start of a chunk's requests: resolve the geometry at a tap boundary
     if (g_c == 0) {
@@ -190,8 +202,13 @@ void dcn_h2_k(const DcnParams p) {
     constexpr int S = decltype(slot_c)::value;
     const int so = g_c * 4;
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < 4; ++c) {
+#ifdef YMI_DIAGNOSTICS
+      ring[S][i][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (p.abl & 1) ? OOB : gq[i][c], so, 0));
+#else
       ring[S][i][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, gq[i][c], so, 0));
+#endif
+    }
 #pragma unroll
     for (int e = 0; e < 5; ++e) ringw[S][i][e] = gwt[i][e];
   };
@@ -202,6 +219,9 @@ void dcn_h2_k(const DcnParams p) {
   // sample -> two fp16 planes -> LDS (row i of the chunk held in ring slot S)
   auto combine_row = [&](auto slot_c, int i, float *As) {
     constexpr int S = decltype(slot_c)::value;
+#ifdef YMI_DIAGNOSTICS
+    if (p.abl & 4) return;
+#endif
     f32x4 v;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -224,6 +244,9 @@ void dcn_h2_k(const DcnParams p) {
   };
   // (a chunk index past the end of K reads the following filter rows — or zeros past the buffer — into a stage nobody multiplies)
   auto issue_b_piece = [&](int kc, int stage, int i) {
+#ifdef YMI_DIAGNOSTICS
+    if (p.abl & 2) { __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(Bbase + stage * B_STAGE + b_lds[i]), 16, OOB, 0, 0, 0); return; }
+#endif
     __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(Bbase + stage * B_STAGE + b_lds[i]), 16, b_off[i], kc * (BK * 2), 0, 0);
   };
 
@@ -264,9 +287,11 @@ void dcn_h2_k(const DcnParams p) {
   // memory access; filter DMAs into stages nobody multiplies), which keeps the step a single straight-line body with one
   // constant vmcnt.
   constexpr int NPIECE = RA + RB, NPOS = 6 * TM * TN;
+  int bst = 0;                                          // filter stage of the chunk being multiplied (= st mod NSB)
   auto step = [&](int st, auto slot_c) {
-    const float *As = Abase + (st & 1) * A_STAGE, *Bs = Bbase + (st & 3) * B_STAGE;
+    const float *As = Abase + (st & 1) * A_STAGE, *Bs = Bbase + bst * B_STAGE;
     float *An = Abase + ((st + 1) & 1) * A_STAGE;
+    const int bnx = bst == 0 ? NSB - 1 : bst - 1;      // stage of chunk st + RING + 1 = (st - 1) mod NSB: free since the last barrier
     load_frag(As, Bs, 0);
     tap_step();
 #pragma unroll
@@ -280,6 +305,9 @@ void dcn_h2_k(const DcnParams p) {
           for (int j = 0; j < TN; ++j) {
             const f16x8 fa_ = pr == 1 ? pa[i].l : pa[i].h;
             const f16x8 fb_ = pr == 0 ? pb[j].l : pb[j].h;
+#ifdef YMI_DIAGNOSTICS
+            if (!(p.abl & 8))
+#endif
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_, fb_, acc[i][j], 0, 0, 0);
             const int pos = ((s2 * 3 + pr) * TM + i) * TN + j;
 #pragma unroll
@@ -289,18 +317,24 @@ void dcn_h2_k(const DcnParams p) {
                   combine_row(slot_c, q, An);
                   gather_row(slot_c, q);
                 } else {
-                  issue_b_piece(st + 3, (st + 3) & 3, q - RA);
+                  issue_b_piece(st + RING + 1, bnx, q - RA);
                 }
               }
             }
           }
     }
     chunk_advance();
-    YMI_WAIT_VM(N_STEADY);        // the filter DMA of chunk st+1 has the 2 * (NG + NB) operations of steps st-1 and st behind it
+    bst = bst + 1 == NSB ? 0 : bst + 1;
+#ifdef YMI_DIAGNOSTICS
+    if (!(p.abl & 32)) YMI_WAIT_VM(N_STEADY);
+    if (!(p.abl & 16)) YMI_BARRIER();
+#else
+    YMI_WAIT_VM(N_STEADY);        // the filter DMA of chunk st+1 has the RING * (NG + NB) operations of the last RING steps behind it
     YMI_BARRIER();
+#endif
   };
 
-  // ---- prologue: chunks 0, 1, 2 requested, chunk 0 combined ------------------------------------------------------------------
+  // ---- prologue: chunks 0 .. RING requested, chunk 0 combined ---------------------------------------------------------------
   raw_fetch(0);
   tap_step();
 #pragma unroll
@@ -308,33 +342,39 @@ void dcn_h2_k(const DcnParams p) {
 #pragma unroll
   for (int i = 0; i < RB; ++i) issue_b_piece(0, 0, i);
   chunk_advance();
-  tap_step();
+  if constexpr (RING == 2) {
+    tap_step();
 #pragma unroll
-  for (int i = 0; i < RA; ++i) gather_row(std::integral_constant<int, 1>{}, i);
+    for (int i = 0; i < RA; ++i) gather_row(std::integral_constant<int, 1>{}, i);
 #pragma unroll
-  for (int i = 0; i < RB; ++i) issue_b_piece(1, 1, i);
-  chunk_advance();
+    for (int i = 0; i < RB; ++i) issue_b_piece(1, 1, i);
+    chunk_advance();
+  }
 #pragma unroll
   for (int i = 0; i < RA; ++i) combine_row(std::integral_constant<int, 0>{}, i, Abase);
   tap_step();
 #pragma unroll
   for (int i = 0; i < RA; ++i) gather_row(std::integral_constant<int, 0>{}, i);
 #pragma unroll
-  for (int i = 0; i < RB; ++i) issue_b_piece(2, 2, i);
+  for (int i = 0; i < RB; ++i) issue_b_piece(RING, RING, i);
   chunk_advance();
-  YMI_WAIT_VM(N_STEADY);        // the filter DMA of chunk 0 has 2 * (NG + NB) younger operations behind it
+  YMI_WAIT_VM(N_STEADY);        // the filter DMA of chunk 0 has RING * (NG + NB) younger operations behind it
   YMI_BARRIER();
 
-  // ---- main loop: two steps per trip (the ring slot is a compile-time index) ------------------------------------------------
-  // (both steps unconditionally inside the trip: with `if (st + 1 < nk)` around the second one the CFG has a path from the first
-  // step straight back to itself, and the compiler's vmcnt for the ring registers drops from ~16 to 3 — measured in the ISA)
+  // ---- main loop: RING steps per trip (the ring slot is a compile-time index) -----------------------------------------------
+  // (RING == 2: both steps unconditionally inside the trip: with `if (st + 1 < nk)` around the second one the CFG has a path from
+  // the first step straight back to itself, and the compiler's vmcnt for the ring registers drops from ~16 to 3 — seen in the ISA)
   const int nk = p.nk;
-  int st = 0;
-  for (; st + 1 < nk; st += 2) {
-    step(st, std::integral_constant<int, 1>{});
-    step(st + 1, std::integral_constant<int, 0>{});
+  if constexpr (RING == 2) {
+    int st = 0;
+    for (; st + 1 < nk; st += 2) {
+      step(st, std::integral_constant<int, 1>{});
+      step(st + 1, std::integral_constant<int, 0>{});
+    }
+    if (st < nk) step(st, std::integral_constant<int, 1>{});      // odd number of chunks (Cin = 32 * odd)
+  } else {
+    for (int st = 0; st < nk; ++st) step(st, std::integral_constant<int, 0>{});
   }
-  if (st < nk) step(st, std::integral_constant<int, 1>{});      // odd number of chunks (Cin = 32 * odd)
   YMI_WAIT_VM(0);               // the run-ahead filter DMAs target LDS the epilogue is about to reuse
   YMI_BARRIER();
 #undef YMI_WAIT_VM
@@ -391,12 +431,12 @@ void dcn_h2_k(const DcnParams p) {
 #endif
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int RING = 2>
 int launch_dcn(DcnParams p, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   p.tiles_n = (p.Cout + BN - 1) / BN;
   const int grid = ((p.M + BM - 1) / BM) * p.tiles_n;
-  hipLaunchKernelGGL((dcn_h2_k<WM, WN, TM, TN>), dim3(grid), dim3(64 * WM * WN), 0, s, p);
+  hipLaunchKernelGGL((dcn_h2_k<WM, WN, TM, TN, RING>), dim3(grid), dim3(64 * WM * WN), 0, s, p);
   return ymi_launch_status();
 }
 
@@ -424,9 +464,13 @@ int ymi_internal_dcn_h2(const ymi_dcn_desc *dd, int base_tile, hipStream_t s) {
   p.x_bytes = (unsigned)((size_t)d->B * d->H * d->W * d->ldx * sizeof(float));
   p.om_bytes = (unsigned)((size_t)M * dd->ldo * sizeof(float));
   p.w_plane = (unsigned)((((long)d->Cout + 127) / 128 * 128) * d->Kpad * 2L);
+  p.abl = 0;
+#ifdef YMI_DIAGNOSTICS   // `make DIAG=1`: stall attribution for tools/dcn_probe.py — wrong results by design
+  { const char *e = getenv("YMI_DCN_ABLATE"); p.abl = e ? atoi(e) : 0; }
+#endif
   const int tile_id = base_tile | YMI_TILE_H2 | YMI_TILE_DCNP;
   const double flops = 2.0 * (double)M * (double)(d->cout_alg > 0 ? d->cout_alg : d->Cout) * 9.0 * (double)(d->cin_alg > 0 ? d->cin_alg : d->Cin);
-  if (base_tile < YMI_DCNP_64x128 || base_tile > YMI_DCNP_32x128) return YMI_EARG;
+  if (base_tile < YMI_DCNP_64x128 || base_tile > YMI_DCNP_192x128_W12) return YMI_EARG;
   int rc;
   const int pr = ymi_internal_prof_begin(flops, tile_id, 9, s);
   switch (base_tile) {                                   // <waves along M, waves along N, 32x32 tiles per wave along M, along N>
@@ -435,7 +479,14 @@ int ymi_internal_dcn_h2(const ymi_dcn_desc *dd, int base_tile, hipStream_t s) {
     case YMI_DCNP_64x64: rc = launch_dcn<2, 2, 1, 1>(p, s); break;
     case YMI_DCNP_128x128_W8: rc = launch_dcn<4, 2, 1, 2>(p, s); break;
     case YMI_DCNP_128x64_W8: rc = launch_dcn<4, 2, 1, 1>(p, s); break;
-    default: rc = launch_dcn<1, 4, 1, 1>(p, s); break;   // YMI_DCNP_32x128
+    case YMI_DCNP_32x128: rc = launch_dcn<1, 4, 1, 1>(p, s); break;
+    // one block per CU sized to M / 256 rows: the kernel is bound by the texture addresser (16 cycles per 1 KB wave load / DMA), so
+    // what counts is (i) every CU busy for the whole launch — no second residency round, no CUs with twice the blocks of others —
+    // and (ii) the filter DMAs (16 per chunk whatever the row count) amortised over more rows
+    case YMI_DCNP_96x128_W6: rc = launch_dcn<3, 2, 1, 2, 1>(p, s); break;
+    case YMI_DCNP_128x128_W8_R1: rc = launch_dcn<4, 2, 1, 2, 1>(p, s); break;
+    case YMI_DCNP_160x128_W10: rc = launch_dcn<5, 2, 1, 2, 1>(p, s); break;
+    default: rc = launch_dcn<6, 2, 1, 2, 1>(p, s); break;   // YMI_DCNP_192x128_W12
   }
   ymi_internal_prof_end(pr, s);
   return rc;

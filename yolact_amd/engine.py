@@ -648,6 +648,9 @@ class Plan:
         mods = list(net.proto_net)
         conv_idx = [i for i, m in enumerate(mods) if isinstance(m, nn.Conv2d)]
         self.proto_patch = None
+        held = None      # low-res source of a fusable 2x upsampling: the consuming conv's F(4x4) input transform may read IT instead
+                         # of the upsampled tensor (ymi_wino_desc.x_up), so its buffer stays allocated until that conv's output
+                         # has been allocated — freed earlier, the best-fit arena could hand it to the conv's own output
         for i, m in enumerate(mods):
             if i == 0 and self._merged_p3 is not None:      # proto.0 was computed together with head0.up0
                 self.free(t)
@@ -672,6 +675,9 @@ class Plan:
                 else:
                     nt = self.conv('proto.%d' % i, t, pk, act=a)
                 self.free(t)
+                if held is not None:
+                    self.free(held)
+                    held = None
                 t = nt
             elif isinstance(m, M.InterpolateModule):
                 s = int(m.scale_factor)
@@ -682,9 +688,11 @@ class Plan:
                 if s == 2 and os.environ.get('YOLACT_AMD_FUSED_UPSAMPLE', '1') == '1':
                     # (the tuner drops this launch when the consuming conv runs as F(4x4,3x3): csrc/winograd.hip UPS)
                     self._upsrc[id(y)] = (len(self.ops) - 1, t.ptr, 1 if has_relu else 0)
-                self.free(t)
+                    held = t
+                else:
+                    self.free(t)
                 t = y
-        assert self.proto_patch is not None
+        assert self.proto_patch is not None and held is None
         self.wait('b_done')
         self.priors = torch.tensor(pri, dtype=torch.float32).view(-1, 4).to(dev)
         assert self.priors.shape[0] == P

@@ -86,7 +86,7 @@ class Detect(object):
         """detection.py:101-106: with use_fast_nms False (the reference's constructor default) the reference runs
         traditional_nms — per-class greedy NMS in Cython on the CPU (utils/cython_nms.pyx), outside the hot path (SURVEY 2:
         non-default in eval.py, a CPU round trip per class).  A plain `Yolact()(x)` must still work, so the engine runs
-        Fast NMS — what eval.py:871 selects through its default --fast_nms=True — and says so ONCE, loudly;
+        Fast NMS — what eval.py:871 selects through its default --fast_nms=True — and says so once per Detect object, loudly;
         YOLACT_AMD_STRICT_NMS=1 turns the warning into NotImplementedError for callers that must not differ."""
         if self.use_fast_nms:
             return
@@ -94,7 +94,8 @@ class Detect(object):
                'hot path; running Fast NMS instead (eval.py:871 sets use_fast_nms = True for its default --fast_nms).')
         if os.environ.get('YOLACT_AMD_STRICT_NMS', '0') == '1':
             raise NotImplementedError(msg)
-        if not Detect._warned_traditional:
+        if not getattr(self, '_warned_traditional_nms', False):    # once per Detect INSTANCE (round-3 advisor: a process-wide
+            self._warned_traditional_nms = True                    # flag hid the deviation for every model after the first)
             Detect._warned_traditional = True
             warnings.warn(msg, UserWarning, stacklevel=3)
 

@@ -45,6 +45,9 @@ def _lowres_masks(det_output, w, h, batch_idx, interpolation_mode, visualize_lin
     if act_name(cfg.mask_proto_mask_activation) != 'sigmoid':
         raise NotImplementedError('mask activation other than sigmoid')
     proto = dets['proto']
+    if proto is None:
+        raise RuntimeError('postprocess: this detection was gathered from another rank (Yolact.forward_sharded) and carries no '
+                           'prototypes; masks are assembled on the rank that computed the image')
     L.require_cuda(proto, "dets['proto']")
     dev = proto.device
     ph, pw, D = proto.shape

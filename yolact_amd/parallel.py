@@ -136,6 +136,22 @@ def sharded_forward(forward_device, x_global: torch.Tensor, D: int, gatherer: Op
     return allrec, out
 
 
+def assemble_sharded(rec: torch.Tensor, mine, lo: int, hi: int, D: int, net=None):
+    """dst side of Yolact.forward_sharded: the gathered records [B, L] -> the list the reference's Detect returns for the global
+    batch ({'detection': {...} | None, 'net': net} per image).  `rec` is first DETACHED from the gatherer's persistent receive
+    buffer (clone; 15 KB per image): unpack_records slices without copying, and the next step overwrites that buffer in place
+    while callers may still hold — or asynchronously postprocess — this step's results.  `proto` is this rank's own prototype
+    tensor for images lo .. hi-1 and None for detections computed elsewhere (masks are assembled where the prototypes live,
+    SURVEY 8(e); postprocess() refuses a None with a clear error)."""
+    rec = rec.clone()
+    out = []
+    for b, det in enumerate(unpack_records(rec, D)):
+        if det is not None:
+            det['proto'] = mine['proto'][b - lo] if (mine is not None and lo <= b < hi) else None
+        out.append({'detection': det, 'net': net})
+    return out
+
+
 def _cap_of(forward_device):
     net = getattr(forward_device, '__self__', None)
     det = getattr(net, 'detect', None)

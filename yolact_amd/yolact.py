@@ -169,7 +169,8 @@ class Yolact(nn.Module):
 
     def forward(self, x):
         """x: float32 [B,3,H,W], normalised RGB (resnet_transform, data/config.py:181-186)."""
-        self.detect._require_fast_nms()      # traditional NMS (the reference's Detect default) is not on the hot path: raise
+        self.detect._require_fast_nms()      # traditional NMS (the reference's Detect default) is not on the hot path: Fast NMS runs
+                                             # instead with one UserWarning per Detect object (YOLACT_AMD_STRICT_NMS=1: raise)
         L.require_cuda(x, 'input batch')
         if x.dim() != 4 or x.shape[1] != 3:
             raise ValueError('expected [B,3,H,W], got %s' % (tuple(x.shape),))
@@ -279,8 +280,10 @@ class Yolact(nn.Module):
         rank computes its contiguous share of the images (parallel.shard_range), then ONE gather of the fixed-size detection
         records brings every image's detections to `dst` (eval.py:630-634,661 is batch splitting with a no-op gather; there is
         no collective inside the network).  Returns, on dst, the list the reference's Detect would return for the global
-        batch — {'detection': {...}|None, 'net': self} per image, `proto` present for the images this rank computed itself —
-        and None on the other ranks."""
+        batch — {'detection': {...}|None, 'net': self} per image; `proto` is the prototype tensor for the images this rank
+        computed itself and None for detections gathered from other ranks (assemble those masks on their own rank: every
+        rank can run postprocess_batch on its forward_device output) — and None on the other ranks.  The returned tensors
+        are fresh copies: they stay valid across later calls."""
         from . import parallel
         L.require_cuda(x_global, 'input batch')
         if not hasattr(self, '_gatherer') or self._gatherer.dst != dst:
@@ -292,12 +295,7 @@ class Yolact(nn.Module):
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         rank = dist.get_rank() if world > 1 else 0
         lo, hi = parallel.shard_range(int(x_global.shape[0]), rank, world)
-        out = []
-        for b, det in enumerate(parallel.unpack_records(rec, self.mask_dim)):
-            if det is not None and mine is not None and lo <= b < hi:
-                det['proto'] = mine['proto'][b - lo]
-            out.append({'detection': det, 'net': self})
-        return out
+        return parallel.assemble_sharded(rec, mine, lo, hi, self.mask_dim, self)
 
     def forward_raw(self, x):
         """Head outputs before Detect (for parity tests): loc, conf (logits), mask, priors, proto — clones."""
