@@ -65,7 +65,7 @@ typedef struct {
   int32_t nseg;         /* 1..3 */
   int32_t tile;         /* 0 = auto; else YMI_TILE_* override (tests / tuning) */
   int32_t cin_alg;      /* real (un-padded) input channels for FLOP accounting; 0 = Cin */
-  int32_t split_k;      /* 0 / 1: off.  S > 1: 1x1 convolutions only — the K = Cin reduction is cut into S ranges computed by S
+  int32_t split_k;      /* 0 / 1: off.  S > 1: 1x1 convolutions (and the pipelined DCN tiles, YMI_TILE_DCNP) only — the K = Cin reduction is cut into S ranges computed by S
                          * times as many blocks (small maps, long K: too few output tiles to fill 256 CUs otherwise); the
                          * partial sums go through `split_ws` and are added in a fixed order (deterministic) by a second
                          * launch that applies scale / bias / residual / activation.  Needs (Kpad / 32) % S == 0, one dense
@@ -134,7 +134,11 @@ enum { YMI_TILE_AUTO = 0, YMI_TILE_128x128 = 1, YMI_TILE_128x64 = 2, YMI_TILE_64
 enum { YMI_DCNP_64x128 = 1, YMI_DCNP_64x128_W8 = 2, YMI_DCNP_64x64 = 3, YMI_DCNP_128x128_W8 = 4, YMI_DCNP_128x64_W8 = 5,
        YMI_DCNP_32x128 = 6,
        /* 6 / 8 / 10 / 12 waves of 32 x 64, corner loads two chunks ahead (one register slot): one block per CU, rows sized to M / 256 */
-       YMI_DCNP_96x128_W6 = 7, YMI_DCNP_128x128_W8_R1 = 8, YMI_DCNP_160x128_W10 = 9, YMI_DCNP_192x128_W12 = 10 };
+       YMI_DCNP_96x128_W6 = 7, YMI_DCNP_128x128_W8_R1 = 8, YMI_DCNP_160x128_W10 = 9, YMI_DCNP_192x128_W12 = 10,
+       /* 256 output channels per block (every sample gathered once for all of them): the Cout >= 256 layers, normally with
+        * ymi_conv_desc.split_k = S (chunk-aligned K ranges, partial sums through split_ws, deterministic second pass) because their
+        * maps are small */
+       YMI_DCNP_64x256_W8 = 11, YMI_DCNP_96x256_W12 = 12, YMI_DCNP_128x256_W16 = 13 };
 
 int ymi_abi_version(void);
 const char *ymi_strerror(int code);

@@ -240,6 +240,23 @@ def test_dcn_pipelined_matches_oracle(case, tile):
     assert abs(run_conv.last_amax[1] - ref.abs().max().item()) <= 2e-5 * ref.abs().max().item()     # the bound it reports for y
 
 
+@pytest.mark.parametrize('tile', [L.DCNP_64x128_W8, L.DCNP_96x128_W6, 11, 12, 13])
+@pytest.mark.parametrize('split', [2, 3, 4, 9])
+def test_dcn_pipelined_split_k(tile, split):
+    """ymi_conv_desc.split_k on the pipelined DCN tiles: chunk-aligned K ranges (4 ranges of 9 chunks start INSIDE a tap when a tap is
+    4 chunks), partial sums through split_ws, deterministic second pass with scale / bias / ReLU and the magnitude bound."""
+    from gpu_utils import run_conv, rel_err
+    from oracle.yolact_oracle import dcn_v2_forward
+    x, w, b, om = _dcn_inputs(61 + split, 2, 128, 13, 11, 260, 1)
+    om[:, :18] *= 2.0
+    y = run_conv(x, w, b, None, 1, 1, dcn_offmask=om, tile=tile | L.TILE_H2 | L.TILE_DCNP, act=L.ACT_RELU, split_k=split)
+    ref = torch.relu(dcn_v2_forward(x, om[:, :18], torch.sigmoid(om[:, 18:]), w, b, 1, 1, 1))
+    assert rel_err(y, ref) < 2e-5
+    assert abs(run_conv.last_amax[1] - ref.abs().max().item()) <= 2e-5 * ref.abs().max().item()
+    y2 = run_conv(x, w, b, None, 1, 1, dcn_offmask=om, tile=tile | L.TILE_H2 | L.TILE_DCNP, act=L.ACT_RELU, split_k=split)
+    assert torch.equal(y, y2)                                               # fixed summation order: bit-reproducible
+
+
 def test_dcn_pipelined_rejects_what_it_cannot_run():
     """An explicit YMI_TILE_DCNP request outside the kernel's envelope is an error code, never a silent other kernel."""
     from gpu_utils import run_conv
@@ -250,7 +267,7 @@ def test_dcn_pipelined_rejects_what_it_cannot_run():
     with pytest.raises(RuntimeError):                                     # no fp16x2 flag
         run_conv(x, w, b, None, 1, 1, dcn_offmask=om, tile=L.TILE_DCNP | L.DCNP_64x128)
     with pytest.raises(RuntimeError):                                     # unknown block tile
-        run_conv(x, w, b, None, 1, 1, dcn_offmask=om, tile=L.TILE_H2 | L.TILE_DCNP | 9)
+        run_conv(x, w, b, None, 1, 1, dcn_offmask=om, tile=L.TILE_H2 | L.TILE_DCNP | 31)
 
 
 def test_dcn_v2_module_reference_kat_through_the_shim():

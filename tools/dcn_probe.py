@@ -49,9 +49,9 @@ def main():
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     old = [t for t in L.BASIC_TILES if t != L.TILE_128x32]
     old = old + [t | L.TILE_H2 for t in old]
-    new = [t | L.TILE_H2 | L.TILE_DCNP for t in sorted(L.DCNP_TILES)]
+    def tname(v):
+        return L.TILE_NAMES[v & 255] + ('/k%d' % (v >> 8) if v >> 8 else '')
     if args.tiles:
-        new = [t for t in new if L.TILE_NAMES[t] in args.tiles.split(',')]
         old = [L.TILE_64x64 | L.TILE_H2]
     abls = [int(a) for a in args.ablate.split(',')] if args.ablate else []
     tot_old = tot_new = tot_fl = 0.0
@@ -61,20 +61,22 @@ def main():
         dd = dptr.contents
         d = dd.conv
         fl = lib.ymi_conv_flops(C.byref(d))
-        tile0 = d.tile
+        tile0 = d.tile + 256 * max(d.split_k, 0) * (1 if d.split_k > 1 else 0)
         M = d.B * d.Ho * d.Wo
         y = torch.empty(M * d.Cout, device=dev)
         yptr0 = d.seg[0].ptr
         d.seg[0].ptr = y.data_ptr()
         times, ref, dev_max = {}, None, {}
+        new = plan.dcnp_candidates(d)
+        if args.tiles:
+            new = [t for t in new if tname(t) in args.tiles.split(',')]
         for t in old + new:
-            d.tile = t
-            if fn(dptr, s) != 0:
+            if plan._apply_choice(fn, dptr, where, t, s) != 0:
                 continue
             torch.cuda.synchronize()
             if t == (L.TILE_64x64 | L.TILE_H2):
                 ref = y.clone()
-            elif t & L.TILE_DCNP and ref is not None:
+            elif (t & 255) & L.TILE_DCNP and ref is not None:
                 dev_max[t] = ((y - ref).abs().max() / ref.abs().max()).item()
             best = 1e30
             for _ in range(2):
@@ -85,7 +87,7 @@ def main():
                 e1.synchronize()
                 best = min(best, e0.elapsed_time(e1) / args.reps)
             times[t] = best
-            if t & L.TILE_DCNP and abls:
+            if (t & 255) & L.TILE_DCNP and abls:
                 row = []
                 for a in abls:
                     os.environ['YMI_DCN_ABLATE'] = str(a)
@@ -97,16 +99,18 @@ def main():
                     e1.synchronize()
                     row.append('abl=%d %.4f' % (a, e0.elapsed_time(e1) / args.reps))
                 os.environ['YMI_DCN_ABLATE'] = '0'
-                print('    %-14s %s full %.4f | %s' % (L.TILE_NAMES[t], name, best, '  '.join(row)))
-        d.tile, d.seg[0].ptr = tile0, yptr0
+                print('    %-14s %s full %.4f | %s' % (tname(t), name, best, '  '.join(row)))
+        d.seg[0].ptr = yptr0
+        plan._apply_choice(fn, dptr, where, tile0, s)
         bo = min((times[t], t) for t in old if t in times)
         bn = min((times[t], t) for t in new if t in times) if any(t in times for t in new) else (float('nan'), 0)
         tot_old += bo[0]; tot_new += bn[0]; tot_fl += fl
         print('%-16s B%d %dx%d s%d %d>%d  %.2f GFLOP  | old best %-10s %.4f ms %6.1f TF/s | pipelined best %-14s %.4f ms %6.1f TF/s' % (
-            name, d.B, d.H, d.W, d.stride, d.Cin, d.Cout, fl / 1e9, L.TILE_NAMES[bo[1]], bo[0], fl / bo[0] / 1e9,
-            L.TILE_NAMES.get(bn[1], '-'), bn[0], fl / bn[0] / 1e9))
-        print('    ' + '  '.join('%s %.4f' % (L.TILE_NAMES[t], times[t]) for t in old + new if t in times))
-        print('    max |pipelined - old fp16x2| / max|y|: ' + '  '.join('%s %.1e' % (L.TILE_NAMES[t], v) for t, v in dev_max.items()))
+            name, d.B, d.H, d.W, d.stride, d.Cin, d.Cout, fl / 1e9, tname(bo[1]), bo[0], fl / bo[0] / 1e9,
+            tname(bn[1]) if bn[1] else '-', bn[0], fl / bn[0] / 1e9))
+        print('    ' + '  '.join('%s %.4f' % (tname(t), times[t]) for t in old + new if t in times))
+        print('    max |pipelined - old fp16x2| / max|y|: %.1e .. %.1e over %d pipelined candidates' % (
+            min(dev_max.values()), max(dev_max.values()), len(dev_max)))
     print('TOTAL %d DCN layers: old %.3f ms (%.1f TF/s), pipelined %.3f ms (%.1f TF/s)' % (
         sum(1 for op in plan.ops if op[0] is lib.ymi_dcn_v2_forward_f32), tot_old, tot_fl / tot_old / 1e9, tot_new, tot_fl / tot_new / 1e9))
 

@@ -87,8 +87,8 @@ PY
       find $O -name "*counter_collection.csv" -size +4M -delete ;;
     dcnabl) # diagnostics build of csrc/dcn.hip only (YMI_DCN_ABLATE switches), then the ablation table of tools/dcn_probe.py
       (cd yolact_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-value -I../../include -DYMI_DIAGNOSTICS=1 -c dcn.hip -o /tmp/dcn_diag.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls *.o | grep -v '^dcn.o$') /tmp/dcn_diag.o -o ../libyolact_amd.so) > $O/dcnabl_build.log 2>&1; tail -2 $O/dcnabl_build.log
-      timeout 600 python tools/dcn_probe.py --tiles ${arg:-dcnp64x128w8,dcnp64x128,dcnp128x128w8} --layers layer1.1,layer2.1,layer3.1 --ablate 1,2,3,4,8,16,32,7,15 > $O/dcn_ablation.txt 2>&1; grep -E "abl=" $O/dcn_ablation.txt | cut -c1-300 ;;
-    upsample) for v in band rows rowsnt; do YOLACT_AMD_UPSAMPLE=$v timeout 120 python tools/upsample_probe.py; YOLACT_AMD_UPSAMPLE=$v timeout 120 python tools/upsample_probe.py --size 337 --width 401 --batch 2 --cap 37; done > $O/upsample_probe.txt 2>&1; cat $O/upsample_probe.txt | cut -c1-220 ;;
+      timeout 600 python tools/dcn_probe.py --tiles ${arg:-dcnp64x128w8,dcnp64x128,dcnp128x128w8} --layers layer1.1,layer2.1,layer3.1 --ablate 1,2,3,4,8,12,16,32,64,7,15 > $O/dcn_ablation.txt 2>&1; grep -E "abl=" $O/dcn_ablation.txt | cut -c1-300 ;;
+    upsample) for v in band rows rowsnt; do YOLACT_AMD_UPSAMPLE=$v timeout 120 python tools/upsample_probe.py; YOLACT_AMD_UPSAMPLE=$v timeout 120 python tools/upsample_probe.py --size 337 --width 401 --batch 2 --cap 37; YOLACT_AMD_UPSAMPLE=$v timeout 120 python tools/upsample_probe.py --batch 1; done > $O/upsample_probe.txt 2>&1; cat $O/upsample_probe.txt | cut -c1-220 ;;
     dcnref) timeout 600 python -m pytest tests/test_gpu_dcn_reference.py -m gpu -q -rA -s > $O/dcnref.log 2>&1; tail -5 $O/dcnref.log ;;
     evalpy) timeout 1500 bash tools/run_reference_eval.sh $O > $O/evalpy.log 2>&1; tail -30 $O/evalpy.log ;;
     py) n=$(basename ${arg%% *} .py); k=0; while [ -e $O/$n$k.log ]; do k=$((k+1)); done

@@ -54,6 +54,15 @@ def main():
         e1.synchronize()
         best = min(best, e0.elapsed_time(e1) / args.reps)
     nbytes = out.numel() * 4
+    fill = 1e30
+    for _ in range(3):                      # reference point: torch's fill kernel over the same bytes (a pure write stream)
+        e0.record()
+        for _ in range(args.reps):
+            out.zero_()
+        e1.record()
+        e1.synchronize()
+        fill = min(fill, e0.elapsed_time(e1) / args.reps)
+    print('   (torch zero_ of the same %d MB: %.4f ms  %.2f TB/s)' % (nbytes // 10 ** 6, fill, nbytes / fill / 1e9))
     print('variant %-7s %d masks %dx%d -> %dx%d: %.4f ms  %.2f TB/s  digest(binarised) %s  digest(soft) %s' % (
         os.environ.get('YOLACT_AMD_UPSAMPLE', 'rows'), args.batch * args.cap, args.proto, args.proto, h, w, best,
         nbytes / best / 1e9, digs[0], digs[1]))

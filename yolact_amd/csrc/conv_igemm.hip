@@ -1440,6 +1440,20 @@ int ymi_internal_grouped_gemm(const ymi_conv_desc *d, int groups, long x_gs, lon
 
 int ymi_internal_dcn_h2(const ymi_dcn_desc *dd, int base_tile, hipStream_t s);   // csrc/dcn.hip (C++ linkage: internal)
 
+int ymi_internal_pipe_conv(const ymi_conv_desc *d, int base_tile, hipStream_t s); // csrc/dcn.hip: the same pipeline, ordinary convolution
+
+// internal (csrc/dcn.hip): the second pass of a split-K launch for a dense [M, Cout] output (Cout % 4 == 0, 16-byte aligned rows)
+int ymi_internal_splitk_fixup(const float *part, long gstride, int S, long M, int Cout, int ldy, float *y, const float *scale,
+                              const float *bias, const float *res, int res_ld, int act, int res_after_act, float *y_amax,
+                              hipStream_t s) {
+  const long total = M * (Cout / 4);
+  long gsz = (total + 255) / 256;
+  const long cap = 256L * 32;
+  hipLaunchKernelGGL(splitk_fixup_k, dim3((unsigned)(gsz > cap ? cap : gsz)), dim3(256), 0, s, part, gstride, S, M, Cout / 4, ldy, y,
+                     scale, bias, res, res_ld, act, res_after_act, y_amax);
+  return ymi_launch_status();
+}
+
 extern "C" {
 
 double ymi_conv_flops(const ymi_conv_desc *d) {
@@ -1451,6 +1465,12 @@ int ymi_conv_pick_tile(const ymi_conv_desc *d) { return d ? pick_tile(d) : YMI_E
 
 int ymi_conv2d_nhwc_f32(const ymi_conv_desc *d, void *stream) {
   if (!d) return YMI_ENULL;
+  if (d->tile & YMI_TILE_DCNP) {             // the pipelined kernel of csrc/dcn.hip as an ordinary convolution (fp16x2 only)
+    if (!(d->tile & YMI_TILE_H2) || (d->tile & YMI_TILE_X3)) return YMI_EARG;
+    const int rc = validate(d, 0);
+    if (rc) return rc;
+    return ymi_internal_pipe_conv(d, d->tile & 31, (hipStream_t)stream);
+  }
   if (d->split_k > 1) return run_splitk(d, (hipStream_t)stream);
   return run_conv(d, d->Cin == 4 ? 1 : 0, nullptr, 0, (hipStream_t)stream);
 }

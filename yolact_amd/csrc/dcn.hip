@@ -48,10 +48,14 @@ struct DcnParams {
   const void *w_h2;
   float *y, *y_amax;
   int B, H, W, Cin, ldx, Ho, Wo, Cout, stride, Kpad, ldo, ldy, act, mask_is_prob;
+  int taps, kw, pad;             // PLAIN (an ordinary convolution): kh * kw (9 or 1), kw, padding; the DCN path is 9 / 3 / 1
+  const float *res; int res_ld, res_after_act;   // PLAIN: optional residual [M, res_ld] added before (or after) the activation
   int M, HoWo, tiles_n, nk;
+  int nk_split;  // chunks per K range (gridDim.y ranges; == nk without split-K); range y writes raw partial sums to y + y * y_gs
+  long y_gs;
   unsigned x_bytes, om_bytes, w_plane;
   int abl;      // diagnostics build only (env YMI_DCN_ABLATE): bit0 corner loads -> OOB (no memory access), bit1 filter DMAs -> OOB,
-                // bit2 no combine / LDS store, bit3 no MFMAs, bit4 no barrier, bit5 no vmcnt wait — wrong results by design
+                // bit2 no combine / LDS store, bit3 no MFMAs, bit4 no barrier, bit5 no vmcnt wait — wrong results by design; bit6 no residency cap
 };
 
 template <int WM, int WN, int TM, int TN, int RING>
@@ -71,7 +75,11 @@ constexpr int dcn_occupancy() {     // blocks per CU: LDS-limited, and capped by
 
 // RING: corner loads run RING + 1 chunks ahead of the MFMAs in a ring of RING register slots (RING + 2 filter stages).  2 for the
 // small tiles (a step is shorter than a load round trip); 1 for the 96 .. 192-row tiles, whose step is >= 1000 TA cycles.
-template <int WM, int WN, int TM, int TN, int RING>
+// PLAIN: the same pipeline as an ORDINARY convolution (3x3 / pad 1 or 1x1 / pad 0, any stride, Cin % 32 == 0): one load per sample
+// instead of four corners, integer tap geometry, optional residual — ymi_conv2d_nhwc_f32 with a YMI_TILE_DCNP tile.  What it has
+// that the LDS-DMA tiles of conv_igemm.hip do not: the A operand is split into its fp16 planes ONCE by the loading thread (the
+// consuming waves run a split-free MFMA loop), 6 .. 16-wave blocks of 32 x 64 wave tiles, 256-column tiles.
+template <int WM, int WN, int TM, int TN, int RING, bool PLAIN>
 __global__ __launch_bounds__(64 * WM * WN, (dcn_occupancy<WM, WN, TM, TN, RING>() * (WM * WN) + 3) / 4)
 void dcn_h2_k(const DcnParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // (host pass: empty body, see conv_igemm.hip)
@@ -85,7 +93,8 @@ void dcn_h2_k(const DcnParams p) {
   static_assert(RING == 1 || RING == 2, "ring depth");
   constexpr int NSB = RING + 2;                         // filter stages: chunk st (multiplied), st+1 .. st+RING (landed / in flight), st+RING+1 (requested)
   constexpr int A_STAGE = 2 * BM * 16, B_STAGE = 2 * BN * 16;    // floats: two fp16 planes of 64-byte rows
-  constexpr int NG = 4 * RA, NB = RB;                   // VMEM operations of one chunk: corner loads, filter DMAs
+  constexpr int NC = PLAIN ? 1 : 4;                     // loads per sample: the four bilinear corners, or the pixel itself
+  constexpr int NG = NC * RA, NB = RB;                  // VMEM operations of one chunk: corner loads, filter DMAs
   constexpr int N_STEADY = RING * (NG + NB);            // operations issued behind the filter DMA of chunk st+1 at the end of step st
   static_assert(N_STEADY <= 63, "vmcnt is a 6-bit counter");
   constexpr int ELD = BN + 4;
@@ -125,8 +134,8 @@ void dcn_h2_k(const DcnParams p) {
     if (m < p.M) {
       const int b = m / p.HoWo, pix = m - b * p.HoWo;
       const int oy = pix / p.Wo, ox = pix - oy * p.Wo;
-      g_iy0[i] = oy * p.stride - 1;
-      g_ix0[i] = ox * p.stride - 1;
+      g_iy0[i] = oy * p.stride - (PLAIN ? p.pad : 1);
+      g_ix0[i] = ox * p.stride - (PLAIN ? p.pad : 1);
       g_ib[i] = b * p.H * p.W;
       g_om[i] = (unsigned)m * (unsigned)p.ldo * 4u;
     } else {
@@ -152,6 +161,7 @@ void dcn_h2_k(const DcnParams p) {
   float gwt[RA][5];
   float raw[RA][3];                                     // dh, dw, mask logit of the next tap to resolve (fetched one tap ahead)
   auto raw_fetch = [&](int tap) {
+    if constexpr (PLAIN) return;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
       const unsigned o = g_om[i] != OOB ? g_om[i] + 8u * tap : OOB;
@@ -160,7 +170,19 @@ void dcn_h2_k(const DcnParams p) {
       raw[i][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ors, o, 4 * 18 - 4 * tap, 0));
     }
   };
+  const int ntaps = PLAIN ? p.taps : 9;
   auto geom = [&](int tap) {
+    if constexpr (PLAIN) {       // an ordinary convolution: the tap's pixel, or nothing where it falls into the padding
+      const int ky = tap / p.kw, kx = tap - p.kw * ky;
+      const bool live = tap < ntaps;
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        const int h = g_iy0[i] + ky, w = g_ix0[i] + kx;
+        const bool in = live && g_om[i] != OOB && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+        gq[i][0] = in ? (unsigned)(((g_ib[i] + h * p.W + w) * p.ldx + 4 * kq) * 4) : OOB;
+      }
+      return;
+    }
     const int ky = tap / 3, kx = tap - 3 * ky;
     const bool live = tap < 9;
 #pragma unroll
@@ -189,32 +211,46 @@ void dcn_h2_k(const DcnParams p) {
   };
 
   // ---- the register ring of the gather: two chunks in flight ---------------------------------------------------------------
-  f32x4 ring[RING][RA][4];
+  f32x4 ring[RING][RA][NC];
   float ringw[RING][RA][5];
-  int g_tap = 0, g_c = 0;                               // (tap, first channel) of the next chunk to request
+  // K range of this block (split-K: gridDim.y ranges of nk_split chunks; chunk-aligned, not necessarily tap-aligned)
+  const int kc0 = blockIdx.y * p.nk_split;
+  const int cpt = p.Cin / BK;                           // chunks per tap
+  int g_tap = kc0 / cpt, g_c = (kc0 - g_tap * cpt) * BK;   // (tap, first channel) of the next chunk to request
+  int g_left = p.nk_split;                              // chunks of the range still to request
+  bool g_first = true;
   auto tap_step = [&]() {                               // start of a chunk's requests: resolve the geometry at a tap boundary
-    if (g_c == 0) {
-      geom(g_tap);
-      if (g_tap + 1 < 9) raw_fetch(g_tap + 1);
+    if (g_c == 0 || g_first) {                          // (or at the start of a range that begins inside a tap)
+      g_first = false;
+      geom(g_left > 0 ? g_tap : ntaps);
+      if (g_tap + 1 < ntaps) raw_fetch(g_tap + 1);
     }
   };
   auto gather_row = [&](auto slot_c, int i) {           // the four corner loads of row i of the chunk at (g_tap, g_c)
     constexpr int S = decltype(slot_c)::value;
     const int so = g_c * 4;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < NC; ++c) {
 #ifdef YMI_DIAGNOSTICS
       ring[S][i][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (p.abl & 1) ? OOB : gq[i][c], so, 0));
 #else
       ring[S][i][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, gq[i][c], so, 0));
 #endif
     }
+    if constexpr (!PLAIN) {
 #pragma unroll
-    for (int e = 0; e < 5; ++e) ringw[S][i][e] = gwt[i][e];
+      for (int e = 0; e < 5; ++e) ringw[S][i][e] = gwt[i][e];
+    }
   };
   auto chunk_advance = [&]() {
     g_c += BK;
     if (g_c == p.Cin) { g_c = 0; ++g_tap; }
+    if (--g_left == 0) {                                // past the end of the range: every further request is an out-of-bounds load
+#pragma unroll
+      for (int i = 0; i < RA; ++i)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) gq[i][c] = OOB;
+    }
   };
   // sample -> two fp16 planes -> LDS (row i of the chunk held in ring slot S)
   auto combine_row = [&](auto slot_c, int i, float *As) {
@@ -223,13 +259,17 @@ void dcn_h2_k(const DcnParams p) {
     if (p.abl & 4) return;
 #endif
     f32x4 v;
+    if constexpr (PLAIN) {
+      v = ring[S][i][0] * sA;
+    } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float a = ringw[S][i][0] * ring[S][i][0][e];
-      a = __builtin_fmaf(ringw[S][i][1], ring[S][i][1][e], a);
-      a = __builtin_fmaf(ringw[S][i][2], ring[S][i][2][e], a);
-      a = __builtin_fmaf(ringw[S][i][3], ring[S][i][3][e], a);
-      v[e] = (a * ringw[S][i][4]) * sA;
+      for (int e = 0; e < 4; ++e) {
+        float a = ringw[S][i][0] * ring[S][i][0][e];
+        a = __builtin_fmaf(ringw[S][i][1], ring[S][i][1][e], a);
+        a = __builtin_fmaf(ringw[S][i][2], ring[S][i][2][e], a);
+        a = __builtin_fmaf(ringw[S][i][3], ring[S][i][3][e], a);
+        v[e] = (a * ringw[S][i][4]) * sA;
+      }
     }
     f16x4 h4, l4;
 #pragma unroll
@@ -247,7 +287,7 @@ void dcn_h2_k(const DcnParams p) {
 #ifdef YMI_DIAGNOSTICS
     if (p.abl & 2) { __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(Bbase + stage * B_STAGE + b_lds[i]), 16, OOB, 0, 0, 0); return; }
 #endif
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(Bbase + stage * B_STAGE + b_lds[i]), 16, b_off[i], kc * (BK * 2), 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(Bbase + stage * B_STAGE + b_lds[i]), 16, b_off[i], (kc0 + kc) * (BK * 2), 0, 0);
   };
 
   f32x16 acc[TM][TN];
@@ -335,7 +375,7 @@ void dcn_h2_k(const DcnParams p) {
   };
 
   // ---- prologue: chunks 0 .. RING requested, chunk 0 combined ---------------------------------------------------------------
-  raw_fetch(0);
+  raw_fetch(g_tap);
   tap_step();
 #pragma unroll
   for (int i = 0; i < RA; ++i) gather_row(std::integral_constant<int, 0>{}, i);
@@ -364,7 +404,7 @@ void dcn_h2_k(const DcnParams p) {
   // ---- main loop: RING steps per trip (the ring slot is a compile-time index) -----------------------------------------------
   // (RING == 2: both steps unconditionally inside the trip: with `if (st + 1 < nk)` around the second one the CFG has a path from
   // the first step straight back to itself, and the compiler's vmcnt for the ring registers drops from ~16 to 3 — seen in the ISA)
-  const int nk = p.nk;
+  const int nk = p.nk_split;
   if constexpr (RING == 2) {
     int st = 0;
     for (; st + 1 < nk; st += 2) {
@@ -394,6 +434,19 @@ void dcn_h2_k(const DcnParams p) {
       for (int e = 0; e < 4; ++e) { sc[e] = p.scale_h2[n + e]; if (p.bias) bi[e] = p.bias[n + e]; }
     }
   }
+  // PLAIN: the residual rows of this thread (bottleneck shortcut), requested before the transposition as well
+  f32x4 rv[PLAIN ? RPT : 1];
+  const bool has_res = PLAIN && p.res != nullptr;
+  if constexpr (PLAIN) {
+    if (has_res && n < p.Cout) {
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) {
+        const int m = m0 + rbase + RSTEP * i;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        rv[i] = m < p.M ? *reinterpret_cast<const f32x4 *>(p.res + (size_t)m * p.res_ld + n) : z;
+      }
+    }
+  }
   float *es = lds;
   {
     const int ncol = lane & 31, half = lane >> 5;
@@ -414,12 +467,14 @@ void dcn_h2_k(const DcnParams p) {
   for (int i = 0; i < RPT; ++i) {
     f32x4 v = *reinterpret_cast<const f32x4 *>(es + (rbase + RSTEP * i) * ELD + 4 * c4);
     v = v * sc + bi;
+    if constexpr (PLAIN) { if (has_res && !p.res_after_act) v += rv[i]; }
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], slope * v[e]);
+    if constexpr (PLAIN) { if (has_res && p.res_after_act) v += rv[i]; }
     o[i] = v;
   }
   if (n < p.Cout) {
-    float *base = p.y + (size_t)(m0 + rbase) * p.ldy + n;
+    float *base = p.y + (size_t)blockIdx.y * p.y_gs + (size_t)(m0 + rbase) * p.ldy + n;
 #pragma unroll
     for (int i = 0; i < RPT; ++i)
       if (m0 + rbase + RSTEP * i < p.M) {
@@ -431,63 +486,136 @@ void dcn_h2_k(const DcnParams p) {
 #endif
 }
 
-template <int WM, int WN, int TM, int TN, int RING = 2>
-int launch_dcn(DcnParams p, hipStream_t s) {
+template <int WM, int WN, int TM, int TN, int RING, bool PLAIN>
+int launch_dcn_k(DcnParams p, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   p.tiles_n = (p.Cout + BN - 1) / BN;
   const int grid = ((p.M + BM - 1) / BM) * p.tiles_n;
-  hipLaunchKernelGGL((dcn_h2_k<WM, WN, TM, TN, RING>), dim3(grid), dim3(64 * WM * WN), 0, s, p);
+  // The workgroup dispatcher does not balance a grid that fits in one residency round: it packs up to `occupancy` blocks on a CU
+  // while others hold none (csrc/conv_igemm.hip launch_cfg).  When the grid is at most occ * 256 blocks, cap the residency at
+  // k = ceil(grid / 256) blocks per CU by padding the block's LDS allocation with unused dynamic LDS.
+  int dyn = 0;
+  {
+    constexpr int LDS_PER_CU = 160 * 1024, static_lds = dcn_lds_floats<WM, WN, TM, TN, RING>() * 4;
+    const int occ = dcn_occupancy<WM, WN, TM, TN, RING>(), k = (grid * (p.nk / p.nk_split) + 255) / 256;
+#ifdef YMI_DIAGNOSTICS
+    const bool cap_on = !(p.abl & 64);
+#else
+    const bool cap_on = true;
+#endif
+    if (k < occ && cap_on) {
+      const int want = LDS_PER_CU / (k + 1) + 1024;
+      if (want > static_lds && want <= LDS_PER_CU / k) dyn = want - static_lds;
+    }
+  }
+  const int splits = p.nk / p.nk_split;
+  hipLaunchKernelGGL((dcn_h2_k<WM, WN, TM, TN, RING, PLAIN>), dim3(grid, splits), dim3(64 * WM * WN), dyn, s, p);
   return ymi_launch_status();
+}
+
+template <int WM, int WN, int TM, int TN, int RING = 2>
+int launch_dcn(const DcnParams &p, bool plain, hipStream_t s) {
+  return plain ? launch_dcn_k<WM, WN, TM, TN, RING, true>(p, s) : launch_dcn_k<WM, WN, TM, TN, RING, false>(p, s);
 }
 
 }  // namespace
 
-// internal (not part of the C ABI; called by ymi_dcn_v2_forward_f32 in csrc/conv_igemm.hip): the pipelined gather-GEMM for a
-// validated descriptor whose tile is YMI_TILE_H2 | YMI_TILE_DCNP | YMI_DCNP_* (base_tile = the YMI_DCNP_* part).  Returns YMI_EARG when the descriptor is outside what
-// the kernel takes (the caller then runs the general loader).
-int ymi_internal_dcn_h2(const ymi_dcn_desc *dd, int base_tile, hipStream_t s) {
-  const ymi_conv_desc *d = &dd->conv;
+// internal (csrc/conv_igemm.hip): second pass of a split-K launch — y = act(scale * sum_g part[g] + bias (+ res)), partials added in a
+// fixed order
+int ymi_internal_splitk_fixup(const float *part, long gstride, int S, long M, int Cout, int ldy, float *y, const float *scale,
+                              const float *bias, const float *res, int res_ld, int act, int res_after_act, float *y_amax,
+                              hipStream_t s);
+
+namespace {
+
+// Shared host side of the two entries below.  `offmask` != nullptr: DCNv2; nullptr: an ordinary convolution (PLAIN).
+// desc->split_k = S > 1 (with split_ws: S * M * Cout floats): the K reduction is cut into S chunk-aligned ranges computed by S times as
+// many blocks — the small maps (35x35, 18x18 at batch 8) have too few row tiles for 256 CUs once a tile covers 256 output channels
+// (every sample gathered once for all of them) — and a second launch adds the partial sums in a fixed order and applies scale / bias /
+// residual / activation (splitk_fixup_k of csrc/conv_igemm.hip: deterministic).
+int run_pipe(const ymi_conv_desc *d, const float *offmask, int ldo, int mask_is_prob, int base_tile, int prof_kind, hipStream_t s) {
+  const bool plain = offmask == nullptr;
   const ymi_conv_seg &g0 = d->seg[0];
   const long HoWo = (long)d->Ho * d->Wo, M = (long)d->B * HoWo;
-  if (d->kh != 3 || d->kw != 3 || d->pad != 1 || d->Cin % 32 != 0 || d->Kpad != 9 * d->Cin) return YMI_EARG;
+  if (plain) {
+    if (!((d->kh == 3 && d->kw == 3 && d->pad == 1) || (d->kh == 1 && d->kw == 1 && d->pad == 0))) return YMI_EARG;
+  } else if (d->kh != 3 || d->kw != 3 || d->pad != 1) return YMI_EARG;
+  if (d->Cin % 32 != 0 || d->Kpad != d->kh * d->kw * d->Cin) return YMI_EARG;
   if (d->nseg != 1 || g0.n0 != 0 || g0.n1 < d->Cout || (d->Cout & 3) || (g0.row_stride & 3) || (((uintptr_t)g0.ptr) & 15) ||
-      g0.batch_stride != HoWo * g0.row_stride || g0.act > YMI_ACT_LEAKY01 || g0.act < 0 || d->res_mode != YMI_RES_NONE)
+      g0.batch_stride != HoWo * g0.row_stride || g0.act > YMI_ACT_LEAKY01 || g0.act < 0)
     return YMI_EARG;
+  if (d->res_mode != YMI_RES_NONE && (!plain || d->res_mode != YMI_RES_ADD || (d->res_ld & 3) || (((uintptr_t)d->res) & 15))) return YMI_EARG;
   if (!d->w_h2 || !d->scale_h2 || !d->x_amax || (((uintptr_t)d->w_h2) & 15)) return YMI_ENULL;
-  if (M * (long)dd->ldo >= (1L << 29) || M * (long)g0.row_stride >= (1L << 31)) return YMI_ESHAPE;
+  if (M * (long)(plain ? 1 : ldo) >= (1L << 29) || M * (long)g0.row_stride >= (1L << 31)) return YMI_ESHAPE;
+  const int S = d->split_k > 1 ? d->split_k : 1;
+  const int nk = d->Kpad / BK;
+  if (nk < 4) return YMI_EARG;
+  if (S > 1) {
+    if (S > 16 || nk % S != 0 || nk / S < 4) return YMI_EARG;
+    if (!d->split_ws || !d->winv_h2) return YMI_ENULL;
+    if ((((uintptr_t)d->split_ws) & 15) || M * (long)d->Cout >= (1L << 29)) return YMI_ESHAPE;
+  }
   DcnParams p;
-  p.x = d->x; p.offmask = dd->offmask; p.scale_h2 = d->scale_h2; p.bias = d->bias; p.x_amax = d->x_amax;
+  p.x = d->x; p.offmask = offmask; p.scale_h2 = d->scale_h2; p.bias = d->bias; p.x_amax = d->x_amax;
   p.w_h2 = d->w_h2; p.y = g0.ptr; p.y_amax = d->y_amax;
   p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.ldx = d->ldx; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
-  p.stride = d->stride; p.Kpad = d->Kpad; p.ldo = dd->ldo; p.ldy = g0.row_stride; p.act = g0.act; p.mask_is_prob = dd->mask_is_prob;
-  p.M = (int)M; p.HoWo = (int)HoWo; p.tiles_n = 0; p.nk = d->Kpad / BK;
+  p.stride = d->stride; p.Kpad = d->Kpad; p.ldo = ldo; p.ldy = g0.row_stride; p.act = g0.act; p.mask_is_prob = mask_is_prob;
+  p.taps = d->kh * d->kw; p.kw = d->kw; p.pad = d->pad;
+  p.res = d->res_mode == YMI_RES_ADD ? d->res : nullptr; p.res_ld = d->res_ld; p.res_after_act = d->res_after_act;
+  p.M = (int)M; p.HoWo = (int)HoWo; p.tiles_n = 0; p.nk = nk; p.nk_split = nk / S; p.y_gs = 0;
   p.x_bytes = (unsigned)((size_t)d->B * d->H * d->W * d->ldx * sizeof(float));
-  p.om_bytes = (unsigned)((size_t)M * dd->ldo * sizeof(float));
+  p.om_bytes = plain ? 0u : (unsigned)((size_t)M * ldo * sizeof(float));
   p.w_plane = (unsigned)((((long)d->Cout + 127) / 128 * 128) * d->Kpad * 2L);
   p.abl = 0;
 #ifdef YMI_DIAGNOSTICS   // `make DIAG=1`: stall attribution for tools/dcn_probe.py — wrong results by design
   { const char *e = getenv("YMI_DCN_ABLATE"); p.abl = e ? atoi(e) : 0; }
 #endif
-  const int tile_id = base_tile | YMI_TILE_H2 | YMI_TILE_DCNP;
-  const double flops = 2.0 * (double)M * (double)(d->cout_alg > 0 ? d->cout_alg : d->Cout) * 9.0 * (double)(d->cin_alg > 0 ? d->cin_alg : d->Cin);
-  if (base_tile < YMI_DCNP_64x128 || base_tile > YMI_DCNP_192x128_W12) return YMI_EARG;
-  int rc;
-  const int pr = ymi_internal_prof_begin(flops, tile_id, 9, s);
-  switch (base_tile) {                                   // <waves along M, waves along N, 32x32 tiles per wave along M, along N>
-    case YMI_DCNP_64x128: rc = launch_dcn<2, 2, 1, 2>(p, s); break;
-    case YMI_DCNP_64x128_W8: rc = launch_dcn<2, 4, 1, 1>(p, s); break;
-    case YMI_DCNP_64x64: rc = launch_dcn<2, 2, 1, 1>(p, s); break;
-    case YMI_DCNP_128x128_W8: rc = launch_dcn<4, 2, 1, 2>(p, s); break;
-    case YMI_DCNP_128x64_W8: rc = launch_dcn<4, 2, 1, 1>(p, s); break;
-    case YMI_DCNP_32x128: rc = launch_dcn<1, 4, 1, 1>(p, s); break;
-    // one block per CU sized to M / 256 rows: the kernel is bound by the texture addresser (16 cycles per 1 KB wave load / DMA), so
-    // what counts is (i) every CU busy for the whole launch — no second residency round, no CUs with twice the blocks of others —
-    // and (ii) the filter DMAs (16 per chunk whatever the row count) amortised over more rows
-    case YMI_DCNP_96x128_W6: rc = launch_dcn<3, 2, 1, 2, 1>(p, s); break;
-    case YMI_DCNP_128x128_W8_R1: rc = launch_dcn<4, 2, 1, 2, 1>(p, s); break;
-    case YMI_DCNP_160x128_W10: rc = launch_dcn<5, 2, 1, 2, 1>(p, s); break;
-    default: rc = launch_dcn<6, 2, 1, 2, 1>(p, s); break;   // YMI_DCNP_192x128_W12
+  if (S > 1) {           // partial launches undo the operand scales only (true partial sums), the second pass does the rest
+    p.scale_h2 = d->winv_h2; p.bias = nullptr; p.act = YMI_ACT_NONE; p.y_amax = nullptr; p.res = nullptr;
+    p.y = d->split_ws; p.ldy = d->Cout; p.y_gs = M * (long)d->Cout;
   }
+  const int tile_id = base_tile | YMI_TILE_H2 | YMI_TILE_DCNP;
+  const double flops = 2.0 * (double)M * (double)(d->cout_alg > 0 ? d->cout_alg : d->Cout) * (double)(d->kh * d->kw) *
+                       (double)(d->cin_alg > 0 ? d->cin_alg : d->Cin);
+  if (base_tile < YMI_DCNP_64x128 || base_tile > YMI_DCNP_128x256_W16) return YMI_EARG;
+  int rc;
+  const int pr = ymi_internal_prof_begin(flops, tile_id, prof_kind, s);
+  switch (base_tile) {                                   // <waves along M, waves along N, 32x32 tiles per wave along M, along N, ring>
+    case YMI_DCNP_64x128: rc = launch_dcn<2, 2, 1, 2>(p, plain, s); break;
+    case YMI_DCNP_64x128_W8: rc = launch_dcn<2, 4, 1, 1>(p, plain, s); break;
+    case YMI_DCNP_64x64: rc = launch_dcn<2, 2, 1, 1>(p, plain, s); break;
+    case YMI_DCNP_128x128_W8: rc = launch_dcn<4, 2, 1, 2>(p, plain, s); break;
+    case YMI_DCNP_128x64_W8: rc = launch_dcn<4, 2, 1, 1>(p, plain, s); break;
+    case YMI_DCNP_32x128: rc = launch_dcn<1, 4, 1, 1>(p, plain, s); break;
+    // one block per CU sized to M / 256 rows: the kernel is bound by the vector-memory pipe (a 1 KB wave load or DMA occupies it for
+    // ~27 cycles whether it hits, misses or is out of bounds: profiles/r04_dcn_ablation.txt), so what counts is (i) every CU busy for
+    // the whole launch — no second residency round, no CUs with twice the blocks of others — (ii) the filter DMAs (16 per chunk per
+    // 128 columns whatever the row count) amortised over more rows, (iii) every sample gathered once for as many columns as possible
+    case YMI_DCNP_96x128_W6: rc = launch_dcn<3, 2, 1, 2, 1>(p, plain, s); break;
+    case YMI_DCNP_128x128_W8_R1: rc = launch_dcn<4, 2, 1, 2, 1>(p, plain, s); break;
+    case YMI_DCNP_160x128_W10: rc = launch_dcn<5, 2, 1, 2, 1>(p, plain, s); break;
+    case YMI_DCNP_192x128_W12: rc = launch_dcn<6, 2, 1, 2, 1>(p, plain, s); break;
+    case YMI_DCNP_64x256_W8: rc = launch_dcn<2, 4, 1, 2, 1>(p, plain, s); break;
+    case YMI_DCNP_96x256_W12: rc = launch_dcn<3, 4, 1, 2, 1>(p, plain, s); break;
+    default: rc = launch_dcn<4, 4, 1, 2, 1>(p, plain, s); break;   // YMI_DCNP_128x256_W16
+  }
+  if (rc == YMI_OK && S > 1)
+    rc = ymi_internal_splitk_fixup(d->split_ws, M * (long)d->Cout, S, M, d->Cout, g0.row_stride, g0.ptr, d->scale, d->bias,
+                                   d->res_mode == YMI_RES_ADD ? d->res : nullptr, d->res_ld, g0.act, d->res_after_act, d->y_amax, s);
   ymi_internal_prof_end(pr, s);
   return rc;
+}
+
+}  // namespace
+
+// internal (not part of the C ABI; called by ymi_dcn_v2_forward_f32 in csrc/conv_igemm.hip): the pipelined gather-GEMM for a
+// validated descriptor whose tile is YMI_TILE_H2 | YMI_TILE_DCNP | YMI_DCNP_* (base_tile = the YMI_DCNP_* part).  YMI_EARG when the
+// descriptor is outside what the kernel takes.  Profiling record kind 9.
+int ymi_internal_dcn_h2(const ymi_dcn_desc *dd, int base_tile, hipStream_t s) {
+  return run_pipe(&dd->conv, dd->offmask, dd->ldo, dd->mask_is_prob, base_tile, 9, s);
+}
+
+// internal (called by ymi_conv2d_nhwc_f32): the same pipeline as an ordinary 3x3 / pad 1 or 1x1 / pad 0 convolution.  Kind 10.
+int ymi_internal_pipe_conv(const ymi_conv_desc *d, int base_tile, hipStream_t s) {
+  return run_pipe(d, nullptr, 0, 0, base_tile, 10, s);
 }

@@ -941,6 +941,8 @@ class Plan:
             for fn, dptr, _n, w in self.ops:          # re-point descriptors that already use the old buffer
                 if fn is self.lib.ymi_conv2d_nhwc_f32 and w == where and dptr.contents.split_k > 1:
                     dptr.contents.split_ws = ws.data_ptr()
+                elif fn is self.lib.ymi_dcn_v2_forward_f32 and w == where and dptr.contents.conv.split_k > 1:
+                    dptr.contents.conv.split_ws = ws.data_ptr()
         return ws
 
     @staticmethod
@@ -956,13 +958,34 @@ class Plan:
         tile, S = int(val) & 255, int(val) >> 8
         d.tile = tile
         if S > 1:
-            if not self._splitk_ok(d) or (d.Kpad // 32) % S:
+            is_dcn = fn is self.lib.ymi_dcn_v2_forward_f32
+            if (not is_dcn and not self._splitk_ok(d)) or (is_dcn and not tile & L.TILE_DCNP) or (d.Kpad // 32) % S:
                 return -1
             d.split_k = S
             d.split_ws = self._splitk_ws(where, S * d.B * d.Ho * d.Wo * d.Cout).data_ptr()
         else:
             d.split_k = 0
         return fn(dptr, s)
+
+    @staticmethod
+    def dcnp_candidates(d):
+        """(tile + 256 * split_k) candidates of the pipelined DCN kernel for a descriptor: every block tile unsplit, and — where a
+        tile's grid alone leaves CUs idle (the 35x35 / 18x18 maps) — chunk-aligned K splits that bring the block count to 0.5 .. 2
+        blocks per CU."""
+        M, nk = d.B * d.Ho * d.Wo, d.Kpad // 32
+        out = []
+        for t, name in sorted(L.DCNP_TILES.items()):
+            bm, bn = (int(v) for v in name[4:].split('w')[0].split('x'))
+            if bn > 128 and d.Cout < 256:
+                continue
+            tid = t | L.TILE_H2 | L.TILE_DCNP
+            out.append(tid)
+            blocks = -(-M // bm) * -(-d.Cout // bn)
+            if blocks < 200 and d.Cout % 4 == 0:
+                for S in (2, 3, 4, 6, 8, 9, 12):
+                    if nk % S == 0 and nk // S >= 6 and 128 <= blocks * S <= 520:
+                        out.append(tid + 256 * S)
+        return out
 
     def _tune_direct(self, e0, e1, s, reps, disk, measure):
         cache = {}
@@ -1003,7 +1026,7 @@ class Plan:
                     cands = cands + [t | spflag for t in cands if t in base_ok
                                      and (d.Cin % 32 == 0 or t in L.BASIC_TILES)]
                 if is_dcn and self.h2:       # the pipelined gather-GEMM of csrc/dcn.hip (fp16x2 plans)
-                    cands = cands + [t | L.TILE_H2 | L.TILE_DCNP for t in sorted(L.DCNP_TILES)]
+                    cands = cands + self.dcnp_candidates(d)
                 if not is_dcn and self._splitk_ok(d) and self.splitk:
                     # split-K candidates: big tiles whose grid alone cannot fill the chip, K cut 2 / 4 ways
                     x3 = spflag
