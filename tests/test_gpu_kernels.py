@@ -257,6 +257,58 @@ def test_dcn_pipelined_split_k(tile, split):
     assert torch.equal(y, y2)                                               # fixed summation order: bit-reproducible
 
 
+@pytest.mark.parametrize('tile', DCNP_ALL)
+@pytest.mark.parametrize('case', [(2, 64, 19, 17, 72, 3, 1, False, L.ACT_RELU), (1, 128, 23, 21, 260, 3, 2, False, L.ACT_NONE),
+                                  (2, 256, 14, 15, 64, 1, 1, True, L.ACT_RELU), (3, 64, 9, 10, 128, 1, 2, False, L.ACT_LEAKY01),
+                                  (1, 32, 31, 29, 36, 3, 1, False, L.ACT_RELU), (2, 96, 12, 13, 512, 1, 1, True, L.ACT_LEAKY01)])
+def test_pipelined_kernel_as_ordinary_convolution(case, tile):
+    """ymi_conv2d_nhwc_f32 with a YMI_TILE_DCNP tile = the pipelined kernel of csrc/dcn.hip in PLAIN mode (one load per sample, integer
+    tap geometry): 3x3 / pad 1 and 1x1 / pad 0, stride 1 / 2, folded BN, bias, residual before or after the activation, ragged row
+    and column tiles, odd chunk counts — against torch fp32."""
+    from gpu_utils import run_conv, rel_err
+    B, Cin, H, W, Cout, k, stride, has_res, act = case
+    g = _g(300 + Cin + Cout + k)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    pad = 1 if k == 3 else 0
+    ref = F.conv2d(x, w, b, stride, pad)
+    res = torch.randn(ref.shape, generator=g) if has_res else None
+    after = 1 if act == L.ACT_LEAKY01 else 0
+    y = run_conv(x, w, b, None, stride, pad, act=act, res=res, res_mode=L.RES_ADD if has_res else L.RES_NONE, res_after_act=after, tile=tile)
+
+    def a_(t):
+        return torch.relu(t) if act == L.ACT_RELU else F.leaky_relu(t, 0.1) if act == L.ACT_LEAKY01 else t
+    if has_res:
+        ref = a_(ref) + res if after else a_(ref + res)
+    else:
+        ref = a_(ref)
+    assert rel_err(y, ref) < 2e-5
+    assert abs(run_conv.last_amax[1] - ref.abs().max().item()) <= 2e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize('tile', [L.DCNP_64x128_W8, L.DCNP_128x128_W8_R1, L.DCNP_96x256_W12, L.DCNP_128x256_W16, L.DCNP_32x128])
+@pytest.mark.parametrize('split', [2, 4, 8])
+def test_pipelined_ordinary_convolution_split_k(tile, split):
+    """K ranges on the PLAIN path (1x1, K = 512 -> 16 chunks; 3x3 with a residual): partial sums + the deterministic second pass."""
+    from gpu_utils import run_conv, rel_err
+    g = _g(400 + split)
+    x = torch.randn(2, 512, 9, 11, generator=g)
+    w = torch.randn(260, 512, 1, 1, generator=g) / 512 ** 0.5
+    b = torch.randn(260, generator=g) * 0.1
+    res = torch.randn(2, 260, 9, 11, generator=g)
+    t = tile | L.TILE_H2 | L.TILE_DCNP
+    y = run_conv(x, w, b, None, 1, 0, act=L.ACT_RELU, res=res, res_mode=L.RES_ADD, tile=t, split_k=split)
+    ref = torch.relu(F.conv2d(x, w, b) + res)
+    assert rel_err(y, ref) < 2e-5
+    assert torch.equal(y, run_conv(x, w, b, None, 1, 0, act=L.ACT_RELU, res=res, res_mode=L.RES_ADD, tile=t, split_k=split))
+    x3 = torch.randn(1, 64, 13, 12, generator=g)
+    w3 = torch.randn(68, 64, 3, 3, generator=g) / 24
+    if (9 * 64 // 32) % split == 0:
+        y3 = run_conv(x3, w3, None, None, 2, 1, tile=t, split_k=split)
+        assert rel_err(y3, F.conv2d(x3, w3, None, 2, 1)) < 2e-5
+
+
 def test_dcn_pipelined_rejects_what_it_cannot_run():
     """An explicit YMI_TILE_DCNP request outside the kernel's envelope is an error code, never a silent other kernel."""
     from gpu_utils import run_conv

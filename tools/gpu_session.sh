@@ -89,6 +89,14 @@ PY
       (cd yolact_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-value -I../../include -DYMI_DIAGNOSTICS=1 -c dcn.hip -o /tmp/dcn_diag.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls *.o | grep -v '^dcn.o$') /tmp/dcn_diag.o -o ../libyolact_amd.so) > $O/dcnabl_build.log 2>&1; tail -2 $O/dcnabl_build.log
       timeout 600 python tools/dcn_probe.py --tiles ${arg:-dcnp64x128w8,dcnp64x128,dcnp128x128w8} --layers layer1.1,layer2.1,layer3.1 --ablate 1,2,3,4,8,12,16,32,64,7,15 > $O/dcn_ablation.txt 2>&1; grep -E "abl=" $O/dcn_ablation.txt | cut -c1-300 ;;
     upsample) for v in band rows rowsnt; do YOLACT_AMD_UPSAMPLE=$v timeout 120 python tools/upsample_probe.py; YOLACT_AMD_UPSAMPLE=$v timeout 120 python tools/upsample_probe.py --size 337 --width 401 --batch 2 --cap 37; YOLACT_AMD_UPSAMPLE=$v timeout 120 python tools/upsample_probe.py --batch 1; done > $O/upsample_probe.txt 2>&1; cat $O/upsample_probe.txt | cut -c1-220 ;;
+    upabl) # diagnostics build of csrc/mask.hip only (YMI_UP_ABLATE), then the ablation of the rows upsample kernel
+      (cd yolact_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-value -I../../include -DYMI_DIAGNOSTICS=1 -c mask.hip -o /tmp/mask_diag.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls *.o | grep -v '^mask.o$') /tmp/mask_diag.o -o ../libyolact_amd.so) > $O/upabl_build.log 2>&1; tail -2 $O/upabl_build.log
+      for a in 0 1 2 3 4 5 6 7; do YMI_UP_ABLATE=$a YOLACT_AMD_UPSAMPLE=rowsnt timeout 120 python tools/upsample_probe.py 2>&1 | grep variant | sed "s/^/abl=$a /"; done > $O/upsample_ablation.txt; cut -c1-120 $O/upsample_ablation.txt ;;
+    uppmc) # wave-state counters of the mask upsample kernel
+      (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-include-regex mask_upsample -f csv -d $R/$O/uppmc1 -- bash -c "cd $R && YOLACT_AMD_UPSAMPLE=${arg:-rowsnt} python tools/upsample_probe.py --reps 3" > $R/$O/uppmc1.log 2>&1)
+      (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM SQ_WAIT_INST_LDS --kernel-include-regex mask_upsample -f csv -d $R/$O/uppmc2 -- bash -c "cd $R && YOLACT_AMD_UPSAMPLE=${arg:-rowsnt} python tools/upsample_probe.py --reps 3" > $R/$O/uppmc2.log 2>&1)
+      for k in 1 2; do python tools/pmc_summary.py $O/uppmc$k > $O/pmc_upsample_p$k.tsv 2> $O/uppmc$k.err; cat $O/pmc_upsample_p$k.tsv | cut -c1-420; done
+      find $O -name "*counter_collection.csv" -size +4M -delete ;;
     dcnref) timeout 600 python -m pytest tests/test_gpu_dcn_reference.py -m gpu -q -rA -s > $O/dcnref.log 2>&1; tail -5 $O/dcnref.log ;;
     evalpy) timeout 1500 bash tools/run_reference_eval.sh $O > $O/evalpy.log 2>&1; tail -30 $O/evalpy.log ;;
     py) n=$(basename ${arg%% *} .py); k=0; while [ -e $O/$n$k.log ]; do k=$((k+1)); done

@@ -549,9 +549,9 @@ int run_pipe(const ymi_conv_desc *d, const float *offmask, int ldo, int mask_is_
   if (M * (long)(plain ? 1 : ldo) >= (1L << 29) || M * (long)g0.row_stride >= (1L << 31)) return YMI_ESHAPE;
   const int S = d->split_k > 1 ? d->split_k : 1;
   const int nk = d->Kpad / BK;
-  if (nk < 4) return YMI_EARG;
+  if (nk < 2) return YMI_EARG;
   if (S > 1) {
-    if (S > 16 || nk % S != 0 || nk / S < 4) return YMI_EARG;
+    if (S > 16 || nk % S != 0 || nk / S < 2) return YMI_EARG;
     if (!d->split_ws || !d->winv_h2) return YMI_ENULL;
     if ((((uintptr_t)d->split_ws) & 15) || M * (long)d->Cout >= (1L << 29)) return YMI_ESHAPE;
   }

@@ -191,80 +191,143 @@ __global__ __launch_bounds__(256) void mask_upsample_band_k(const float *__restr
 // What bounded the band kernel: per block TWO phases around a barrier (columns -> LDS band -> copy out), and inside phase 1 a
 // dependent global-load round trip every time the source row changes (2 - 3 per 8-row band), with 8 small blocks per CU to hide it.
 // Here the horizontal half of the bilinear form is evaluated ONCE per needed source row into LDS ((R * ph / h) + 3 rows of w floats:
-// all loads of the block are issued together, one round trip), and after the single barrier every thread produces aligned float4s
-// of the FLAT output directly: two LDS values and one vertical lerp per pixel, one compare, one 16-byte global store — no second
-// pass over the band.  Arithmetic: (1 - lx) * v0 + lx * v1 per source row, then (1 - ly) * top + ly * bottom — exactly the two
+// all loads of the block are issued together, one round trip), and after the single barrier every WAVE produces whole output rows:
+// two LDS values and one vertical lerp per pixel, one compare, one store — no second pass over the band.  Arithmetic: (1 - lx) * v0 + lx * v1 per source row, then (1 - ly) * top + ly * bottom — exactly the two
 // lerps of up_lerp2 in its association (no FMA contraction), so the outputs are bit-identical to both kernels above.
 // NT: nontemporal stores (the 121 MB per image are written once and read by another kernel, or the host, much later).
 template <int R, bool NT>
 __global__ __launch_bounds__(256) void mask_upsample_rows_k(const float *__restrict__ lo, float *__restrict__ out, int ph,
                                                             int pw, int h, int w, float sh, float sw, float thresh,
-                                                            const int *__restrict__ count, int cap) {
-  extern __shared__ __attribute__((aligned(16))) float hs[];        // [ns][w]: source rows ys0 .. ys0 + ns - 1, interpolated along x
+                                                            const int *__restrict__ count, int cap, int abl, int nmask) {
+  extern __shared__ __attribute__((aligned(16))) float hs[];        // [ns][w] source rows ys0 .. ys0 + ns - 1 interpolated along x,
+                                                                    // then [ns][pw] the raw source rows
+  __shared__ f32x4 rowinfo[R];                                      // per output row of the band: {offset of its top row in hs, of its
+                                                                    // bottom row (as int bits), ly, 1 - ly}
   const int n = blockIdx.y;
   if (count) {
     const int b = n / cap, i = n - b * cap;
     if (i >= count[b]) return;
   }
   const int t = threadIdx.x;
-  const int y_begin = blockIdx.x * R;
+  const int bxi = blockIdx.x;
+  const int y_begin = bxi * R;
   const int rows = (h - y_begin) < R ? (h - y_begin) : R;
   int ys0, ys1, tmp; float tl;
   up_coord(y_begin, sh, ph, ys0, tmp, tl);
   up_coord(y_begin + rows - 1, sh, ph, tmp, ys1, tl);
   const int ns = ys1 - ys0 + 1;
   const float *img = lo + (size_t)n * ph * pw + (size_t)ys0 * pw;
+  float *raw = hs + ns * w;
+  // phase 0: the needed source rows are one contiguous run of the low-resolution mask: coalesced copy into LDS, then every thread
+  // owns output columns (their x coordinates are computed once) and walks down the rows out of LDS
+#ifdef YMI_DIAGNOSTICS   // abl (env YMI_UP_ABLATE, tools/upsample_probe.py): bit0 no phase 0, bit1 no LDS reads in phase 1, bit2 no stores
+  if (!(abl & 1))
+#endif
   {
-    int s = 0, x = t;
-    while (x >= w) { x -= w; ++s; }
-    for (int idx = t; idx < ns * w; idx += 256) {
+    for (int i = t; i < ns * pw; i += 256) raw[i] = img[i];
+    __syncthreads();
+    for (int x = t; x < w; x += 256) {
       int x0, x1; float lx;
       up_coord(x, sw, pw, x0, x1, lx);
-      const float *row = img + s * pw;
-      hs[idx] = (1.f - lx) * row[x0] + lx * row[x1];
-      x += 256;
-      while (x >= w) { x -= w; ++s; }
+      const float omx = 1.f - lx;
+      int s = 0;
+      for (; s + 4 <= ns; s += 4) {                  // four rows per trip: eight independent LDS reads, then the arithmetic
+        float a[4], b[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a[k] = raw[(s + k) * pw + x0]; b[k] = raw[(s + k) * pw + x1]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) hs[(s + k) * w + x] = omx * a[k] + lx * b[k];
+      }
+      for (; s < ns; ++s) hs[s * w + x] = omx * raw[s * pw + x0] + lx * raw[s * pw + x1];
     }
   }
+  if (t < rows) {
+    int a0, a1; float la;
+    up_coord(y_begin + t, sh, ph, a0, a1, la);
+    f32x4 ri;
+    ri[0] = __int_as_float((a0 - ys0) * w); ri[1] = __int_as_float((a1 - ys0) * w);
+    ri[2] = la; ri[3] = 1.f - la;
+    rowinfo[t] = ri;
+  }
   __syncthreads();
+  // phase 1: the band as a FLAT range of the output, cut into segments of 64 consecutive floats that start on 128-byte lines of
+  // the output tensor; wave v sweeps its quarter of the segments, lane l <-> float l of the segment.  All bookkeeping (element,
+  // row, column of the segment's first float) is wave-uniform, i.e. scalar; a segment straddles at most one row boundary (w >= 64:
+  // launcher), where lanes select between the constants of the two rows.  Per segment: two conflict-free LDS reads (consecutive
+  // lanes, consecutive banks), three multiply / adds, a compare, one store instruction writing two whole cache lines.
+  // Measured on the way here (profiles/r04_upsample_probe.txt, r04_upsample_ablation.txt): (i) an aligned float4 of the flat band
+  // per lane (16-byte stores) has a lane stride of 16 bytes in LDS — 4-way bank conflicts; (ii) one wave per output ROW (stores
+  // start wherever the row starts: 550 floats = 17.2 lines) reached 3.5 TB/s at 550 x 550 but 5.2 TB/s at 512 x 512, where rows are
+  // whole lines; (iii) per-LANE row / column bookkeeping with a row-table read per pixel: the stores could be removed without
+  // changing the time (3.8 TB/s) — 60 % of it was the loop skeleton.  torch's fill kernel: 6.8 TB/s over the same bytes.
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+  const bool soft = thresh < 0.f;
   const long g0 = ((long)n * h + y_begin) * w;       // first flat element of the band
-  const int shift = (int)(g0 & 3);                   // chunk j holds flat elements g0 - shift + 4j .. + 3 = band elements 4j - shift ..
+  const int lead = (int)(g0 & 31);                   // floats between the preceding 128-byte line boundary and the band
   const int total = rows * w;
-  const int nchunk = (shift + total + 3) >> 2;
-  float *dst = out + (g0 - shift);                   // 16-byte aligned (out is, and g0 - shift is a multiple of 4)
-  int e = 4 * t - shift, r = 0, x = e;               // band element / row / column of the chunk's first element (x < 0: before the band)
-  while (x >= w) { x -= w; ++r; }
-  for (int j = t; j < nchunk; j += 256) {
-    int a0, a1, b0 = 0, b1 = 0; float la, lb = 0.f;
-    up_coord(y_begin + r, sh, ph, a0, a1, la);
-    if (x + 3 >= w) up_coord(y_begin + r + 1, sh, ph, b0, b1, lb);      // the chunk straddles a row boundary (w >= 4)
-    const float *ta = hs + (a0 - ys0) * w, *ba = hs + (a1 - ys0) * w;
-    const float *tb = hs + (b0 - ys0) * w, *bb = hs + (b1 - ys0) * w;
-    f32x4 o;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int ee = e + k;
-      float res = 0.f;
-      if (ee >= 0 && ee < total) {
-        const int xk = x + k;
-        const bool wrap = xk >= w;
-        const int xx = wrap ? xk - w : xk;
-        const float top = wrap ? tb[xx] : ta[xx], bot = wrap ? bb[xx] : ba[xx], ly = wrap ? lb : la;
-        const float v = (1.f - ly) * top + ly * bot;
-        res = thresh < 0.f ? v : (v > thresh ? 1.f : 0.f);
-      }
-      o[k] = res;
+  float *base = out + (g0 - lead);                   // 128-byte aligned when `out` is (torch allocations are)
+  const int nseg = (lead + total + 63) >> 6;
+  const int per = (nseg + 3) >> 2;
+  const int q0 = wave * per, q1 = (q0 + per) < nseg ? (q0 + per) : nseg;
+  // Two independent streams per wave (halves of its segments), advanced together: the loop body then holds two independent
+  // LDS-read -> lerp -> store chains instead of one serial chain (two streams: 0.272 -> 0.227 ms) (with ~5 waves per SIMD the single chain left the
+  // waves parked on lgkmcnt 64 % of the time: profiles/r04_pmc_upsample.tsv).  Row selection is per lane and branch-free.
+  struct Stream { int q, qe, e0, x0, r0, ta, ba, tb, bb; float lya, oma, lyb, omb; };
+  auto row_of = [&](int r, int &toff, int &boff, float &ly, float &oml) {
+    const f32x4 ri = rowinfo[r < rows ? r : rows - 1];
+    const float f0 = ri[0], f1 = ri[1];              // (scalar copies first: __builtin_bit_cast applied directly to a vector ELEMENT
+    toff = __float_as_int(f0); boff = __float_as_int(f1);   //  reads element 0 — hipcc 7.2, seen in the ISA)
+    ly = ri[2]; oml = ri[3];
+  };
+  auto open = [&](Stream &st, int qa, int qb) {
+    st.q = qa; st.qe = qb;
+    st.e0 = 64 * qa - lead; st.r0 = 0; st.x0 = st.e0;
+    if (st.e0 > 0) { st.r0 = st.e0 / w; st.x0 = st.e0 - st.r0 * w; }
+    row_of(st.r0, st.ta, st.ba, st.lya, st.oma);
+    row_of(st.r0 + 1, st.tb, st.bb, st.lyb, st.omb);
+  };
+  auto fetch = [&](const Stream &st, float &top, float &bot, float &ly, float &oml, bool &ok) {
+    const int e = st.e0 + lane, xl = st.x0 + lane;
+    ok = st.q < st.qe && e >= 0 && e < total;
+    const bool nx = xl >= w;
+    const int x = ok ? (nx ? xl - w : xl) : 0;
+    top = hs[(ok ? (nx ? st.tb : st.ta) : 0) + x];
+    bot = hs[(ok ? (nx ? st.bb : st.ba) : 0) + x];
+    ly = nx ? st.lyb : st.lya; oml = nx ? st.omb : st.oma;
+  };
+  auto finish = [&](Stream &st, float top, float bot, float ly, float oml, bool ok) {
+    float v = oml * top + ly * bot;
+#ifdef YMI_DIAGNOSTICS
+    if (abl & 2) v = (float)st.x0;
+    if (abl & 4) ok = ok && v == 12345.f;
+#endif
+    const float o = soft ? v : (v > thresh ? 1.f : 0.f);
+    if (ok) {
+      float *dst = base + 64 * st.q + lane;
+      if (NT) __builtin_nontemporal_store(o, dst);
+      else *dst = o;
     }
-    if (e >= 0 && e + 3 < total) {
-      if (NT) __builtin_nontemporal_store(o, reinterpret_cast<f32x4 *>(dst + 4 * j));
-      else *reinterpret_cast<f32x4 *>(dst + 4 * j) = o;
-    } else {
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (e + k >= 0 && e + k < total) dst[4 * j + k] = o[k];
+    ++st.q; st.e0 += 64; st.x0 += 64;
+    if (st.x0 >= w) {                                           // (wave-uniform) next row
+      st.x0 -= w; ++st.r0;
+      st.ta = st.tb; st.ba = st.bb; st.lya = st.lyb; st.oma = st.omb;
+      row_of(st.r0 + 1, st.tb, st.bb, st.lyb, st.omb);
     }
-    e += 1024; x += 1024;
-    while (x >= w) { x -= w; ++r; }
+  };
+  constexpr int NSTR = 2;                            // independent streams per wave (4: 0.241 ms, 2: 0.224 - 0.227, 1: 0.272)
+  const int len = q1 > q0 ? q1 - q0 : 0, part = (len + NSTR - 1) / NSTR;
+  Stream st[NSTR];
+#pragma unroll
+  for (int k = 0; k < NSTR; ++k) {
+    const int qa = q0 + k * part, qb = qa + part;
+    open(st[k], qa < q1 ? qa : q1, qb < q1 ? qb : q1);
+  }
+  for (int it = 0; it < part; ++it) {
+    float tp_[NSTR], bt_[NSTR], ly_[NSTR], om_[NSTR]; bool ok_[NSTR];
+#pragma unroll
+    for (int k = 0; k < NSTR; ++k) fetch(st[k], tp_[k], bt_[k], ly_[k], om_[k], ok_[k]);
+#pragma unroll
+    for (int k = 0; k < NSTR; ++k) finish(st[k], tp_[k], bt_[k], ly_[k], om_[k], ok_[k]);
   }
 }
 
@@ -313,13 +376,13 @@ int ymi_lincomb_crop_batch_f32(const float *proto, const float *coef, const floa
 
 namespace {
 constexpr int UP_ROWS = 8;
-constexpr int UP_ROWS2 = 16;
-// YOLACT_AMD_UPSAMPLE = rows (default: mask_upsample_rows_k) | rowsnt (the same with nontemporal stores) | band (the round-2
+constexpr int UP_ROWS2 = 32;
+// YOLACT_AMD_UPSAMPLE = rowsnt (default: mask_upsample_rows_k with nontemporal stores) | rows (the same with plain stores) | band (the round-2
 // kernel) — an A/B switch for the measurement log (tools/upsample_probe.py); all three produce the same bits
 int upsample_variant() {
   static const int v = [] {
     const char *e = getenv("YOLACT_AMD_UPSAMPLE");
-    if (!e) return 0;
+    if (!e) return 1;
     return e[0] == 'b' ? 2 : (e[0] == 'r' && e[1] == 'o' && e[2] == 'w' && e[3] == 's' && e[4] == 'n') ? 1 : 0;
   }();
   return v;
@@ -329,17 +392,26 @@ int launch_upsample(const float *masks_lo, float *out, const int32_t *count, int
                     float thresh, hipStream_t s) {
   {
     const float sh = (float)ph / (float)h;
-    const long ns_max = (long)((float)UP_ROWS2 * sh) + 3;        // source rows a band of UP_ROWS2 output rows can touch
-    const size_t lds = (size_t)ns_max * w * sizeof(float);
     const int variant = upsample_variant();
-    if (variant != 2 && w >= 4 && lds <= 40 * 1024 && nmask <= 65535 && ((uintptr_t)out & 15) == 0) {
-      const dim3 grid((h + UP_ROWS2 - 1) / UP_ROWS2, nmask);
-      if (variant == 1)
-        hipLaunchKernelGGL((mask_upsample_rows_k<UP_ROWS2, true>), grid, dim3(256), lds, s, masks_lo, out, ph, pw, h, w, sh,
-                           (float)pw / (float)w, thresh, (const int *)count, cap);
-      else
-        hipLaunchKernelGGL((mask_upsample_rows_k<UP_ROWS2, false>), grid, dim3(256), lds, s, masks_lo, out, ph, pw, h, w, sh,
-                           (float)pw / (float)w, thresh, (const int *)count, cap);
+    int abl = 0;
+#ifdef YMI_DIAGNOSTICS
+    { const char *e = getenv("YMI_UP_ABLATE"); abl = e ? atoi(e) : 0; }
+#endif
+    // bands of 32 output rows when that still gives every CU several blocks, else 16; tiny launches (< ~2 blocks per CU even so)
+    // stay on the band kernel, whose 8-row blocks spread better (100 masks of 550 x 550: 0.033 vs 0.037 ms)
+    const long bands32 = (long)((h + 31) / 32) * nmask, bands16 = (long)((h + 15) / 16) * nmask;
+    const int R = bands32 >= 5120 ? 32 : 16;
+    const long ns_max = (long)((float)R * sh) + 3;               // source rows a band of R output rows can touch
+    const size_t lds = (size_t)ns_max * (w + pw) * sizeof(float);
+    if (variant != 2 && w >= 64 && lds <= 48 * 1024 && nmask <= 65535 && ((uintptr_t)out & 15) == 0 && (R == 32 || bands16 >= 4096)) {
+      // (one block per band: persistent blocks looping over bands measured SLOWER, 0.295 vs 0.272 ms — profiles/r04_upsample_ablation.txt)
+      const dim3 grid((h + R - 1) / R, nmask);
+      const float sw = (float)pw / (float)w;
+#define YMI_UP_LAUNCH(RR, NTV) hipLaunchKernelGGL((mask_upsample_rows_k<RR, NTV>), grid, dim3(256), lds, s, masks_lo, out, ph, pw, h, w, \
+                                                  sh, sw, thresh, (const int *)count, cap, abl, nmask)
+      if (R == 32) { if (variant == 1) YMI_UP_LAUNCH(32, true); else YMI_UP_LAUNCH(32, false); }
+      else { if (variant == 1) YMI_UP_LAUNCH(16, true); else YMI_UP_LAUNCH(16, false); }
+#undef YMI_UP_LAUNCH
       return ymi_launch_status();
     }
   }

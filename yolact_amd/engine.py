@@ -307,6 +307,8 @@ class Plan:
         self._nslots = 0
         # YOLACT_AMD_SPLITK=0 keeps every GEMM a single pass (no split-K candidates in the tuner)
         self.splitk = os.environ.get('YOLACT_AMD_SPLITK', '1') == '1'
+        # YOLACT_AMD_PIPE=0 keeps the pipelined kernel of csrc/dcn.hip out of the candidates of ORDINARY convolutions (A/B switch)
+        self.pipe = os.environ.get('YOLACT_AMD_PIPE', '1') == '1'
         self._sk_ws = {}
         self.down_on_side_stream = os.environ.get('YOLACT_AMD_DOWN_STREAM', 'B') == 'B'      # measured +1 %
         self.wino_alt, self._wino_packed, self._wino_ws = {}, {}, {}
@@ -959,13 +961,25 @@ class Plan:
         d.tile = tile
         if S > 1:
             is_dcn = fn is self.lib.ymi_dcn_v2_forward_f32
-            if (not is_dcn and not self._splitk_ok(d)) or (is_dcn and not tile & L.TILE_DCNP) or (d.Kpad // 32) % S:
+            if tile & L.TILE_DCNP:
+                if (d.Kpad // 32) % S:
+                    return -1
+            elif is_dcn or not self._splitk_ok(d) or (d.Kpad // 32) % S:
                 return -1
             d.split_k = S
             d.split_ws = self._splitk_ws(where, S * d.B * d.Ho * d.Wo * d.Cout).data_ptr()
         else:
             d.split_k = 0
         return fn(dptr, s)
+
+    @staticmethod
+    def _pipe_ok(d):
+        """Ordinary convolutions the pipelined kernel of csrc/dcn.hip takes (run_pipe): 3x3 / pad 1 or 1x1 / pad 0, Cin % 32 == 0, one
+        dense output, activation none / ReLU / LeakyReLU, residual none / add."""
+        return ((d.kh, d.kw, d.pad) in ((3, 3, 1), (1, 1, 0)) and d.Cin % 32 == 0 and d.Kpad == d.kh * d.kw * d.Cin and d.Kpad >= 64
+                and d.nseg == 1 and d.Cout % 4 == 0 and d.seg[0].n0 == 0 and d.seg[0].act <= L.ACT_LEAKY01
+                and d.seg[0].row_stride % 4 == 0 and d.seg[0].batch_stride == d.Ho * d.Wo * d.seg[0].row_stride
+                and d.res_mode in (L.RES_NONE, L.RES_ADD))
 
     @staticmethod
     def dcnp_candidates(d):
@@ -982,8 +996,8 @@ class Plan:
             out.append(tid)
             blocks = -(-M // bm) * -(-d.Cout // bn)
             if blocks < 200 and d.Cout % 4 == 0:
-                for S in (2, 3, 4, 6, 8, 9, 12):
-                    if nk % S == 0 and nk // S >= 6 and 128 <= blocks * S <= 520:
+                for S in (2, 3, 4, 6, 8, 9, 12, 16):
+                    if nk % S == 0 and nk // S >= 4 and 128 <= blocks * S <= 520:
                         out.append(tid + 256 * S)
         return out
 
@@ -1026,6 +1040,8 @@ class Plan:
                     cands = cands + [t | spflag for t in cands if t in base_ok
                                      and (d.Cin % 32 == 0 or t in L.BASIC_TILES)]
                 if is_dcn and self.h2:       # the pipelined gather-GEMM of csrc/dcn.hip (fp16x2 plans)
+                    cands = cands + self.dcnp_candidates(d)
+                if not is_dcn and self.h2 and self.pipe and self._pipe_ok(d):   # the same pipelined kernel as an ordinary convolution
                     cands = cands + self.dcnp_candidates(d)
                 if not is_dcn and self._splitk_ok(d) and self.splitk:
                     # split-K candidates: big tiles whose grid alone cannot fill the chip, K cut 2 / 4 ways
