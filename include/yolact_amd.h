@@ -138,7 +138,9 @@ enum { YMI_DCNP_64x128 = 1, YMI_DCNP_64x128_W8 = 2, YMI_DCNP_64x64 = 3, YMI_DCNP
        /* 256 output channels per block (every sample gathered once for all of them): the Cout >= 256 layers, normally with
         * ymi_conv_desc.split_k = S (chunk-aligned K ranges, partial sums through split_ws, deterministic second pass) because their
         * maps are small */
-       YMI_DCNP_64x256_W8 = 11, YMI_DCNP_96x256_W12 = 12, YMI_DCNP_128x256_W16 = 13 };
+       YMI_DCNP_64x256_W8 = 11, YMI_DCNP_96x256_W12 = 12, YMI_DCNP_128x256_W16 = 13,
+       /* 64 x 64 wave tiles (ordinary convolutions only: ymi_conv2d_nhwc_f32) */
+       YMI_DCNP_128x256_W8T = 14, YMI_DCNP_128x128_W4T = 15, YMI_DCNP_256x128_W8T = 16 };
 
 int ymi_abi_version(void);
 const char *ymi_strerror(int code);

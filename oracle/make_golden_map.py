@@ -2,7 +2,8 @@
 
 For every golden case the reference's stored postprocess() outputs (tests/golden/<case>.npz, produced by executing the
 reference model) are scored by the reference's own eval.prep_metrics / eval.calc_map (eval.py:386-470,1005-1031)
-against pseudo ground truth built from those same detections (oracle/map_eval.pseudo_gt).  eval.postprocess is
+against pseudo ground truth built from those same detections (oracle/map_eval.pseudo_gt) and then displaced object by
+object (oracle/map_eval.perturb_gt) so that the table falls from IoU .50 to .95 instead of being flat.  eval.postprocess is
 replaced by a stub that returns the stored outputs, so exactly the evaluator code is exercised.  Writes
 tests/golden/map.npz: per case the GT (boxes, classes, packed masks) and the reference's box / mask mAP table.
 """
@@ -54,6 +55,7 @@ def main():
                 continue
             post = load_post(z, b, w, h)
             gt, gt_masks = ME.pseudo_gt(*post, w, h)
+            gt, gt_masks = ME.perturb_gt(gt, gt_masks, w, h, seed=CASES.index(name) * 4 + b)     # a table that falls from .50 to .95
             out['%s_gt%d' % (name, b)] = gt
             out['%s_gtmaskbits%d' % (name, b)] = np.packbits(gt_masks.reshape(-1))
             E.postprocess = lambda dets, w_, h_, **kw: post          # the evaluator sees the stored reference outputs

@@ -169,6 +169,40 @@ def pseudo_gt(classes, scores, boxes, masks, w, h, max_gt=10, max_overlap=0.3):
     return gt, masks[chosen].numpy().astype(np.uint8)
 
 
+def perturb_gt(gt, gt_masks, w, h, seed=0):
+    """Make the pseudo ground truth DISCRIMINATING.  pseudo_gt() returns the reference's own detections, so the
+    reference scores IoU = 1 against every GT object and its AP table is flat from IoU .50 to .95: a mask that drifted by 5 % IoU
+    would change nothing.  Here every GT object r is displaced so that the detection it came from overlaps it with a chosen IoU
+    t_r, the t_r spread quasi-uniformly over [0.52, 0.98] (golden-ratio sequence, deterministic in (seed, r)): boxes are shifted
+    along x by s * width with s = (1 - t) / (1 + t) (two equal boxes shifted by s * width overlap with IoU (1 - s) / (1 + s) = t),
+    masks by the same fraction of their own extent (zero fill).  The reference's table then FALLS from .50 to .95 as objects drop
+    below the threshold one by one, and an evaluated path only reproduces it if its boxes / masks have the reference's IoUs — to
+    within the spacing of the t_r — at every threshold.  Returns (gt', gt_masks')."""
+    gt = np.array(gt, dtype=np.float64, copy=True)
+    gm = np.array(gt_masks, copy=True)
+    out = np.zeros_like(gm)
+    for r in range(gt.shape[0]):
+        t = 0.52 + 0.46 * (((r + 1 + 7 * seed) * 0.6180339887498949) % 1.0)
+        s = (1.0 - t) / (1.0 + t)
+        sign = 1.0 if (r + seed) % 2 == 0 else -1.0
+        bw = gt[r, 2] - gt[r, 0]
+        dx = sign * s * bw
+        if gt[r, 0] + dx < 0.0 or gt[r, 2] + dx > 1.0:        # keep the box inside the image: shift the other way
+            dx = -dx
+        gt[r, 0] += dx
+        gt[r, 2] += dx
+        cols = np.nonzero(gm[r].any(axis=0))[0]
+        if cols.size:
+            px = int(round(s * (cols[-1] - cols[0] + 1))) * (1 if dx >= 0 else -1)
+            if px > 0:
+                out[r][:, px:] = gm[r][:, :-px]
+            elif px < 0:
+                out[r][:, :px] = gm[r][:, -px:]
+            else:
+                out[r] = gm[r]
+    return gt, out
+
+
 # ----------------------------------------------------------------------------------------------
 # prep_display, GPU half (SURVEY §8(f) rank 2) — eval.py:135-209,228 with undo_transform=False
 COLORS = ((244, 67, 54), (233, 30, 99), (156, 39, 176), (103, 58, 183), (63, 81, 181), (33, 150, 243), (3, 169, 244),

@@ -126,6 +126,75 @@ def test_forced_f4x4_plan_matches_oracle_at_batch8():
                 os.environ[k] = v
 
 
+def _plant_outlier_channels(sd, k_exp, nch=4):
+    """Equivalent re-parametrisation of the network with OUTLIER CHANNELS (what real BN-folded checkpoints have): in
+    stages C3 .. C5 `nch` channels of the stage tensor are scaled by 2^k (every block's bn3 and the projection shortcut's BN), and
+    every consumer of that tensor (the conv1 of the following blocks, the next stage's first conv1 / projection shortcut, the FPN
+    lateral) divides its weights for those input channels by 2^k; likewise four output channels of proto_net.0 against proto_net.2.  Powers of two commute with fp32 rounding (no overflow here), so in exact
+    fp32 arithmetic every product — hence every head tensor — is unchanged; what changes is the dynamic range INSIDE the activation
+    tensors (2^k between channels of one tensor: the fp16x2 tiles use ONE power-of-two scale per tensor) and inside the filter rows
+    (2^-k between columns of one row: one scale per row)."""
+    sd = {k: v.clone() for k, v in sd.items()}
+    f = float(2 ** k_exp)
+    planted = []
+
+    def scale_out(bn, ch):
+        sd[bn + '.weight'][ch] *= f
+        sd[bn + '.bias'][ch] *= f
+
+    def scale_in(conv_w, ch):
+        sd[conv_w][:, ch] /= f
+    nblocks = {}
+    for key in sd:
+        if key.startswith('backbone.layers.') and key.endswith('.bn3.weight'):
+            _, _, li, bi = key.split('.')[:4]
+            nblocks[int(li)] = max(nblocks.get(int(li), 0), int(bi) + 1)
+    nstage = len(nblocks)
+    for li in range(1, nstage):                       # C3, C4, C5 (stage outputs the FPN consumes; backbone.py:126-139, yolact.py:310-341)
+        n = nblocks[li]
+        C = sd['backbone.layers.%d.%d.bn3.weight' % (li, n - 1)].shape[0]
+        ch = torch.arange(nch) * (C // nch) + 3
+        # the stage tensor runs through identity shortcuts (y = relu(bn3(conv3) + x), backbone.py:50-55): the channel must be
+        # scaled in EVERY block's bn3 and in the projection shortcut's BN, and every conv1 that reads the stage tensor divides
+        for bi in range(n):
+            scale_out('backbone.layers.%d.%d.bn3' % (li, bi), ch)
+            if bi > 0:
+                scale_in('backbone.layers.%d.%d.conv1.weight' % (li, bi), ch)
+        scale_out('backbone.layers.%d.0.downsample.1' % li, ch)
+        if li + 1 < nstage:
+            scale_in('backbone.layers.%d.0.conv1.weight' % (li + 1), ch)
+            scale_in('backbone.layers.%d.0.downsample.0.weight' % (li + 1), ch)
+        scale_in('fpn.lat_layers.%d.weight' % (nstage - 1 - li), ch)     # lat_layers are stored top-down (yolact.py:286-289)
+        planted.append(('C%d' % (li + 2), ch.tolist()))
+    ch = torch.tensor([5, 70, 131, 200])
+    sd['proto_net.0.weight'][ch] *= f
+    sd['proto_net.0.bias'][ch] *= f
+    sd['proto_net.2.weight'][:, ch] /= f
+    planted.append(('proto_net.0', ch.tolist()))
+    return sd, planted
+
+
+@pytest.mark.parametrize('k_exp', [12, 14, 16])
+def test_outlier_channels_end_to_end_at_batch8(k_exp):
+    """fp16x2 carries one power-of-two scale per activation TENSOR (h stays a normal fp16 27 binades below the bound,
+    l 15) and one per FILTER ROW; a single-layer test covered 2^14 outliers, nothing did end to end.  Here the R50 network is
+    re-parametrised (exactly, see _plant_outlier_channels) so that C3 / C4 / C5 and a protonet tensor carry channels 2^12 .. 2^16 times
+    larger than the rest, and the default batch-8 plan is held to the same bars as the timed plan: heads within 1e-4, every
+    decidable detection reproduced."""
+    tag, config, B, size, seed, gain, img_seed = CASES[0]
+    net, sd0 = _build(config, seed, gain)
+    sd, planted = _plant_outlier_channels({k: v.cpu() for k, v in sd0.items()}, k_exp)
+    net.load_state_dict_compat(sd)
+    net._synth_key = (config, seed, gain, 'outliers', k_exp)
+    plan, _, _ = _compare(net, sd, config, B, size, img_seed, 'outlier channels 2^%d %s' % (k_exp, planted))
+    # the planted channels really are outliers of their tensors on the device: the bound of C3's slot vs a typical channel
+    x = synth_images(B, size, size, seed=img_seed).to(DEV)
+    net.forward_raw(x)
+    bounds = sorted(plan.bound(sl) for sl in range(plan._nslots))
+    print('magnitude bounds of the plan\'s tensors with 2^%d outliers: median %.3g, max %.3g' % (k_exp, bounds[len(bounds) // 2], bounds[-1]))
+    assert bounds[-1] >= 2 ** (k_exp - 4) * bounds[len(bounds) // 2]
+
+
 def test_plan_is_deterministic_across_processes():
     """The default plan comes from the shipped tune table, so two fresh processes produce identical bits (the round-1
     plan timed its tiles per process: K-split tiles change the summation order, i.e. the bits)."""

@@ -1,12 +1,14 @@
 """Mask / box mAP parity on pseudo ground truth (BASELINE metric: "mask mAP parity").
 
-tests/golden/map.npz holds, per golden case, pseudo GT (the reference's own top detections) and the mAP table that the
-reference's OWN evaluator (eval.prep_metrics / eval.calc_map, executed in the build container by
+tests/golden/map.npz holds, per golden case, pseudo GT (the reference's own top detections, each DISPLACED to a chosen IoU in
+[0.52, 0.98] against the detection it came from — oracle/map_eval.perturb_gt — so that the table falls from IoU .50 to .95 instead
+of being flat: round 3's stand-in read the same value at every threshold and could not see a mask drifting by 5 % IoU) and the mAP
+table that the reference's OWN evaluator (eval.prep_metrics / eval.calc_map, executed in the build container by
 oracle/make_golden_map.py) gives the reference's detections on it.
   * CPU: oracle/map_eval.py (restated evaluator) on the stored reference detections reproduces that table exactly.
   * GPU: the HIP path's detections for the same images, scored by the same evaluator on the same GT, give the same
-    table within 0.5 mAP points (a single borderline detection flipping at one IoU threshold moves a class AP by
-    1/(#gt) and the mean over ~10 classes by less than that).
+    table within 0.1 mAP points at EVERY threshold (measured: equal) — an object whose IoU with its displaced GT sits within the
+    engine-vs-reference mask difference of a threshold would move a class AP by 1/(#gt), i.e. whole points.
 """
 import json
 import os
@@ -89,5 +91,6 @@ def test_hip_path_map_matches_reference(name):
     box, mask = _table(ME.calc_map(ap, NUM_CLASSES))
     rb, rm = z[name + '_box'], z[name + '_mask']
     print('%s  box mAP ref %.2f hip %.2f | mask mAP ref %.2f hip %.2f' % (name, rb[0], box[0], rm[0], mask[0]))
-    assert np.abs(box - rb).max() <= 0.5, (box, rb)
-    assert np.abs(mask - rm).max() <= 0.5, (mask, rm)
+    assert rb[1] - rb[-1] >= 10.0 and rm[1] - rm[-1] >= 3.0, 'the golden table must fall from .50 to .95 (a flat one sees nothing)'
+    assert np.abs(box - rb).max() <= 0.1, (box, rb)
+    assert np.abs(mask - rm).max() <= 0.1, (mask, rm)

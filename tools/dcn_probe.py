@@ -67,7 +67,7 @@ def main():
         yptr0 = d.seg[0].ptr
         d.seg[0].ptr = y.data_ptr()
         times, ref, dev_max = {}, None, {}
-        new = plan.dcnp_candidates(d)
+        new = plan.dcnp_candidates(d, dcn=True)
         if args.tiles:
             new = [t for t in new if tname(t) in args.tiles.split(',')]
         for t in old + new:

@@ -97,6 +97,9 @@ PY
       (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM SQ_WAIT_INST_LDS --kernel-include-regex mask_upsample -f csv -d $R/$O/uppmc2 -- bash -c "cd $R && YOLACT_AMD_UPSAMPLE=${arg:-rowsnt} python tools/upsample_probe.py --reps 3" > $R/$O/uppmc2.log 2>&1)
       for k in 1 2; do python tools/pmc_summary.py $O/uppmc$k > $O/pmc_upsample_p$k.tsv 2> $O/uppmc$k.err; cat $O/pmc_upsample_p$k.tsv | cut -c1-420; done
       find $O -name "*counter_collection.csv" -size +4M -delete ;;
+    pipeabl) # diagnostics build of csrc/dcn.hip, then the ablation of the pipelined kernel as an ordinary convolution on representative layers
+      (cd yolact_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-value -I../../include -DYMI_DIAGNOSTICS=1 -c dcn.hip -o /tmp/dcn_diag.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls *.o | grep -v '^dcn.o$') /tmp/dcn_diag.o -o ../libyolact_amd.so) > $O/pipeabl_build.log 2>&1; tail -2 $O/pipeabl_build.log
+      timeout 600 python tools/pipe_probe.py --layers ${arg:-proto.8,proto.2,layer1.1.conv2,layer1.1.conv1,layer2.1.conv1,layer3.0.conv1,layer2.1.conv3} --ablate 1,2,3,4,8,12,16,15,31 > $O/pipe_ablation.txt 2>&1; grep -E "abl=|pipelined" $O/pipe_ablation.txt | cut -c1-330 ;;
     dcnref) timeout 600 python -m pytest tests/test_gpu_dcn_reference.py -m gpu -q -rA -s > $O/dcnref.log 2>&1; tail -5 $O/dcnref.log ;;
     evalpy) timeout 1500 bash tools/run_reference_eval.sh $O > $O/evalpy.log 2>&1; tail -30 $O/evalpy.log ;;
     py) n=$(basename ${arg%% *} .py); k=0; while [ -e $O/$n$k.log ]; do k=$((k+1)); done

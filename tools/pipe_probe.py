@@ -24,6 +24,8 @@ def main():
     ap.add_argument('--reps', type=int, default=5)
     ap.add_argument('--layers', default='')
     ap.add_argument('--all-cands', action='store_true', help='print every candidate, not only the best')
+    ap.add_argument('--ablate', default='', help='comma list of YMI_DCN_ABLATE masks (diagnostics build): the best candidate is re-timed per mask')
+    ap.add_argument('--tiles', default='', help='restrict the pipelined candidates to these names (e.g. dcnp128x256w16,dcnp160x128w10/k2)')
     args = ap.parse_args()
     import yolact_amd
     from yolact_amd import _lib as L
@@ -91,6 +93,8 @@ def main():
         d.seg[0].ptr = yref.data_ptr()
         times, devmax = {}, {}
         for cand in plan.dcnp_candidates(d):
+            if args.tiles and tname(cand) not in args.tiles.split(','):
+                continue
             tile, S = cand & 255, cand >> 8
             d.tile = tile
             d.split_k = S if S > 1 else 0
@@ -110,6 +114,17 @@ def main():
         print('%-22s B%d %3dx%-3d s%d k%d %4d>%-4d %6.2f GF | plan %-34s %.4f ms %6.1f TF/s | pipelined %-18s %.4f ms %6.1f TF/s  x%.2f  dev %.1e' % (
             base, d.B, d.H, d.W, d.stride, d.kh, d.Cin, d.Cout, fl / 1e9, name[-34:], t_plan, fl / t_plan / 1e9, tname(best), times[best],
             fl / times[best] / 1e9, t_plan / times[best], devmax.get(best, float('nan'))), flush=True)
+        if args.ablate:
+            tile, S = best & 255, best >> 8
+            d.tile, d.split_k = tile, (S if S > 1 else 0)
+            if S > 1:
+                d.split_ws = plan._splitk_ws(where, S * M * d.Cout).data_ptr()
+            row = []
+            for a in args.ablate.split(','):
+                os.environ['YMI_DCN_ABLATE'] = a
+                row.append('abl=%s %.4f' % (a, timed(lib.ymi_conv2d_nhwc_f32, C.pointer(d))))
+            os.environ['YMI_DCN_ABLATE'] = '0'
+            print('      %s: %s' % (tname(best), '  '.join(row)), flush=True)
         if args.all_cands:
             print('      ' + '  '.join('%s %.4f' % (tname(c), t) for c, t in sorted(times.items(), key=lambda kv: kv[1])[:10]))
     print('TOTAL eligible layers: plan %.3f ms, with the pipelined kernel where it wins %.3f ms (%.1f -> %.1f TF/s algorithmic)' % (

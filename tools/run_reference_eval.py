@@ -107,6 +107,7 @@ def main():
     ap.add_argument('--cuda', type=int, default=1)
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--conf-gain', type=float, default=0.04)
+    ap.add_argument('--perturb', type=int, default=1, help='gt mode: 1 = displaced pseudo-GT (discriminating table), 0 = the flat round-3 form')
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     REF = reference_dir()
@@ -168,7 +169,7 @@ def main():
         gt_file = os.path.join(a.out, 'gt.npz')
 
         if a.mode == 'gt':
-            from oracle.map_eval import pseudo_gt
+            from oracle.map_eval import perturb_gt, pseudo_gt
             net.detect.use_fast_nms = True
             cfg.mask_proto_debug = False
             ds = SynthDataset(a.images, cfg.max_size)
@@ -181,6 +182,8 @@ def main():
                     continue
                 sc = [s.cpu() for s in scores] if isinstance(scores, list) else scores.cpu()
                 gt, gm = pseudo_gt(classes.cpu(), sc, boxes.cpu(), masks.cpu(), W_IMG, H_IMG)
+                if a.perturb:        # displace every GT object to a chosen IoU in [0.52, 0.98]: the table then falls from .50 to .95
+                    gt, gm = perturb_gt(gt, gm, W_IMG, H_IMG, seed=i)
                 rec['gt%d' % iid] = gt
                 rec['bits%d' % iid] = np.packbits(gm.reshape(-1))
             np.savez_compressed(gt_file, **rec)

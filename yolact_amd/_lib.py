@@ -38,7 +38,9 @@ DCNP_64x128, DCNP_64x128_W8, DCNP_64x64, DCNP_128x128_W8, DCNP_128x64_W8, DCNP_3
 DCNP_96x128_W6, DCNP_128x128_W8_R1, DCNP_160x128_W10, DCNP_192x128_W12, DCNP_64x256_W8, DCNP_96x256_W12, DCNP_128x256_W16 = range(7, 14)
 DCNP_TILES = {1: 'dcnp64x128', 2: 'dcnp64x128w8', 3: 'dcnp64x64', 4: 'dcnp128x128w8', 5: 'dcnp128x64w8', 6: 'dcnp32x128',
               7: 'dcnp96x128w6', 8: 'dcnp128x128w8r1', 9: 'dcnp160x128w10', 10: 'dcnp192x128w12',
-              11: 'dcnp64x256w8', 12: 'dcnp96x256w12', 13: 'dcnp128x256w16'}
+              11: 'dcnp64x256w8', 12: 'dcnp96x256w12', 13: 'dcnp128x256w16',
+              14: 'dcnp128x256w8t', 15: 'dcnp128x128w4t', 16: 'dcnp256x128w8t'}
+DCNP_PLAIN_ONLY = (14, 15, 16)     # 64x64 wave tiles: ordinary convolutions only
 for _t, _n in DCNP_TILES.items():
     TILE_NAMES[_t | TILE_H2 | TILE_DCNP] = _n
 WINO_PLANES = 1024                  # tune-table flag on a Winograd GEMM tile id: V written as fp16x2 planes (ymi_wino_desc.v_planes)

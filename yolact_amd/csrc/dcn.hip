@@ -64,12 +64,13 @@ constexpr int dcn_lds_floats() {
   constexpr int pipe = 2 * (2 * BM * 16) + (RING + 2) * (2 * BN * 16), epi = BM * (BN + 4);
   return pipe > epi ? pipe : epi;
 }
-template <int WM, int WN, int TM, int TN, int RING>
-constexpr int dcn_occupancy() {     // blocks per CU: LDS-limited, and capped by the register ring of the gather (16 registers per
-                                    // row and ring slot): 4-wave blocks and 8-wave blocks with one row per thread run two per CU,
-                                    // anything larger one
+template <int WM, int WN, int TM, int TN, int RING, bool PLAIN>
+constexpr int dcn_occupancy() {     // blocks per CU: LDS-limited (at most two), and — DCN gather only — capped by its register ring (16
+                                    // registers per row and ring slot): 4-wave blocks and 8-wave blocks with one row per thread run two
+                                    // per CU, anything larger one.  An ordinary convolution (PLAIN) loads one sample, not four corners,
+                                    // and has no such cap (68 - 110 registers)
   constexpr int occ = (160 * 1024) / (dcn_lds_floats<WM, WN, TM, TN, RING>() * 4);
-  constexpr int nw = WM * WN, ra = (WM * TM * 32) / (8 * nw), cap = (nw > 8 || (nw == 8 && ra > 1)) ? 1 : 2;
+  constexpr int nw = WM * WN, ra = (WM * TM * 32) / (8 * nw), cap = (!PLAIN && (nw > 8 || (nw == 8 && ra > 1))) ? 1 : 2;
   return occ > cap ? cap : (occ < 1 ? 1 : occ);
 }
 
@@ -80,7 +81,7 @@ constexpr int dcn_occupancy() {     // blocks per CU: LDS-limited, and capped by
 // that the LDS-DMA tiles of conv_igemm.hip do not: the A operand is split into its fp16 planes ONCE by the loading thread (the
 // consuming waves run a split-free MFMA loop), 6 .. 16-wave blocks of 32 x 64 wave tiles, 256-column tiles.
 template <int WM, int WN, int TM, int TN, int RING, bool PLAIN>
-__global__ __launch_bounds__(64 * WM * WN, (dcn_occupancy<WM, WN, TM, TN, RING>() * (WM * WN) + 3) / 4)
+__global__ __launch_bounds__(64 * WM * WN, (dcn_occupancy<WM, WN, TM, TN, RING, PLAIN>() * (WM * WN) + 3) / 4)
 void dcn_h2_k(const DcnParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // (host pass: empty body, see conv_igemm.hip)
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NW = WM * WN, NT = 64 * NW;
@@ -497,7 +498,7 @@ int launch_dcn_k(DcnParams p, hipStream_t s) {
   int dyn = 0;
   {
     constexpr int LDS_PER_CU = 160 * 1024, static_lds = dcn_lds_floats<WM, WN, TM, TN, RING>() * 4;
-    const int occ = dcn_occupancy<WM, WN, TM, TN, RING>(), k = (grid * (p.nk / p.nk_split) + 255) / 256;
+    const int occ = dcn_occupancy<WM, WN, TM, TN, RING, PLAIN>(), k = (grid * (p.nk / p.nk_split) + 255) / 256;
 #ifdef YMI_DIAGNOSTICS
     const bool cap_on = !(p.abl & 64);
 #else
@@ -577,7 +578,7 @@ int run_pipe(const ymi_conv_desc *d, const float *offmask, int ldo, int mask_is_
   const int tile_id = base_tile | YMI_TILE_H2 | YMI_TILE_DCNP;
   const double flops = 2.0 * (double)M * (double)(d->cout_alg > 0 ? d->cout_alg : d->Cout) * (double)(d->kh * d->kw) *
                        (double)(d->cin_alg > 0 ? d->cin_alg : d->Cin);
-  if (base_tile < YMI_DCNP_64x128 || base_tile > YMI_DCNP_128x256_W16) return YMI_EARG;
+  if (base_tile < YMI_DCNP_64x128 || base_tile > YMI_DCNP_256x128_W8T) return YMI_EARG;
   int rc;
   const int pr = ymi_internal_prof_begin(flops, tile_id, prof_kind, s);
   switch (base_tile) {                                   // <waves along M, waves along N, 32x32 tiles per wave along M, along N, ring>
@@ -597,7 +598,12 @@ int run_pipe(const ymi_conv_desc *d, const float *offmask, int ldo, int mask_is_
     case YMI_DCNP_192x128_W12: rc = launch_dcn<6, 2, 1, 2, 1>(p, plain, s); break;
     case YMI_DCNP_64x256_W8: rc = launch_dcn<2, 4, 1, 2, 1>(p, plain, s); break;
     case YMI_DCNP_96x256_W12: rc = launch_dcn<3, 4, 1, 2, 1>(p, plain, s); break;
-    default: rc = launch_dcn<4, 4, 1, 2, 1>(p, plain, s); break;   // YMI_DCNP_128x256_W16
+    case YMI_DCNP_128x256_W16: rc = launch_dcn<4, 4, 1, 2, 1>(p, plain, s); break;
+    // 64 x 64 wave tiles (a third fewer LDS fragment reads per MFMA, half the barriers per FLOP of a block of equal wave count):
+    // ordinary convolutions only — four gathered rows per thread would not fit the DCN path's register ring
+    case YMI_DCNP_128x256_W8T: rc = plain ? launch_dcn_k<2, 4, 2, 2, 1, true>(p, s) : YMI_EARG; break;
+    case YMI_DCNP_128x128_W4T: rc = plain ? launch_dcn_k<2, 2, 2, 2, 1, true>(p, s) : YMI_EARG; break;
+    default: rc = plain ? launch_dcn_k<4, 2, 2, 2, 1, true>(p, s) : YMI_EARG; break;   // YMI_DCNP_256x128_W8T
   }
   if (rc == YMI_OK && S > 1)
     rc = ymi_internal_splitk_fixup(d->split_ws, M * (long)d->Cout, S, M, d->Cout, g0.row_stride, g0.ptr, d->scale, d->bias,

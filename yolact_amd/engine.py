@@ -26,7 +26,7 @@ def _ceil(a, b):
 
 # ---- shipped tile / algorithm table ------------------------------------------------------------------------------
 SPLIT_DEFAULT = '2'   # default of YOLACT_AMD_SPLIT (see Plan.__init__): 0 exact-fp32 MFMA, 1 bf16x3, 2 fp16x2
-TUNE_GEN = 4          # bump whenever tile ids or kernel variants change meaning: older tables are ignored
+TUNE_GEN = 5          # bump whenever tile ids or kernel variants change meaning: older tables are ignored (5: pipelined kernel of csrc/dcn.hip)
 AMAX_SLOT_FLOATS = 16 * 64   # one magnitude-bound slot: YMI_AMAX_SUB sub-slots, YMI_AMAX_STRIDE floats apart (include/yolact_amd.h)
 TUNE_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tune')
 _table_cache = {}
@@ -38,8 +38,8 @@ def _read_table_file(path):
             doc = json.load(f)
     except (OSError, ValueError):
         return {}
-    if not isinstance(doc, dict) or doc.get('gen') != TUNE_GEN or doc.get('abi') != L.ABI_VERSION:
-        return {}
+    if not isinstance(doc, dict) or doc.get('gen') != TUNE_GEN or not isinstance(doc.get('abi'), int) or doc['abi'] > L.ABI_VERSION:
+        return {}       # (gen = meaning of the tile ids; a table written under an OLDER ABI of the same generation stays valid)
     return dict(doc.get('entries', {}))
 
 
@@ -982,7 +982,7 @@ class Plan:
                 and d.res_mode in (L.RES_NONE, L.RES_ADD))
 
     @staticmethod
-    def dcnp_candidates(d):
+    def dcnp_candidates(d, dcn=False):
         """(tile + 256 * split_k) candidates of the pipelined DCN kernel for a descriptor: every block tile unsplit, and — where a
         tile's grid alone leaves CUs idle (the 35x35 / 18x18 maps) — chunk-aligned K splits that bring the block count to 0.5 .. 2
         blocks per CU."""
@@ -990,7 +990,7 @@ class Plan:
         out = []
         for t, name in sorted(L.DCNP_TILES.items()):
             bm, bn = (int(v) for v in name[4:].split('w')[0].split('x'))
-            if bn > 128 and d.Cout < 256:
+            if (bn > 128 and d.Cout < 256) or (dcn and t in L.DCNP_PLAIN_ONLY):
                 continue
             tid = t | L.TILE_H2 | L.TILE_DCNP
             out.append(tid)
@@ -1040,7 +1040,7 @@ class Plan:
                     cands = cands + [t | spflag for t in cands if t in base_ok
                                      and (d.Cin % 32 == 0 or t in L.BASIC_TILES)]
                 if is_dcn and self.h2:       # the pipelined gather-GEMM of csrc/dcn.hip (fp16x2 plans)
-                    cands = cands + self.dcnp_candidates(d)
+                    cands = cands + self.dcnp_candidates(d, dcn=True)
                 if not is_dcn and self.h2 and self.pipe and self._pipe_ok(d):   # the same pipelined kernel as an ordinary convolution
                     cands = cands + self.dcnp_candidates(d)
                 if not is_dcn and self._splitk_ok(d) and self.splitk:
