@@ -126,7 +126,8 @@ def roofline(net, x, reps=3):
     # record kinds: 0/1/2 = one direct conv launch (loader id), 7 = a direct 1x1 launch on the pointwise loader (kernel
     # template LOADER 3); 3 / 4 = a whole Winograd F(2x2) / F(4x4) layer (input transform + 16- / 36-group GEMM + output
     # transform, ALGORITHMIC conv FLOPs); 5 / 6 = the Winograd GEMM launch alone (the FLOPs it executes).
-    # 9 = the pipelined DCNv2 gather-GEMM (csrc/dcn.hip).
+    # 9 = the pipelined DCNv2 gather-GEMM (csrc/dcn.hip: pipe_h2_k<..., PLAIN = false>), 10 = the same kernel as an ordinary 3x3 / 1x1
+    # convolution (PLAIN = true).
     # 8 = the fused ResNet stem launch (layout change + 7x7 conv + BN + ReLU + max-pool; the conv's algorithmic FLOPs).
     # Layer table / all_conv: kinds 0-4, 7 and 8.  Single-kernel roofline: kinds 0-2, 7, 8, 5 and 6.
     by_kernel, layers = {}, {}
@@ -171,7 +172,8 @@ def roofline(net, x, reps=3):
             li += 1
             lkey = ('winograd F(%dx%d,3x3) <gemm %s> (3 launches)' % (2 * kind.value - 4, 2 * kind.value - 4, tname)) \
                 if kind.value in (3, 4) else 'stem_pool_k<%s,conv 7x7/2 + BN + ReLU + max-pool 3x3/2 fused>' % tname if kind.value == 8 \
-                else 'dcn_h2_k<%s,pipelined gather>' % tname if kind.value == 9 \
+                else 'pipe_h2_k<%s,DCNv2 gather>' % tname if kind.value == 9 \
+                else 'pipe_h2_k<%s,convolution>' % tname if kind.value == 10 \
                 else 'conv_igemm_f32<%s,loader%d>' % (tname, 3 if kind.value == 7 else kind.value)
             la = layers.setdefault(names[li % nl], [0.0, fl.value, lkey])
             la[0] += ms.value / reps
@@ -180,7 +182,8 @@ def roofline(net, x, reps=3):
         if kind.value not in (3, 4):
             key = ('conv_igemm_f32<%s,winograd grouped GEMM>' % tname) if kind.value in (5, 6) else \
                 ('stem_pool_k<%s,fused stem>' % tname) if kind.value == 8 else \
-                ('dcn_h2_k<%s,pipelined gather>' % tname) if kind.value == 9 else \
+                ('pipe_h2_k<%s,DCNv2 gather>' % tname) if kind.value == 9 else \
+                ('pipe_h2_k<%s,convolution>' % tname) if kind.value == 10 else \
                 'conv_igemm_f32<%s,loader%d>' % (tname, 3 if kind.value == 7 else kind.value)
             a = by_kernel.setdefault(key, [0.0, 0.0, 0, 0.0, 0.0, 0.0])
             a[0] += ms.value; a[1] += fl.value; a[2] += 1; a[3] += nbytes
@@ -249,7 +252,7 @@ def roofline(net, x, reps=3):
                               'every conv-layer launch incl. the Winograd transforms; of %d layers %d run Winograd '
                               'F(2x2,3x3) (2.25x fewer multiplications) and %d F(4x4,3x3) (4x fewer), so this figure '
                               'can exceed what the matrix cores execute' % (len(layers), wino2, wino4)},
-        'engine': {'kernel': 'conv_igemm_f32<*> (every instantiation: direct loaders + grouped Winograd GEMM)',
+        'engine': {'kernel': 'conv_igemm_f32<*> + pipe_h2_k<*> (every instantiation: direct loaders, pipelined kernel, grouped Winograd GEMM)',
                    'ms_per_step': round(eng_ms / reps, 3),
                    'executed_tflops': round(sum(v[1] for v in by_kernel.values()) / (eng_ms * 1e-3) / 1e12, 2),
                    'frac': round(eng_ideal_ms / eng_ms, 4),
@@ -293,7 +296,7 @@ def traffic_from_profiles(kernel):
     inside this process, so the figure is STATIC: the committed summary of separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
     passes over this very command (FETCH_SIZE doubled per MI355X_MICROARCH.md; `tools/gpu_session.sh <name> traffic`).
     It is only reported when that summary was measured with the tile table this run uses (`tune_sha`), else null."""
-    for fn in ('r03_traffic.json', 'r02_traffic.json'):
+    for fn in ('r04_traffic.json', 'r03_traffic.json', 'r02_traffic.json'):
         path = os.path.join(ROOT, 'profiles', fn)
         if os.path.exists(path):
             with open(path) as f:

@@ -30,7 +30,7 @@ for st in "$@"; do
       for m in 1 0; do YOLACT_AMD_SPLIT=$m timeout 600 python tools/make_tune_table.py --only configs1_r50_b8 r50_b1 r50_b2 >> $O/tune.log 2>&1; done   # bf16x3 / exact-fp32 keys of configs[1]
       cp yolact_amd/tune/gfx950.json $O/gfx950.json; grep -E "plan|table" $O/tune.log | cut -c1-160 | tail -20 ;;
     tune1) timeout 900 python tools/make_tune_table.py --only configs1_r50_b8 r50_b1 r50_b2 --copy-to $O/gfx950.json > $O/tune.log 2>&1; grep -E "plan|table" $O/tune.log | cut -c1-160 ;;
-    pytest) timeout 2400 python -m pytest tests -m gpu -q --timeout 900 -rA ${arg:+-k "$arg"} > $O/pytest.log 2>&1; grep -E "passed|failed" $O/pytest.log | tail -3; grep -E "^FAILED|^ERROR" $O/pytest.log | head -20 ;;
+    pytest) timeout ${PYTEST_TIMEOUT:-2400} python -m pytest tests -m gpu -q --timeout 600 -rA ${arg:+-k "$arg"} > $O/pytest.log 2>&1; grep -E "passed|failed" $O/pytest.log | tail -3; grep -E "^FAILED|^ERROR" $O/pytest.log | head -20 ;;
     pytestf) timeout 1200 python -m pytest tests/$arg -m gpu -q --timeout 600 -rA -s > $O/pytest_${arg%.py}.log 2>&1; grep -E "passed|failed" $O/pytest_${arg%.py}.log | tail -3; grep -E "^FAILED|^ERROR" $O/pytest_${arg%.py}.log | head -20 ;;
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log ;;
     bench) timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --layers $arg > $O/bench.json 2> $O/bench_layers.txt; head -1 $O/bench.json | cut -c1-600 ;;
@@ -57,12 +57,12 @@ PY
       done; head -12 $O/kernel_stats_streams1.txt | cut -c1-200 ;;
     traffic)
       CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary"
-      (cd /tmp && YOLACT_AMD_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex conv_igemm -f csv -d $R/$O/fetch -- bash -c "cd $R && $CMD" > $R/$O/fetch.log 2>&1)
-      (cd /tmp && YOLACT_AMD_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --kernel-include-regex conv_igemm -f csv -d $R/$O/write -- bash -c "cd $R && $CMD" > $R/$O/write.log 2>&1)
+      (cd /tmp && YOLACT_AMD_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex "conv_igemm|pipe_h2_k" -f csv -d $R/$O/fetch -- bash -c "cd $R && $CMD" > $R/$O/fetch.log 2>&1)
+      (cd /tmp && YOLACT_AMD_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --kernel-include-regex "conv_igemm|pipe_h2_k" -f csv -d $R/$O/write -- bash -c "cd $R && $CMD" > $R/$O/write.log 2>&1)
       python tools/traffic_summary.py $O/fetch $O/write > $O/traffic.json 2> $O/traffic.err; head -c 600 $O/traffic.json
       find $O -name "*counter_collection.csv" -size +4M -delete ;;
     pmc)
-      (cd /tmp && YOLACT_AMD_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --kernel-include-regex conv_igemm -f csv -d $R/$O/pmc1 -- bash -c "cd $R && python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary" > $R/$O/pmc1.log 2>&1)
+      (cd /tmp && YOLACT_AMD_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --kernel-include-regex "conv_igemm|pipe_h2_k|wino|stem_pool" -f csv -d $R/$O/pmc1 -- bash -c "cd $R && python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary" > $R/$O/pmc1.log 2>&1)
       python tools/pmc_summary.py $O/pmc1 > $O/pmc_plan_p1.tsv 2> $O/pmc.err; head -20 $O/pmc_plan_p1.tsv | cut -c1-200
       find $O -name "*counter_collection.csv" -size +4M -delete ;;
     pmcw) # wave-level counters of the Winograd GEMM variants on proto.8 (one pass, counters only)
@@ -79,11 +79,12 @@ PY
       f=$(find $O/b1_1 -name "*kernel_stats.csv" | head -1); head -25 $f | cut -c1-150 > $O/b1_kernel_stats_head.txt; cat $O/b1_kernel_stats_head.txt ;;
     avail) (cd /tmp && timeout 120 rocprofv3 --list-avail > $R/$O/avail.txt 2>&1); grep -cE "" $O/avail.txt; grep -oE "\b(TA_[A-Z_]+|TCP_[A-Z_0-9]+|TCC_(HIT|MISS|REQ|READ|EA0_RDREQ)[A-Z_0-9]*|SQ_(WAIT|ACTIVE|INSTS|BUSY|WAVE)[A-Z_0-9]*|SQ_LDS[A-Z_]*|FETCH_SIZE|WRITE_SIZE|L2CacheHit|MemUnitBusy|MemUnitStalled|TA_BUSY_avr|LDSBankConflict)\b" $O/avail.txt | sort -u | tr '\n' ' ' ;;
     dcnpmc) # counters of the pipelined DCN kernel (csrc/dcn.hip) on three representative layers: wave states, then the memory pipe, then bytes
-      PCMD="python tools/dcn_probe.py --tiles ${arg:-dcnp64x128w8} --layers layer1.1,layer2.1,layer3.1 --reps 2"
-      (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-include-regex dcn_h2_k -f csv -d $R/$O/dcnpmc1 -- bash -c "cd $R && $PCMD" > $R/$O/dcnpmc1.log 2>&1)
-      (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-include-regex dcn_h2_k -f csv -d $R/$O/dcnpmc2 -- bash -c "cd $R && $PCMD" > $R/$O/dcnpmc2.log 2>&1)
-      (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TA_BUSY_avr TA_TA_BUSY_sum --kernel-include-regex dcn_h2_k -f csv -d $R/$O/dcnpmc3 -- bash -c "cd $R && $PCMD" > $R/$O/dcnpmc3.log 2>&1)
-      for k in 1 2 3; do python tools/pmc_summary.py $O/dcnpmc$k > $O/pmc_dcn_p$k.tsv 2> $O/dcnpmc$k.err; cat $O/pmc_dcn_p$k.tsv | cut -c1-420; tail -3 $O/dcnpmc$k.log | cut -c1-200; done
+      PCMD="python tools/dcn_probe.py --tiles ${arg:-dcnp160x128w10,dcnp128x256w16/k3,dcnp128x256w16/k6} --layers layer1.1,layer2.1,layer3.1 --reps 2"
+      (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-include-regex pipe_h2_k -f csv -d $R/$O/dcnpmc1 -- bash -c "cd $R && $PCMD" > $R/$O/dcnpmc1.log 2>&1)
+      (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-include-regex pipe_h2_k -f csv -d $R/$O/dcnpmc2 -- bash -c "cd $R && $PCMD" > $R/$O/dcnpmc2.log 2>&1)
+      (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-include-regex pipe_h2_k -f csv -d $R/$O/dcnpmc3 -- bash -c "cd $R && $PCMD" > $R/$O/dcnpmc3.log 2>&1)
+      (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum --kernel-include-regex pipe_h2_k -f csv -d $R/$O/dcnpmc4 -- bash -c "cd $R && $PCMD" > $R/$O/dcnpmc4.log 2>&1)
+      for k in 1 2 3 4; do python tools/pmc_summary.py $O/dcnpmc$k > $O/pmc_dcn_p$k.tsv 2> $O/dcnpmc$k.err; cat $O/pmc_dcn_p$k.tsv | cut -c1-420; tail -3 $O/dcnpmc$k.log | cut -c1-200; done
       find $O -name "*counter_collection.csv" -size +4M -delete ;;
     dcnabl) # diagnostics build of csrc/dcn.hip only (YMI_DCN_ABLATE switches), then the ablation table of tools/dcn_probe.py
       (cd yolact_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-value -I../../include -DYMI_DIAGNOSTICS=1 -c dcn.hip -o /tmp/dcn_diag.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls *.o | grep -v '^dcn.o$') /tmp/dcn_diag.o -o ../libyolact_amd.so) > $O/dcnabl_build.log 2>&1; tail -2 $O/dcnabl_build.log

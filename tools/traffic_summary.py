@@ -14,6 +14,15 @@ TILES = {(2, 2, 1, 2, 2, 2): '128x128', (2, 2, 1, 2, 1, 2): '128x64', (2, 2, 1, 
          (4, 2, 1, 1, 2, 4): '128x128w8s4'}
 
 
+# pipe_h2_k<WM, WN, TM, TN, RING, PLAIN> (csrc/dcn.hip) -> the tile names of yolact_amd/_lib.py DCNP_TILES
+PIPE = {(2, 2, 1, 2, 2): 'dcnp64x128', (2, 4, 1, 1, 2): 'dcnp64x128w8', (2, 2, 1, 1, 2): 'dcnp64x64', (4, 2, 1, 2, 2): 'dcnp128x128w8',
+        (4, 2, 1, 1, 2): 'dcnp128x64w8', (1, 4, 1, 1, 2): 'dcnp32x128', (3, 2, 1, 2, 1): 'dcnp96x128w6', (4, 2, 1, 2, 1): 'dcnp128x128w8r1',
+        (5, 2, 1, 2, 1): 'dcnp160x128w10', (6, 2, 1, 2, 1): 'dcnp192x128w12', (2, 4, 1, 2, 1): 'dcnp64x256w8',
+        (3, 4, 1, 2, 1): 'dcnp96x256w12', (4, 4, 1, 2, 1): 'dcnp128x256w16', (2, 4, 2, 2, 1): 'dcnp128x256w8t',
+        (2, 2, 2, 2, 1): 'dcnp128x128w4t', (4, 2, 2, 2, 1): 'dcnp256x128w8t'}
+CONV = ('conv_igemm', 'pipe_h2_k')
+
+
 def grouped_dispatches(counter_csv):
     """Dispatch ids of launches with gridDim.y > 1 (the grouped Winograd GEMMs), from the kernel trace of the same run:
     the pointwise loader (template LOADER 3) serves both the 1x1 convolutions and the grouped GEMMs."""
@@ -28,7 +37,7 @@ def grouped_dispatches(counter_csv):
 def steady_rows(f, counter):
     """Rows of one process in dispatch order, cut to the trailing part that repeats with the plan's period (the bench
     passes), so that launches made while autotuning (other tiles, other layers) do not pollute the per-kernel means."""
-    rows = [r for r in csv.DictReader(open(f)) if r['Counter_Name'] == counter and 'conv_igemm' in r['Kernel_Name']]
+    rows = [r for r in csv.DictReader(open(f)) if r['Counter_Name'] == counter and any(c in r['Kernel_Name'] for c in CONV)]
     rows.sort(key=lambda r: int(r['Dispatch_Id']))
     names = [r['Kernel_Name'] for r in rows]
     for L in range(20, 400):
@@ -46,6 +55,13 @@ def collect(root, counter):
     for f in files[-1:]:                      # the newest run only (gpurun_out/ accumulates earlier sessions)
         grouped = grouped_dispatches(f)
         for r in steady_rows(f, counter):
+            mp = re.search(r'pipe_h2_k<(\d+), (\d+), (\d+), (\d+), (\d+), (true|false|\(bool\)1|\(bool\)0|1|0)>', r['Kernel_Name'])
+            if mp:
+                vp = tuple(int(x) for x in mp.groups()[:5])
+                plain = mp.group(6) in ('true', '(bool)1', '1')
+                a = acc['pipe_h2_k<%s,%s>' % (PIPE.get(vp, str(vp)), 'convolution' if plain else 'DCNv2 gather')]
+                a[0] += float(r['Counter_Value']); a[1] += 1
+                continue
             m = re.search(r'conv_igemm_f32<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>', r['Kernel_Name'])
             if not m:
                 continue

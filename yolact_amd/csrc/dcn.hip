@@ -82,7 +82,7 @@ constexpr int dcn_occupancy() {     // blocks per CU: LDS-limited (at most two),
 // consuming waves run a split-free MFMA loop), 6 .. 16-wave blocks of 32 x 64 wave tiles, 256-column tiles.
 template <int WM, int WN, int TM, int TN, int RING, bool PLAIN>
 __global__ __launch_bounds__(64 * WM * WN, (dcn_occupancy<WM, WN, TM, TN, RING, PLAIN>() * (WM * WN) + 3) / 4)
-void dcn_h2_k(const DcnParams p) {
+void pipe_h2_k(const DcnParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // (host pass: empty body, see conv_igemm.hip)
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NW = WM * WN, NT = 64 * NW;
   constexpr int RPP = NT / 8, RA = BM / RPP;            // gather: 8 lanes (32 channels) per row, RA rows per thread per chunk
@@ -218,7 +218,8 @@ void dcn_h2_k(const DcnParams p) {
   const int kc0 = blockIdx.y * p.nk_split;
   const int cpt = p.Cin / BK;                           // chunks per tap
   int g_tap = kc0 / cpt, g_c = (kc0 - g_tap * cpt) * BK;   // (tap, first channel) of the next chunk to request
-  int g_left = p.nk_split;                              // chunks of the range still to request
+  const int my_nk = (p.nk - kc0) < p.nk_split ? (p.nk - kc0) : p.nk_split;   // (the last range may be shorter)
+  int g_left = my_nk;                                   // chunks of the range still to request
   bool g_first = true;
   auto tap_step = [&]() {                               // start of a chunk's requests: resolve the geometry at a tap boundary
     if (g_c == 0 || g_first) {                          // (or at the start of a range that begins inside a tap)
@@ -405,7 +406,7 @@ void dcn_h2_k(const DcnParams p) {
   // ---- main loop: RING steps per trip (the ring slot is a compile-time index) -----------------------------------------------
   // (RING == 2: both steps unconditionally inside the trip: with `if (st + 1 < nk)` around the second one the CFG has a path from
   // the first step straight back to itself, and the compiler's vmcnt for the ring registers drops from ~16 to 3 — seen in the ISA)
-  const int nk = p.nk_split;
+  const int nk = my_nk;
   if constexpr (RING == 2) {
     int st = 0;
     for (; st + 1 < nk; st += 2) {
@@ -498,7 +499,7 @@ int launch_dcn_k(DcnParams p, hipStream_t s) {
   int dyn = 0;
   {
     constexpr int LDS_PER_CU = 160 * 1024, static_lds = dcn_lds_floats<WM, WN, TM, TN, RING>() * 4;
-    const int occ = dcn_occupancy<WM, WN, TM, TN, RING, PLAIN>(), k = (grid * (p.nk / p.nk_split) + 255) / 256;
+    const int occ = dcn_occupancy<WM, WN, TM, TN, RING, PLAIN>(), k = (grid * ((p.nk + p.nk_split - 1) / p.nk_split) + 255) / 256;
 #ifdef YMI_DIAGNOSTICS
     const bool cap_on = !(p.abl & 64);
 #else
@@ -509,8 +510,8 @@ int launch_dcn_k(DcnParams p, hipStream_t s) {
       if (want > static_lds && want <= LDS_PER_CU / k) dyn = want - static_lds;
     }
   }
-  const int splits = p.nk / p.nk_split;
-  hipLaunchKernelGGL((dcn_h2_k<WM, WN, TM, TN, RING, PLAIN>), dim3(grid, splits), dim3(64 * WM * WN), dyn, s, p);
+  const int splits = (p.nk + p.nk_split - 1) / p.nk_split;
+  hipLaunchKernelGGL((pipe_h2_k<WM, WN, TM, TN, RING, PLAIN>), dim3(grid, splits), dim3(64 * WM * WN), dyn, s, p);
   return ymi_launch_status();
 }
 
@@ -552,7 +553,8 @@ int run_pipe(const ymi_conv_desc *d, const float *offmask, int ldo, int mask_is_
   const int nk = d->Kpad / BK;
   if (nk < 2) return YMI_EARG;
   if (S > 1) {
-    if (S > 16 || nk % S != 0 || nk / S < 2) return YMI_EARG;
+    // (ranges of ceil(nk / S) chunks, the last one shorter when S does not divide nk; every range non-empty)
+    if (S > 16 || (nk + S - 1) / S < 2 || ((nk + S - 1) / S) * (S - 1) >= nk) return YMI_EARG;
     if (!d->split_ws || !d->winv_h2) return YMI_ENULL;
     if ((((uintptr_t)d->split_ws) & 15) || M * (long)d->Cout >= (1L << 29)) return YMI_ESHAPE;
   }
@@ -563,7 +565,7 @@ int run_pipe(const ymi_conv_desc *d, const float *offmask, int ldo, int mask_is_
   p.stride = d->stride; p.Kpad = d->Kpad; p.ldo = ldo; p.ldy = g0.row_stride; p.act = g0.act; p.mask_is_prob = mask_is_prob;
   p.taps = d->kh * d->kw; p.kw = d->kw; p.pad = d->pad;
   p.res = d->res_mode == YMI_RES_ADD ? d->res : nullptr; p.res_ld = d->res_ld; p.res_after_act = d->res_after_act;
-  p.M = (int)M; p.HoWo = (int)HoWo; p.tiles_n = 0; p.nk = nk; p.nk_split = nk / S; p.y_gs = 0;
+  p.M = (int)M; p.HoWo = (int)HoWo; p.tiles_n = 0; p.nk = nk; p.nk_split = (nk + S - 1) / S; p.y_gs = 0;
   p.x_bytes = (unsigned)((size_t)d->B * d->H * d->W * d->ldx * sizeof(float));
   p.om_bytes = plain ? 0u : (unsigned)((size_t)M * ldo * sizeof(float));
   p.w_plane = (unsigned)((((long)d->Cout + 127) / 128 * 128) * d->Kpad * 2L);

@@ -962,7 +962,8 @@ class Plan:
         if S > 1:
             is_dcn = fn is self.lib.ymi_dcn_v2_forward_f32
             if tile & L.TILE_DCNP:
-                if (d.Kpad // 32) % S:
+                nk_ = d.Kpad // 32
+                if -(-nk_ // S) * (S - 1) >= nk_:
                     return -1
             elif is_dcn or not self._splitk_ok(d) or (d.Kpad // 32) % S:
                 return -1
@@ -995,9 +996,10 @@ class Plan:
             tid = t | L.TILE_H2 | L.TILE_DCNP
             out.append(tid)
             blocks = -(-M // bm) * -(-d.Cout // bn)
-            if blocks < 200 and d.Cout % 4 == 0:
-                for S in (2, 3, 4, 6, 8, 9, 12, 16):
-                    if nk % S == 0 and nk // S >= 4 and 128 <= blocks * S <= 520:
+            if blocks < 400 and d.Cout % 4 == 0:
+                for S in (2, 3, 4, 5, 6, 8, 9, 12, 16):
+                    per = -(-nk // S)                     # chunks per range (the last range may be shorter, never empty)
+                    if per >= 4 and per * (S - 1) < nk and 128 <= blocks * S <= 1100:
                         out.append(tid + 256 * S)
         return out
 
