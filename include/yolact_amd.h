@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define YMI_ABI_VERSION 4
+#define YMI_ABI_VERSION 5
 
 /* negative return codes (ymi_strerror) */
 #define YMI_EFORMAT (-4)       /* corrupt or truncated input stream (ymi_jpeg_*) */
@@ -94,7 +94,9 @@ typedef struct {
   const float *winv_h2;
   const float *x_amax;
   float *y_amax;        /* any tile: DEVICE slot (same layout as x_amax) or NULL: raised atomically so that its maximum becomes
-                         * max|y| over everything this launch writes */
+                         * max|y| over everything this launch writes.  nseg > 1 (ABI 5): nseg CONSECUTIVE slots (YMI_AMAX_SUB *
+                         * YMI_AMAX_STRIDE floats apart), segment k raises slot k — the segments of one launch may be different
+                         * tensors with different consumers (the merged head0.upfeature + proto_net[0] launch) */
   float x_amax_mul;     /* static factor on *x_amax; 0 = 1 */
   int32_t _pad3;
 } ymi_conv_desc;

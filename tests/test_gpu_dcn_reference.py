@@ -85,6 +85,8 @@ def test_dcn_hip_and_oracle_match_reference_kernel(shape, stride):
     e_p = {}
     if Co % 4 == 0:
         for t in sorted(L.DCNP_TILES):
+            if t in L.DCNP_PLAIN_ONLY:               # 64x64 wave tiles: ordinary convolutions only
+                continue
             hp = run_conv(x, w, b, None, stride, 1, dcn_offmask=om, tile=t | L.TILE_H2 | L.TILE_DCNP)
             e_p[L.DCNP_TILES[t]] = (hp.double() - ref).abs().max().item()
         print('    pipelined: ' + '  '.join('%s %.2e' % kv for kv in e_p.items()))

@@ -29,6 +29,9 @@ TILES = sorted(L.TILE_NAMES)
 def test_conv_plain(shape, tile):
     from gpu_utils import run_conv, rel_err
     B, Cin, H, W, Cout, k, s, p = shape
+    if (tile & L.TILE_DCNP) and Cout % 4:
+        pytest.skip('the pipelined kernel (csrc/dcn.hip) stores float4 rows: Cout % 4 == 0 (an explicit request is refused, see '
+                    'test_dcn_pipelined_rejects_what_it_cannot_run)')
     g = _g(B * 1000 + Cin + Cout + k)
     x = torch.randn(B, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
@@ -552,9 +555,10 @@ def test_merged_two_output_conv(mode):
     g = _g(77)
     B, Cin, H, W, C1, C2 = 2, 64, 11, 9, 64, 32
     x = torch.randn(B, Cin, H, W, generator=g)
-    w1, w2 = torch.randn(C1, Cin, 3, 3, generator=g) / 24, torch.randn(C2, Cin, 3, 3, generator=g) / 24
+    w1, w2 = torch.randn(C1, Cin, 3, 3, generator=g) / 24, torch.randn(C2, Cin, 3, 3, generator=g) * 40      # the second tensor is ~1000x larger
     b1, b2 = torch.randn(C1, generator=g), torch.randn(C2, generator=g)
     wcat, bcat = torch.cat([w1, w2]), torch.cat([b1, b2])
+    amax = torch.zeros(3 * 1024, device=DEV)       # two consecutive magnitude-bound slots (+ a guard slot): one per segment (ABI 5)
     pk = Packed(wcat, bcat, None, 1, 1, None, DEV)
     xd = nhwc(x).to(DEV)
     y1 = torch.full((B, H, W, C1), float('nan'), device=DEV)
@@ -568,6 +572,7 @@ def test_merged_two_output_conv(mode):
         d.kh, d.kw, d.stride, d.pad, d.Kpad = 3, 3, 1, 1, pk.Kpad
         d.nseg, d.tile = 2, L.TILE_64x64 | x3
         d.seg[0], d.seg[1] = segs
+        d.y_amax = amax.data_ptr()
         if x3:
             d.w_x3 = pk.w3().data_ptr()
         L.check(L.lib().ymi_conv2d_nhwc_f32(C.byref(d), L.stream_ptr()), 'merged direct')
@@ -583,6 +588,7 @@ def test_merged_two_output_conv(mode):
         d.B, d.H, d.W, d.C, d.Cout, d.m, d.nseg = B, H, W, Cin, C1 + C2, m, 2
         d.tile = L.TILE_64x64 | x3
         d.seg[0], d.seg[1] = segs
+        d.y_amax = amax.data_ptr()
         if x3:
             d.u_x3 = wp.u3().data_ptr()
         L.check(L.lib().ymi_conv3x3_winograd_f32(C.byref(d), L.stream_ptr()), 'merged winograd')
@@ -591,6 +597,10 @@ def test_merged_two_output_conv(mode):
     r1, r2 = F.relu(F.conv2d(x, w1, b1, 1, 1)), F.relu(F.conv2d(x, w2, b2, 1, 1))
     from gpu_utils import rel_err
     assert rel_err(nchw(y1.cpu()), r1) < tol and rel_err(nchw(y2.cpu()), r2) < tol
+    # each segment raises ITS slot to max|y| of that tensor (a shared bound would report the larger one for both)
+    bounds = amax.view(3, 1024).amax(1).cpu().tolist()
+    assert bounds[0] == y1.abs().max().item() and bounds[1] == y2.abs().max().item() and bounds[2] == 0.0
+    assert bounds[1] > 100 * bounds[0]
 
 
 @pytest.mark.parametrize('base', [3, 5, 1, 8, 6, 16, 17, 19, 21])

@@ -146,20 +146,20 @@ __device__ __forceinline__ void bilin_coord(int dst, float scale, int in_size, i
 // Returns the magnitude bound (max |value written|) of this thread; the caller commits it at a CONVERGED point of the wave
 // (the reduction uses cross-lane shuffles, so it must not sit behind the early exit of the lanes past Cout).
 template <int BM, int BN, int WK, int RPT, int RSTEP, bool RES_PREFETCH>
-__device__ __forceinline__ float epilogue_general_rows(const KParams &p, const float *es, f32x4 sc, f32x4 bi, const f32x4 *rpre,
-                                                    int m0, int n, int c4, int rbase, bool vec_res, float invA) {
+__device__ __forceinline__ void epilogue_general_rows(const KParams &p, const float *es, f32x4 sc, f32x4 bi, const f32x4 *rpre,
+                                                   int m0, int n, int c4, int rbase, bool vec_res, float invA, float (&amax)[3]) {
   constexpr int ELD = BN + 4;
   const ymi_conv_desc &d = p.d;
-  if (n >= d.Cout) return 0.f;
+  if (n >= d.Cout) return;
   // The segment table lives in the kernel arguments; resolve it with compile-time indices + selects (indexing
   // d.seg[] with a per-lane value turns into dependent per-lane global loads).
-  struct SegR { float *ptr; int64_t bs; int rs, act, n0; };
+  struct SegR { float *ptr; int64_t bs; int rs, act, n0, idx; };
   auto seg_of = [&](int nn) -> SegR {   // segment holding output channel nn (ptr == nullptr: none)
-    SegR r = {nullptr, 0, 0, 0, 0};
+    SegR r = {nullptr, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int s = 0; s < 3; ++s)
       if (s < d.nseg && nn >= d.seg[s].n0 && nn < d.seg[s].n1 && nn < d.Cout)
-        r = SegR{d.seg[s].ptr, d.seg[s].batch_stride, d.seg[s].row_stride, d.seg[s].act, d.seg[s].n0};
+        r = SegR{d.seg[s].ptr, d.seg[s].batch_stride, d.seg[s].row_stride, d.seg[s].act, d.seg[s].n0, s};
     return r;
   };
   SegR se[4];
@@ -168,7 +168,7 @@ __device__ __forceinline__ float epilogue_general_rows(const KParams &p, const f
   // vector store only if all 4 channels live in one aligned segment
   const bool vec_out = se[0].ptr != nullptr && se[0].ptr == se[3].ptr && ((n - se[0].n0) & 3) == 0 && (se[0].rs & 3) == 0 &&
                        (se[0].bs & 3) == 0 && (((uintptr_t)se[0].ptr) & 15) == 0;
-  float amax = 0.f;                     // magnitude bound of what this thread writes (ymi_conv_desc.y_amax)
+  // magnitude bounds of what this thread writes, one per segment (ymi_conv_desc.y_amax: nseg consecutive slots)
   float rscale_h = 0.f, rscale_w = 0.f;
   if (d.res_mode == YMI_RES_BILINEAR) {
     rscale_h = (float)d.res_H / (float)d.Ho;
@@ -216,7 +216,13 @@ __device__ __forceinline__ float epilogue_general_rows(const KParams &p, const f
     for (int e = 0; e < 4; ++e) o[e] = act_apply(o[e], se[e].act);
     if (d.res_after_act) o += rv;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) if (se[e].ptr != nullptr) amax = fmaxf(amax, fabsf(o[e]));
+    for (int e = 0; e < 4; ++e)
+      if (se[e].ptr != nullptr) {
+        const float a = fabsf(o[e]);
+        amax[0] = se[e].idx == 0 ? fmaxf(amax[0], a) : amax[0];
+        amax[1] = se[e].idx == 1 ? fmaxf(amax[1], a) : amax[1];
+        amax[2] = se[e].idx == 2 ? fmaxf(amax[2], a) : amax[2];
+      }
     if (vec_out) {
       *reinterpret_cast<f32x4 *>(se[0].ptr + (size_t)b * se[0].bs + (size_t)pix * se[0].rs + (n - se[0].n0)) = o;
     } else {
@@ -225,14 +231,20 @@ __device__ __forceinline__ float epilogue_general_rows(const KParams &p, const f
         if (se[e].ptr != nullptr) se[e].ptr[(size_t)b * se[e].bs + (size_t)pix * se[e].rs + (n + e - se[e].n0)] = o[e];
     }
   }
-  return amax;
 }
 
+// (per-segment bounds, ABI 5: segment k of a multi-segment launch raises slot k of nseg consecutive slots — see csrc/winograd.hip)
 template <int BM, int BN, int WK, int RPT, int RSTEP, bool RES_PREFETCH>
 __device__ __forceinline__ void epilogue_general(const KParams &p, const float *es, f32x4 sc, f32x4 bi, const f32x4 *rpre,
                                               int m0, int n, int c4, int rbase, bool vec_res, float invA, const ymi_amax_pre &apre) {
-  const float am = epilogue_general_rows<BM, BN, WK, RPT, RSTEP, RES_PREFETCH>(p, es, sc, bi, rpre, m0, n, c4, rbase, vec_res, invA);
-  if (p.d.y_amax) ymi_amax_finish(apre, am);
+  float am[3] = {0.f, 0.f, 0.f};
+  epilogue_general_rows<BM, BN, WK, RPT, RSTEP, RES_PREFETCH>(p, es, sc, bi, rpre, m0, n, c4, rbase, vec_res, invA, am);
+  if (p.d.y_amax) {
+    constexpr int SLOT = YMI_AMAX_SUB * YMI_AMAX_STRIDE;
+    ymi_amax_finish(apre, am[0]);
+    if (p.d.nseg > 1) ymi_amax_finish(ymi_amax_prefetch(p.d.y_amax + SLOT), am[1]);
+    if (p.d.nseg > 2) ymi_amax_finish(ymi_amax_prefetch(p.d.y_amax + 2 * SLOT), am[2]);
+  }
 }
 
 // LOADER: 0 = Cin % 32 == 0 (a K chunk lies inside one filter tap; tap is block-uniform)

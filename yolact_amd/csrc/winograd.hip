@@ -188,6 +188,24 @@ __device__ __forceinline__ SegVec seg_vec_setup(const SegTab &st, int k, const f
   for (int e = 0; e < 4; ++e) { v.sc[e] = scale ? scale[n + e] : 1.f; v.bi[e] = bias ? bias[n + e] : 0.f; }
   return v;
 }
+
+// Per-segment magnitude bounds (ABI 5): a launch with nseg > 1 segments raises nseg CONSECUTIVE slots (YMI_AMAX_SUB * YMI_AMAX_STRIDE
+// floats apart), segment k -> slot k.  One shared bound was wrong for the merged head0.upfeature + proto_net[0] launch: its two
+// halves are different tensors with different consumers, and a large proto_net[0] channel inflated the bound — hence coarsened the
+// fp16x2 scale — of the head's input (tests/test_gpu_batch_parity.py test_outlier_channels_end_to_end_at_batch8).
+constexpr int YMI_AMAX_SLOT = YMI_AMAX_SUB * YMI_AMAX_STRIDE;
+__device__ __forceinline__ void seg_amax_add(float (&am)[3], int k, float v) {
+  am[0] = k == 0 ? fmaxf(am[0], v) : am[0];
+  am[1] = k == 1 ? fmaxf(am[1], v) : am[1];
+  am[2] = k == 2 ? fmaxf(am[2], v) : am[2];
+}
+__device__ __forceinline__ void seg_amax_commit(float *y_amax, int nseg, const ymi_amax_pre &apre0, const float (&am)[3]) {
+  if (!y_amax) return;
+  ymi_amax_finish(apre0, am[0]);
+  if (nseg > 1) ymi_amax_finish(ymi_amax_prefetch(y_amax + YMI_AMAX_SLOT), am[1]);
+  if (nseg > 2) ymi_amax_finish(ymi_amax_prefetch(y_amax + 2 * YMI_AMAX_SLOT), am[2]);
+}
+
 __device__ __forceinline__ float seg_vec_store(const SegVec &sv, f32x4 v, long b, long pix) {
   v = v * sv.sc + sv.bi;
   if (sv.act <= YMI_ACT_LEAKY01) {      // none / ReLU / LeakyReLU: max(x, slope x)
@@ -205,7 +223,7 @@ __device__ __forceinline__ float seg_vec_store(const SegVec &sv, f32x4 v, long b
 __global__ __launch_bounds__(256) void wino_out_seg_k(const float *__restrict__ Mm, const SegTab st,
                                                       const float *__restrict__ scale, const float *__restrict__ bias,
                                                       int Ho, int Wo, int N4, int Cout, int th, int tw, long T, long total, float *__restrict__ y_amax) {
-  float am = 0.f;
+  float am[3] = {0.f, 0.f, 0.f};
   const ymi_amax_pre apre = ymi_amax_prefetch(y_amax);
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256u) {   // 32-bit index math
     const unsigned tu = i / (unsigned)N4, ru = tu / (unsigned)tw, bu = ru / (unsigned)th;          // (total < 2^31, host-checked;
@@ -236,7 +254,7 @@ __global__ __launch_bounds__(256) void wino_out_seg_k(const float *__restrict__ 
 #pragma unroll
         for (int ix = 0; ix < 2; ++ix) {
           const int oy = 2 * ty + iy, ox = 2 * tx + ix;
-          if (oy < Ho && ox < Wo) am = fmaxf(am, seg_vec_store(sv, o[iy][ix], b, (long)oy * Wo + ox));
+          if (oy < Ho && ox < Wo) seg_amax_add(am, kv, seg_vec_store(sv, o[iy][ix], b, (long)oy * Wo + ox));
         }
       continue;
     }
@@ -245,11 +263,11 @@ __global__ __launch_bounds__(256) void wino_out_seg_k(const float *__restrict__ 
       const int n = n4 * 4 + e;
       if (n >= Cout) continue;
       // segment of channel n: compile-time indices + selects (the table lives in SGPRs)
-      float *ptr = nullptr; long bs = 0; int rs = 0, act = 0, n0 = 0;
+      float *ptr = nullptr; long bs = 0; int rs = 0, act = 0, n0 = 0, ks = 0;
 #pragma unroll
       for (int k = 0; k < 3; ++k)
         if (k < st.nseg && n >= st.seg[k].n0 && n < st.seg[k].n1) {
-          ptr = st.seg[k].ptr; bs = st.seg[k].batch_stride; rs = st.seg[k].row_stride; act = st.seg[k].act; n0 = st.seg[k].n0;
+          ptr = st.seg[k].ptr; bs = st.seg[k].batch_stride; rs = st.seg[k].row_stride; act = st.seg[k].act; n0 = st.seg[k].n0; ks = k;
         }
       if (!ptr) continue;
       const float sc = scale ? scale[n] : 1.f, bi = bias ? bias[n] : 0.f;
@@ -262,13 +280,13 @@ __global__ __launch_bounds__(256) void wino_out_seg_k(const float *__restrict__ 
           const int ox = 2 * tx + ix;
           if (ox >= Wo) continue;
           const float val = wino_act(o[iy][ix][e] * sc + bi, act);
-          am = fmaxf(am, fabsf(val));
+          seg_amax_add(am, ks, fabsf(val));
           ptr[b * bs + ((long)oy * Wo + ox) * rs + (n - n0)] = val;
         }
       }
     }
   }
-  if (y_amax) ymi_amax_finish(apre, am);
+  seg_amax_commit(y_amax, st.nseg, apre, am);
 }
 
 // ---- F(4x4, 3x3): 36 multiplications per 4x4 output tile instead of 144 (4x fewer MFMA FLOPs than direct, 1.78x fewer
@@ -451,7 +469,7 @@ __global__ __launch_bounds__(256) void wino43_out_k(const float *__restrict__ Mm
 __global__ __launch_bounds__(256) void wino43_out_seg_k(const float *__restrict__ Mm, const SegTab st,
                                                         const float *__restrict__ scale, const float *__restrict__ bias,
                                                         int Ho, int Wo, int N4, int Cout, int th, int tw, long T, long total, float *__restrict__ y_amax) {
-  float am = 0.f;
+  float am[3] = {0.f, 0.f, 0.f};
   const ymi_amax_pre apre = ymi_amax_prefetch(y_amax);
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256u) {   // 32-bit index math
     const unsigned tu = i / (unsigned)N4, ru = tu / (unsigned)tw, bu = ru / (unsigned)th;          // (total < 2^31, host-checked;
@@ -467,7 +485,7 @@ __global__ __launch_bounds__(256) void wino43_out_seg_k(const float *__restrict_
 #pragma unroll
         for (int ix = 0; ix < 4; ++ix) {
           const int oy = 4 * ty + iy, ox = 4 * tx + ix;
-          if (oy < Ho && ox < Wo) am = fmaxf(am, seg_vec_store(sv, o[iy][ix], b, (long)oy * Wo + ox));
+          if (oy < Ho && ox < Wo) seg_amax_add(am, kv, seg_vec_store(sv, o[iy][ix], b, (long)oy * Wo + ox));
         }
       continue;
     }
@@ -475,11 +493,11 @@ __global__ __launch_bounds__(256) void wino43_out_seg_k(const float *__restrict_
     for (int e = 0; e < 4; ++e) {
       const int n = n4 * 4 + e;
       if (n >= Cout) continue;
-      float *ptr = nullptr; long bs = 0; int rs = 0, act = 0, n0 = 0;
+      float *ptr = nullptr; long bs = 0; int rs = 0, act = 0, n0 = 0, ks = 0;
 #pragma unroll
       for (int k = 0; k < 3; ++k)
         if (k < st.nseg && n >= st.seg[k].n0 && n < st.seg[k].n1) {
-          ptr = st.seg[k].ptr; bs = st.seg[k].batch_stride; rs = st.seg[k].row_stride; act = st.seg[k].act; n0 = st.seg[k].n0;
+          ptr = st.seg[k].ptr; bs = st.seg[k].batch_stride; rs = st.seg[k].row_stride; act = st.seg[k].act; n0 = st.seg[k].n0; ks = k;
         }
       if (!ptr) continue;
       const float sc = scale ? scale[n] : 1.f, bi = bias ? bias[n] : 0.f;
@@ -492,13 +510,13 @@ __global__ __launch_bounds__(256) void wino43_out_seg_k(const float *__restrict_
           const int ox = 4 * tx + ix;
           if (ox >= Wo) continue;
           const float val = wino_act(o[iy][ix][e] * sc + bi, act);
-          am = fmaxf(am, fabsf(val));
+          seg_amax_add(am, ks, fabsf(val));
           ptr[b * bs + ((long)oy * Wo + ox) * rs + (n - n0)] = val;
         }
       }
     }
   }
-  if (y_amax) ymi_amax_finish(apre, am);
+  seg_amax_commit(y_amax, st.nseg, apre, am);
 }
 
 unsigned grid_for(long total) {

@@ -140,6 +140,21 @@ class Packed:
         self.scale = scale.to(device).contiguous() if scale is not None else None
         self.bias = shift.to(device).contiguous() if shift is not None else None
 
+    def tiny_columns(self, binades=10):
+        """True when some input channel is weighted >= 2^binades less than the typical one (column maximum over filters and taps
+        against the median column maximum; all-zero padding columns ignored).  That is the signature of a layer whose input
+        carries OUTLIER channels that the filters compensate (BN-folded checkpoints): the typical channels then sit that many
+        binades below the tensor's magnitude bound, and the fp16x2 tiles — ONE power-of-two scale per activation tensor — keep the
+        low piece of a value normal only 15 binades below the bound (tests/test_gpu_batch_parity.py
+        test_outlier_channels_end_to_end_at_batch8: 2^12 outliers 9e-6, 2^14 3e-5, 2^16 1.3e-4 of the head tensors).  Such layers run
+        on the bf16x3 tiles instead (bf16 has the fp32 exponent range: no scale, no dependence on the bound)."""
+        if getattr(self, '_tiny_cols', None) is None:
+            w = self._wp_host[:self.Cout, :self.kh * self.kw * self.Cin].abs().float().cpu()
+            col = w.view(self.Cout, self.kh * self.kw, self.Cin).amax(dim=(0, 1))
+            nz = col[col > 0]
+            self._tiny_cols = bool(nz.numel() > 8 and (nz.min() * float(2 ** binades) < nz.median()).item())
+        return self._tiny_cols
+
     def w3(self):
         """[3][CoutPad][Kpad] bf16 planes of the same filters for the bf16x3 tiles (built on first use)."""
         if self._w3 is None:
@@ -152,7 +167,7 @@ class Packed:
         1 / the row's filter scale) for the fp16x2 tiles (ymi_conv_desc.w_h2 / scale_h2 / winv_h2); built on first use."""
         if self._h2 is None:
             planes, winv = split2_planes_f16(self._wp_host.cpu())
-            sc = torch.ones(self.CoutPad, dtype=torch.float32)
+            sc = torch.ones(self.CoutPad, dtype=torch.float32, device='cpu')    # (explicit: eval.py:1080 makes CUDA the default tensor type)
             if self.scale is not None:
                 sc[:self.Cout] = self.scale.detach().float().cpu()
             dev = self.w.device
@@ -309,6 +324,10 @@ class Plan:
         self.splitk = os.environ.get('YOLACT_AMD_SPLITK', '1') == '1'
         # YOLACT_AMD_PIPE=0 keeps the pipelined kernel of csrc/dcn.hip out of the candidates of ORDINARY convolutions (A/B switch)
         self.pipe = os.environ.get('YOLACT_AMD_PIPE', '1') == '1'
+        # YOLACT_AMD_WIDE_GUARD=0: keep fp16x2 tiles even on layers whose filters give away outlier input channels (tests of the
+        # unguarded behaviour); default: such layers run on bf16x3 tiles (Packed.tiny_columns)
+        self.wide_guard = os.environ.get('YOLACT_AMD_WIDE_GUARD', '1') == '1'
+        self.wide_ops = set()
         self._sk_ws = {}
         self.down_on_side_stream = os.environ.get('YOLACT_AMD_DOWN_STREAM', 'B') == 'B'      # measured +1 %
         self.wino_alt, self._wino_packed, self._wino_ws = {}, {}, {}
@@ -372,9 +391,13 @@ class Plan:
         d.tile = L.TILE_AUTO
         d.cin_alg = pk.cin_alg
         d.cout_alg = pk.cout_alg
-        if self.split and dcn_offmask is None:
+        # fp16x2 plans: a layer whose filters give away outlier input channels runs on the bf16x3 tiles (Packed.tiny_columns)
+        wide = self.h2 and self.wide_guard and pk.Cin % 32 == 0 and pk.tiny_columns()
+        if (self.split or wide) and dcn_offmask is None:
             d.w_x3 = pk.w3().data_ptr()
         yslot = self._slot()                    # fp16x2 plans: every launch records the magnitude bound of what it writes
+        for _ in range(len(segs) - 1 if segs else 0):       # (one slot per output segment, consecutive: ABI 5)
+            self._slot()
         if self.h2:                             # (csrc/common.h: one XCD-local atomic per wave at most); consumers read it as
             d.y_amax = self._slot_ptr(yslot)    # x_amax.  The bf16x3 / exact-fp32 plans need no bounds and do not pay for them
         if x.slot is not None:
@@ -396,7 +419,7 @@ class Plan:
                 d.seg[i] = L.ConvSeg(*s)
         self.keepalive.append(pk)
         wino = None
-        if (self.use_winograd and dcn_offmask is None and out is None and pk.weight_oihw is not None
+        if (self.use_winograd and dcn_offmask is None and out is None and pk.weight_oihw is not None and not wide
                 and wino_eligible(pk, res, segs, act, x.C)):
             wino = [w for w in (self._wino_op(x, pk, act, y, name, segs, m) for m in self.wino_variants) if w is not None]
             wino = wino or None
@@ -406,9 +429,13 @@ class Plan:
             dd.offmask, dd.ldo = dcn_offmask.ptr, dcn_offmask.C
             self.ops.append((self.lib.ymi_dcn_v2_forward_f32, C.pointer(dd), name, self._cur))
             self.conv_meta.append((name, dd.conv))
+            if wide:
+                self.wide_ops.add(len(self.ops) - 1)
         else:
             self.ops.append((self.lib.ymi_conv2d_nhwc_f32, C.pointer(d), name, self._cur))
             self.conv_meta.append((name, d))
+            if wide:
+                self.wide_ops.add(len(self.ops) - 1)
             if wino is not None:
                 self.wino_alt[len(self.ops) - 1] = wino      # op index -> alternative; autotune picks the faster one
                 if id(x) in self._upsrc:
@@ -596,7 +623,9 @@ class Plan:
                     (0, cu.out_channels, L.ACT_RELU, cu.out_channels, hw * cu.out_channels, u.ptr),
                     (cu.out_channels, cu.out_channels + cp.out_channels, L.ACT_RELU, cp.out_channels, hw * cp.out_channels,
                      t0.ptr)])
-                u.slot = t0.slot = self.last_yslot      # one bound (the maximum over both halves) serves both consumers
+                # one bound PER HALF (segment k raises slot k of consecutive slots): the two halves are different tensors — a large
+                # proto_net[0] channel must not coarsen the fp16x2 scale of the head's input (round-4 outlier stress test)
+                u.slot, t0.slot = self.last_yslot, self.last_yslot + 1
                 self._merged_p3 = t0
             else:
                 for k, pk in enumerate(up_pk):
@@ -1005,13 +1034,16 @@ class Plan:
 
     def _tune_direct(self, e0, e1, s, reps, disk, measure):
         cache = {}
-        for fn, dptr, name, where in self.ops:
+        for opi, (fn, dptr, name, where) in enumerate(self.ops):
             is_dcn = fn is self.lib.ymi_dcn_v2_forward_f32
             if fn is not self.lib.ymi_conv2d_nhwc_f32 and not is_dcn:
                 continue
             d = dptr.contents.conv if is_dcn else dptr.contents
             key = (d.B, d.H, d.W, d.Cin, d.Cout, d.kh, d.kw, d.stride, d.pad, d.res_mode, d.nseg, d.Kpad) + (('dcn',) if is_dcn else ())
-            skey = str(key) + self.mode_key
+            wide = opi in self.wide_ops            # outlier-channel guard: bf16x3 tiles (DCN: exact-fp32 tiles) for this layer only
+            h2_, split_ = self.h2 and not wide, self.split or (wide and not is_dcn)
+            skey = str(key) + ('|x3' if split_ else '|h2' if h2_ else '')
+            key = key + (('wide',) if wide else ())
             if key not in cache and skey in disk:
                 if self._apply_choice(fn, dptr, where, disk[skey], s) == 0:   # a stale / foreign entry must not make every forward raise
                     cache[key] = int(disk[skey])
@@ -1036,14 +1068,14 @@ class Plan:
                     cands = [t for t in sorted(L.TILE_NAMES) if t != L.TILE_128x32 and not (t & (L.TILE_X3 | L.TILE_H2))]
                     if d.Cout < 256:
                         cands = [t for t in cands if t != L.TILE_128x256_W8]
-                spflag = (L.TILE_X3 if self.split else L.TILE_H2 if self.h2 else 0) if not (is_dcn and self.split) else 0
+                spflag = (L.TILE_X3 if split_ else L.TILE_H2 if h2_ else 0) if not (is_dcn and split_) else 0
                 if spflag:      # (the Cin = 4 stem loader has the basic tiles only)
                     base_ok = L.H2_BASE_TILES if spflag == L.TILE_H2 else L.X3_BASE_TILES
                     cands = cands + [t | spflag for t in cands if t in base_ok
                                      and (d.Cin % 32 == 0 or t in L.BASIC_TILES)]
-                if is_dcn and self.h2:       # the pipelined gather-GEMM of csrc/dcn.hip (fp16x2 plans)
+                if is_dcn and h2_:           # the pipelined gather-GEMM of csrc/dcn.hip (fp16x2 plans)
                     cands = cands + self.dcnp_candidates(d, dcn=True)
-                if not is_dcn and self.h2 and self.pipe and self._pipe_ok(d):   # the same pipelined kernel as an ordinary convolution
+                if not is_dcn and h2_ and self.pipe and self._pipe_ok(d):   # the same pipelined kernel as an ordinary convolution
                     cands = cands + self.dcnp_candidates(d)
                 if not is_dcn and self._splitk_ok(d) and self.splitk:
                     # split-K candidates: big tiles whose grid alone cannot fill the chip, K cut 2 / 4 ways
