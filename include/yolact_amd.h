@@ -385,23 +385,6 @@ typedef struct {
 } ymi_dcn_desc;
 int ymi_dcn_v2_forward_f32(const ymi_dcn_desc *d, void *stream);
 
-/* -- fused ResNet bottleneck, identity shortcut (backbone.py:37-57 with stride 1 and no downsample) ----------------------
- * y = relu(bn3(conv3_1x1(relu(bn2(conv2_3x3(relu(bn1(conv1_1x1(x)))))))) + x), x and y [B,H,W,4P] NHWC fp32, in ONE launch:
- * the two P-channel intermediates live in LDS and x is read once (csrc/bottleneck.hip).  fp16x2 arithmetic only (the three
- * filters as ymi_conv_desc.w_h2 / scale_h2 planes, x_amax / y_amax as there); P = 64.  The per-tile power-of-two scales of
- * the intermediates make the result differ from the three separate launches by rounding only (same error class). */
-typedef struct ymi_bneck_desc {
-  const float *x;        /* [B,H,W,4P] */
-  float *y;              /* [B,H,W,4P] (must not alias x) */
-  int32_t B, H, W, P;
-  const void *w1_h2, *w2_h2, *w3_h2;          /* fp16 planes [2][cout_pad][Kpad]: Kpad = 4P, 9P, P */
-  int32_t cout_pad1, cout_pad2, cout_pad3, _pad0;
-  const float *scale1, *bias1, *scale2, *bias2, *scale3, *bias3;   /* scale_h2 (folded BN scale / filter row scale), folded bias */
-  const float *x_amax;   /* magnitude bound of x (required) */
-  float *y_amax;         /* magnitude bound of y (may be NULL) */
-} ymi_bneck_desc;
-int ymi_bottleneck_f32(const ymi_bneck_desc *d, void *stream);
-
 /* -- ResNet stem in one launch (backbone.py:126-133 + the layout change of yolact.py:564) ---------------------------------
  * x [B,3,H,W] NCHW fp32 (the normalised image) -> conv 7x7 / 2 / pad 3 (3 -> 64) + folded BN + ReLU -> max-pool 3x3 / 2 / pad 1
  * -> y [B,Hp,Wp,64] NHWC fp32, Hp = ((H - 1) / 2 + 1 - 1) / 2 + 1.  The 64-channel stem output stays in LDS (csrc/stem.hip).

@@ -674,64 +674,6 @@ def test_winograd_fp16x2(shape, tile, m, v_planes):
     assert run_wino.last_amax[1] == y_fp32.abs().max().item() or abs(run_wino.last_amax[1] - y_fp32.abs().max().item()) < 1e-3
 
 
-def test_fused_bottleneck_matches_fp64_reference_and_the_three_launches():
-    """ymi_bottleneck_f32 (csrc/bottleneck.hip: conv1 1x1 -> conv2 3x3 -> conv3 1x1 + identity shortcut in ONE launch, intermediates
-    in LDS as fp16x2 planes with per-tile scales) on a ragged size with one hot pixel (so neighbouring tiles pick different scales):
-    fp32-class against an fp64 reference, and the same error class as the three separate fp16x2 launches it would replace.
-    Not part of the default plan: measured 0.180 ms against 0.170 ms for the three launches at 138^2 x 8 (profiles/README.md)."""
-    from gpu_utils import DEV
-    import ctypes as C
-    import torch.nn as nn
-    from yolact_amd.engine import Packed
-    lib, s = L.lib(), L.stream_ptr()
-    g = _g(5)
-    P, C4 = 64, 256
-
-    def bn(c):
-        m = nn.BatchNorm2d(c)
-        m.weight.data = torch.rand(c, generator=g) + 0.5
-        m.bias.data = torch.randn(c, generator=g) * 0.2
-        m.running_mean = torch.randn(c, generator=g) * 0.1
-        m.running_var = torch.rand(c, generator=g) + 0.5
-        return m.eval()
-    blk = [(torch.randn(P, C4, 1, 1, generator=g) / 16, bn(P)), (torch.randn(P, P, 3, 3, generator=g) / 24, bn(P)),
-           (torch.randn(C4, P, 1, 1, generator=g) / 8, bn(C4))]
-    pks = [Packed(w, None, b, 1, 1 if w.shape[-1] == 3 else 0, None, DEV) for (w, b) in blk]
-    B, H, W = 2, 37, 43
-    x = torch.relu(torch.randn(B, H, W, C4, generator=g)) * 1.7
-    x[0, 5, 7, :] *= 40.0
-    t = x.permute(0, 3, 1, 2).double()
-    xin = t
-    for i, (w, b) in enumerate(blk):
-        t = torch.nn.functional.conv2d(t, w.double(), padding=1 if w.shape[-1] == 3 else 0)
-        inv = 1.0 / torch.sqrt(b.running_var.double() + b.eps)
-        t = t * (b.weight.double() * inv).view(1, -1, 1, 1) + (b.bias.double() - b.running_mean.double() * b.weight.double() * inv).view(1, -1, 1, 1)
-        if i < 2:
-            t = torch.relu(t)
-    ref = torch.relu(t + xin).permute(0, 2, 3, 1).contiguous()
-    xd = x.to(DEV)
-    y = torch.zeros(B, H, W, C4, device=DEV)
-    amax = torch.zeros(2 * 1024, device=DEV)
-    L.check(lib.ymi_amax_f32(xd.data_ptr(), xd.numel(), amax.data_ptr(), s))
-    d = L.BneckDesc()
-    d.x, d.y, d.B, d.H, d.W, d.P = xd.data_ptr(), y.data_ptr(), B, H, W, P
-    keep = []
-    for i, pk in enumerate(pks):
-        hp, sc2, winv = pk.h2()
-        keep.append((hp, sc2))
-        setattr(d, 'w%d_h2' % (i + 1), hp.data_ptr()); setattr(d, 'cout_pad%d' % (i + 1), pk.CoutPad)
-        setattr(d, 'scale%d' % (i + 1), sc2.data_ptr()); setattr(d, 'bias%d' % (i + 1), pk.bias.data_ptr())
-    d.x_amax, d.y_amax = amax.data_ptr(), amax.data_ptr() + 4096
-    L.check(lib.ymi_bottleneck_f32(C.byref(d), s), 'bottleneck')
-    torch.cuda.synchronize()
-    err = (y.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
-    print('fused bottleneck: max error %.2e of max|y|' % err)
-    assert err < 5e-7
-    assert amax[1024:].max().item() == y.max().item()            # the launch reports the magnitude bound of what it wrote
-    d.P = 128
-    assert lib.ymi_bottleneck_f32(C.byref(d), s) == -2              # YMI_ESHAPE: only the 64-channel form is instantiated
-
-
 @pytest.mark.parametrize('B,H,W', [(2, 61, 77), (1, 550, 550)])
 def test_fused_stem_matches_reference_and_the_three_launches(B, H, W):
     """ymi_stem_pool_f32 (csrc/stem.hip): NCHW image -> conv 7x7/2 + BN + ReLU -> max-pool 3x3/2 -> NHWC in one launch, per-tile input

@@ -132,12 +132,12 @@ def test_struct_layout_matches_c_compiler(tmp_path):
     from yolact_amd import _lib as L
     src = tmp_path / 'sz.c'
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu '
-                   '%%zu %%zu %%zu %%zu %%zu %%zu\\n",'
+                   '%%zu %%zu %%zu %%zu\\n",'
                    'sizeof(ymi_conv_seg),sizeof(ymi_conv_desc),sizeof(ymi_dcn_desc),sizeof(ymi_detect_desc),'
                    'offsetof(ymi_conv_desc,seg),offsetof(ymi_conv_desc,B),offsetof(ymi_detect_desc,scores_t),'
                    'offsetof(ymi_dcn_desc,offmask),sizeof(ymi_wino_desc),offsetof(ymi_wino_desc,u_x3),'
                    'sizeof(ymi_jpeg_info),offsetof(ymi_jpeg_info,coef_count),offsetof(ymi_jpeg_info,dw),'
-                   'offsetof(ymi_wino_desc,x_up),offsetof(ymi_wino_desc,up_relu),sizeof(ymi_bneck_desc),offsetof(ymi_bneck_desc,scale1),'
+                   'offsetof(ymi_wino_desc,x_up),offsetof(ymi_wino_desc,up_relu),'
                    'sizeof(ymi_stem_desc),offsetof(ymi_stem_desc,kpad));return 0;}'
                    % os.path.join(ROOT, 'include', 'yolact_amd.h'))
     exe = tmp_path / 'sz'
@@ -146,17 +146,17 @@ def test_struct_layout_matches_c_compiler(tmp_path):
     want = [ctypes.sizeof(L.ConvSeg), ctypes.sizeof(L.ConvDesc), ctypes.sizeof(L.DcnDesc), ctypes.sizeof(L.DetectDesc),
             L.ConvDesc.seg.offset, L.ConvDesc.B.offset, L.DetectDesc.scores_t.offset, L.DcnDesc.offmask.offset,
             ctypes.sizeof(L.WinoDesc), L.WinoDesc.u_x3.offset, ctypes.sizeof(L.JpegInfo), L.JpegInfo.coef_count.offset,
-            L.JpegInfo.dw.offset, L.WinoDesc.x_up.offset, L.WinoDesc.up_relu.offset, ctypes.sizeof(L.BneckDesc),
-            L.BneckDesc.scale1.offset, ctypes.sizeof(L.StemDesc), L.StemDesc.kpad.offset]
+            L.JpegInfo.dw.offset, L.WinoDesc.x_up.offset, L.WinoDesc.up_relu.offset,
+            ctypes.sizeof(L.StemDesc), L.StemDesc.kpad.offset]
     assert got == want, (got, want)
 
 
 def test_new_entries_validate_their_descriptors_before_any_launch():
-    """ymi_stem_pool_f32 / ymi_bottleneck_f32 / the fused-upsampling form of ymi_conv3x3_winograd_f32 reject bad descriptors with
+    """ymi_stem_pool_f32 / the fused-upsampling form of ymi_conv3x3_winograd_f32 reject bad descriptors with
     the documented codes (-3 null, -1 argument, -2 shape) — checked without a GPU: the validation comes before any HIP call."""
     from yolact_amd import _lib as L
     lib = L.lib()
-    assert lib.ymi_stem_pool_f32(None, None) == -3 and lib.ymi_bottleneck_f32(None, None) == -3
+    assert lib.ymi_stem_pool_f32(None, None) == -3
     buf = (ctypes.c_float * 64)()
     p = ctypes.addressof(buf)
     p16 = (p + 15) & ~15
@@ -167,13 +167,6 @@ def test_new_entries_validate_their_descriptors_before_any_launch():
     assert lib.ymi_stem_pool_f32(ctypes.byref(d), None) == -1           # smaller than the 7x7 filter
     d.H, d.kpad = 64, 196
     assert lib.ymi_stem_pool_f32(ctypes.byref(d), None) == -2           # filters not in the Kpad-224 plane layout
-    b = L.BneckDesc()
-    for f in ('x', 'y', 'w1_h2', 'w2_h2', 'w3_h2', 'scale1', 'bias1', 'scale2', 'bias2', 'scale3', 'bias3', 'x_amax'):
-        setattr(b, f, p16)
-    b.B, b.H, b.W, b.P, b.cout_pad1, b.cout_pad2, b.cout_pad3 = 1, 8, 8, 128, 128, 128, 512
-    assert lib.ymi_bottleneck_f32(ctypes.byref(b), None) == -2          # only the 64-channel form is instantiated
-    b.P, b.B = 64, 0
-    assert lib.ymi_bottleneck_f32(ctypes.byref(b), None) == -1
     w = L.WinoDesc()
     w.u, w.V, w.M, w.y, w.x_up = p16, p16, p16, p16, p16
     w.B, w.H, w.W, w.C, w.Cout, w.m = 1, 8, 8, 32, 32, 2

@@ -102,14 +102,6 @@ class JpegInfo(C.Structure):
                 ('coef_count', C.c_int64), ('plane_bytes', C.c_int64)]
 
 
-class BneckDesc(C.Structure):
-    _fields_ = [('x', C.c_void_p), ('y', C.c_void_p), ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('P', C.c_int32),
-                ('w1_h2', C.c_void_p), ('w2_h2', C.c_void_p), ('w3_h2', C.c_void_p),
-                ('cout_pad1', C.c_int32), ('cout_pad2', C.c_int32), ('cout_pad3', C.c_int32), ('_pad0', C.c_int32),
-                ('scale1', C.c_void_p), ('bias1', C.c_void_p), ('scale2', C.c_void_p), ('bias2', C.c_void_p),
-                ('scale3', C.c_void_p), ('bias3', C.c_void_p), ('x_amax', C.c_void_p), ('y_amax', C.c_void_p)]
-
-
 class StemDesc(C.Structure):
     _fields_ = [('x', C.c_void_p), ('y', C.c_void_p), ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('cout_pad', C.c_int32),
                 ('w_h2', C.c_void_p), ('scale_h2', C.c_void_p), ('bias', C.c_void_p), ('y_amax', C.c_void_p),
@@ -148,7 +140,6 @@ SYMBOLS = [
     ('ymi_mask_bits_f32', C.c_int, [_P, _I, C.c_long, _P, _P]),
     ('ymi_mask_upsample_bits', C.c_int, [_P, _I, _I, _I, _I, _I, _F, _P, _P]),
     ('ymi_mask_iou_bits', C.c_int, [_P, _P, _I, _I, C.c_long, _I, _P, _P]),
-    ('ymi_bottleneck_f32', C.c_int, [_P, _P]),
     ('ymi_stem_pool_f32', C.c_int, [_P, _P]),
     ('ymi_mask_rle_f32', C.c_int, [_P, _I, _I, _I, _P, _P, _I, _P]),
     ('ymi_mask_rle_upsampled_f32', C.c_int, [_P, _I, _I, _I, _I, _I, _F, _P, _P, _I, _P]),
