@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define YMI_ABI_VERSION 5
+#define YMI_ABI_VERSION 6
 
 /* negative return codes (ymi_strerror) */
 #define YMI_EFORMAT (-4)       /* corrupt or truncated input stream (ymi_jpeg_*) */
@@ -142,7 +142,11 @@ enum { YMI_DCNP_64x128 = 1, YMI_DCNP_64x128_W8 = 2, YMI_DCNP_64x64 = 3, YMI_DCNP
         * maps are small */
        YMI_DCNP_64x256_W8 = 11, YMI_DCNP_96x256_W12 = 12, YMI_DCNP_128x256_W16 = 13,
        /* 64 x 64 wave tiles (ordinary convolutions only: ymi_conv2d_nhwc_f32) */
-       YMI_DCNP_128x256_W8T = 14, YMI_DCNP_128x128_W4T = 15, YMI_DCNP_256x128_W8T = 16 };
+       YMI_DCNP_128x256_W8T = 14, YMI_DCNP_128x128_W4T = 15, YMI_DCNP_256x128_W8T = 16,
+       /* 32 output channels per block (ordinary convolutions only): the 27-channel conv_offset_mask of a DCN layer
+        * (dcn_v2.py:107-112) with its filters zero-padded to 32 — the cost of such a layer is staging its input, so a block
+        * spends its waves on rows, not on columns nobody needs */
+       YMI_DCNP_128x32_W4 = 17, YMI_DCNP_256x32_W8 = 18, YMI_DCNP_64x32_W2 = 19 };
 
 int ymi_abi_version(void);
 const char *ymi_strerror(int code);
@@ -377,11 +381,16 @@ int ymi_coco_rle_string_fill_u8(const char *s, long len, int h, int w, uint8_t *
 /* -- DCNv2 forward (external/DCNv2/src/vision.cpp:5, dcn_v2.h:9-39, dcn_v2_cuda.cu:42-172) ---- */
 typedef struct {
   ymi_conv_desc conv;    /* main 3x3 conv: x, packed w, bias, epilogue, outputs (kh=kw=3, pad=1) */
-  const float *offmask;  /* [B,Ho,Wo,ldo] NHWC output of conv_offset_mask: ch 2k=dh_k, 2k+1=dw_k, 18+k=mask logit */
+  const float *offmask;  /* [B,Ho,Wo,ldo] NHWC output of conv_offset_mask: ch 2k=dh_k, 2k+1=dw_k, 18+k=mask logit (om_layout 0) */
   int32_t ldo;           /* channel stride of offmask pixels (>= 27) */
   int32_t mask_is_prob;  /* 0: channels 18.. are mask LOGITS, the kernel applies the sigmoid (DCN.forward, dcn_v2.py:118-128 — the
                           * engine's plans); 1: they are the modulation itself, already in [0,1] (dcn_v2_conv / DCNv2.forward,
                           * dcn_v2.py:16-33,85-96, whose callers pass torch.sigmoid(mask)).  Occupies what was tail padding. */
+  int32_t om_layout;     /* channel order of offmask.  0: the reference's (dcn_v2.py:118-122: 18 offsets, then 9 masks).  1: per tap
+                          * [dh_k, dw_k, mask_k] at channels 3k .. 3k+2 — a caller that owns conv_offset_mask's filters (the engine)
+                          * permutes their ROWS once on the host, and the gather kernel then fetches a tap's three values with one
+                          * 12-byte load instead of three (it is bound by vector-memory instructions) */
+  int32_t _pad1;
 } ymi_dcn_desc;
 int ymi_dcn_v2_forward_f32(const ymi_dcn_desc *d, void *stream);
 

@@ -20,7 +20,7 @@ def nchw(x_nhwc):
 
 
 def run_conv(x, weight, bias=None, bn=None, stride=1, pad=0, act=L.ACT_NONE, res=None, res_mode=L.RES_NONE,
-             res_after_act=0, tile=L.TILE_AUTO, cin_pad=None, dcn_offmask=None, planes=True, split_k=0):
+             res_after_act=0, tile=L.TILE_AUTO, cin_pad=None, dcn_offmask=None, planes=True, split_k=0, om_layout=0):
     """x: CPU NCHW tensor. Returns CPU NCHW output of the HIP conv.  `planes`: for bf16x3 tiles also hand the kernel the
     pre-split filter planes (ymi_conv_desc.w_x3); False = both operands are split on the fly."""
     pk = Packed(weight, bias, bn, stride, pad, cin_pad, DEV)
@@ -63,7 +63,7 @@ def run_conv(x, weight, bias=None, bn=None, stride=1, pad=0, act=L.ACT_NONE, res
         om = nhwc(dcn_offmask).to(DEV)
         dd = L.DcnDesc()
         dd.conv = d
-        dd.offmask, dd.ldo = om.data_ptr(), om.shape[3]
+        dd.offmask, dd.ldo, dd.om_layout = om.data_ptr(), om.shape[3], om_layout
         L.check(L.lib().ymi_dcn_v2_forward_f32(C.byref(dd), s), 'dcn')
     else:
         L.check(L.lib().ymi_conv2d_nhwc_f32(C.byref(d), s), 'conv')

@@ -244,6 +244,23 @@ def test_dcn_pipelined_matches_oracle(case, tile):
     assert abs(run_conv.last_amax[1] - ref.abs().max().item()) <= 2e-5 * ref.abs().max().item()     # the bound it reports for y
 
 
+@pytest.mark.parametrize('tile', [L.TILE_AUTO, L.TILE_64x64 | L.TILE_H2] + DCNP_ALL)
+def test_dcn_tap_interleaved_offmask_is_the_same_launch(tile):
+    """ymi_dcn_desc.om_layout = 1 ([dh_k, dw_k, mask_k] per tap, padded to 32 channels — what engine.pack_offmask makes
+    conv_offset_mask write) against layout 0 (the reference's 18 offsets | 9 masks, dcn_v2.py:118-122) on the same values: the same
+    samples in the same order, so bit-identical — on the register-staged loader (exact fp32, fp16x2) and on every pipelined tile."""
+    from gpu_utils import run_conv
+    x, w, b, om = _dcn_inputs(77, 2, 64, 13, 11, 132, 1)
+    om[:, :18] *= 2.0
+    order = [c for k in range(9) for c in (2 * k, 2 * k + 1, 18 + k)]
+    om1 = torch.cat([om[:, order], torch.full((2, 5, 13, 11), float('nan'))], 1)         # the 5 padding channels are never read
+    y0 = run_conv(x, w, b, None, 1, 1, dcn_offmask=om, tile=tile, act=L.ACT_RELU)
+    y1 = run_conv(x, w, b, None, 1, 1, dcn_offmask=om1, tile=tile, act=L.ACT_RELU, om_layout=1)
+    assert torch.equal(y0, y1)
+    with pytest.raises(RuntimeError):
+        run_conv(x, w, b, None, 1, 1, dcn_offmask=om1, tile=tile, om_layout=2)
+
+
 @pytest.mark.parametrize('tile', [L.DCNP_64x128_W8, L.DCNP_96x128_W6, 11, 12, 13])
 @pytest.mark.parametrize('split', [2, 3, 4, 5, 9])
 def test_dcn_pipelined_split_k(tile, split):
@@ -264,13 +281,17 @@ def test_dcn_pipelined_split_k(tile, split):
 @pytest.mark.parametrize('tile', PIPE_ALL)
 @pytest.mark.parametrize('case', [(2, 64, 19, 17, 72, 3, 1, False, L.ACT_RELU), (1, 128, 23, 21, 260, 3, 2, False, L.ACT_NONE),
                                   (2, 256, 14, 15, 64, 1, 1, True, L.ACT_RELU), (3, 64, 9, 10, 128, 1, 2, False, L.ACT_LEAKY01),
-                                  (1, 32, 31, 29, 36, 3, 1, False, L.ACT_RELU), (2, 96, 12, 13, 512, 1, 1, True, L.ACT_LEAKY01)])
+                                  (1, 32, 31, 29, 36, 3, 1, False, L.ACT_RELU), (2, 96, 12, 13, 512, 1, 1, True, L.ACT_LEAKY01),
+                                  (2, 64, 19, 17, 32, 3, 1, False, L.ACT_NONE), (1, 128, 23, 21, 28, 3, 2, False, L.ACT_RELU),
+                                  (3, 256, 14, 15, 32, 1, 1, True, L.ACT_RELU)])
 def test_pipelined_kernel_as_ordinary_convolution(case, tile):
     """ymi_conv2d_nhwc_f32 with a YMI_TILE_DCNP tile = the pipelined kernel of csrc/dcn.hip in PLAIN mode (one load per sample, integer
     tap geometry): 3x3 / pad 1 and 1x1 / pad 0, stride 1 / 2, folded BN, bias, residual before or after the activation, ragged row
     and column tiles, odd chunk counts — against torch fp32."""
     from gpu_utils import run_conv, rel_err
     B, Cin, H, W, Cout, k, stride, has_res, act = case
+    if (tile & 31) >= L.DCNP_128x32_W4 and Cout > 32:
+        pytest.skip('32-column tiles take Cout <= 32 only (rejected with YMI_EARG: test_dcn_pipelined_rejects_what_it_cannot_run)')
     g = _g(300 + Cin + Cout + k)
     x = torch.randn(B, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
@@ -314,6 +335,25 @@ def test_pipelined_ordinary_convolution_split_k(tile, split):
         assert rel_err(y3, F.conv2d(x3, w3, None, 2, 1)) < 2e-5
 
 
+@pytest.mark.parametrize('tile', [L.DCNP_128x32_W4, L.DCNP_256x32_W8, L.DCNP_64x32_W2])
+@pytest.mark.parametrize('split', [1, 2, 4, 9])
+def test_offset_mask_convolution_on_the_32_column_tiles(tile, split):
+    """The shape the 32-column tiles exist for: a 3x3 / pad 1 convolution to 27 channels zero-padded to 32 (engine.pack_offmask), K
+    ranges included (35x35 / 18x18 maps have few row tiles) — against torch fp32, the padding channels exactly zero."""
+    from gpu_utils import run_conv, rel_err
+    g = _g(500 + split)
+    x = torch.randn(2, 128, 18, 19, generator=g)
+    w = torch.zeros(32, 128, 3, 3)
+    w[:27] = torch.randn(27, 128, 3, 3, generator=g) / 34
+    b = torch.zeros(32)
+    b[:27] = torch.randn(27, generator=g)
+    t = tile | L.TILE_H2 | L.TILE_DCNP
+    y = run_conv(x, w, b, None, 1, 1, tile=t, split_k=split if split > 1 else 0)
+    assert rel_err(y, F.conv2d(x, w, b, 1, 1)) < 2e-5
+    assert y[:, 27:].abs().max().item() == 0
+    assert torch.equal(y, run_conv(x, w, b, None, 1, 1, tile=t, split_k=split if split > 1 else 0))
+
+
 def test_dcn_pipelined_rejects_what_it_cannot_run():
     """An explicit YMI_TILE_DCNP request outside the kernel's envelope is an error code, never a silent other kernel."""
     from gpu_utils import run_conv
@@ -325,6 +365,8 @@ def test_dcn_pipelined_rejects_what_it_cannot_run():
         run_conv(x, w, b, None, 1, 1, dcn_offmask=om, tile=L.TILE_DCNP | L.DCNP_64x128)
     with pytest.raises(RuntimeError):                                     # unknown block tile
         run_conv(x, w, b, None, 1, 1, dcn_offmask=om, tile=L.TILE_H2 | L.TILE_DCNP | 31)
+    with pytest.raises(RuntimeError):                                     # a 32-column tile for 48 output channels
+        run_conv(x, w, b, None, 1, 1, tile=L.TILE_H2 | L.TILE_DCNP | L.DCNP_128x32_W4)
 
 
 def test_dcn_v2_module_reference_kat_through_the_shim():

@@ -78,7 +78,7 @@ def test_struct_sizes_match_header():
     from yolact_amd import _lib as L
     assert ctypes.sizeof(L.ConvSeg) == 32
     assert ctypes.sizeof(L.ConvDesc) == 5 * 8 + 22 * 4 + 3 * 32 + 16 + 8 + 5 * 8 + 8      # + fp16x2 planes / scales / amax slots
-    assert ctypes.sizeof(L.DcnDesc) == ctypes.sizeof(L.ConvDesc) + 16
+    assert ctypes.sizeof(L.DcnDesc) == ctypes.sizeof(L.ConvDesc) + 24        # offmask, ldo, mask_is_prob, om_layout, pad
     assert ctypes.sizeof(L.DetectDesc) == 4 * 8 + 7 * 4 + 2 * 4 + 4 + 2 * 4 + 14 * 8
 
 

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libyolact_amd.so')
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 ACT_NONE, ACT_RELU, ACT_LEAKY01, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 RES_NONE, RES_ADD, RES_BILINEAR = 0, 1, 2
@@ -39,8 +39,10 @@ DCNP_96x128_W6, DCNP_128x128_W8_R1, DCNP_160x128_W10, DCNP_192x128_W12, DCNP_64x
 DCNP_TILES = {1: 'dcnp64x128', 2: 'dcnp64x128w8', 3: 'dcnp64x64', 4: 'dcnp128x128w8', 5: 'dcnp128x64w8', 6: 'dcnp32x128',
               7: 'dcnp96x128w6', 8: 'dcnp128x128w8r1', 9: 'dcnp160x128w10', 10: 'dcnp192x128w12',
               11: 'dcnp64x256w8', 12: 'dcnp96x256w12', 13: 'dcnp128x256w16',
-              14: 'dcnp128x256w8t', 15: 'dcnp128x128w4t', 16: 'dcnp256x128w8t'}
-DCNP_PLAIN_ONLY = (14, 15, 16)     # 64x64 wave tiles: ordinary convolutions only
+              14: 'dcnp128x256w8t', 15: 'dcnp128x128w4t', 16: 'dcnp256x128w8t',
+              17: 'dcnp128x32w4', 18: 'dcnp256x32w8', 19: 'dcnp64x32w2'}
+DCNP_128x32_W4, DCNP_256x32_W8, DCNP_64x32_W2 = 17, 18, 19
+DCNP_PLAIN_ONLY = (14, 15, 16, 17, 18, 19)     # 64x64 wave tiles, 32-column tiles: ordinary convolutions only
 for _t, _n in DCNP_TILES.items():
     TILE_NAMES[_t | TILE_H2 | TILE_DCNP] = _n
 WINO_PLANES = 1024                  # tune-table flag on a Winograd GEMM tile id: V written as fp16x2 planes (ymi_wino_desc.v_planes)
@@ -78,7 +80,8 @@ class WinoDesc(C.Structure):
 
 
 class DcnDesc(C.Structure):
-    _fields_ = [('conv', ConvDesc), ('offmask', C.c_void_p), ('ldo', C.c_int32), ('mask_is_prob', C.c_int32)]
+    _fields_ = [('conv', ConvDesc), ('offmask', C.c_void_p), ('ldo', C.c_int32), ('mask_is_prob', C.c_int32),
+                ('om_layout', C.c_int32), ('_pad1', C.c_int32)]
 
 
 class DetectDesc(C.Structure):

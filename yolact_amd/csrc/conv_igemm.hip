@@ -103,7 +103,7 @@ struct KParams {
   int M, HoWo, tiles_n, nk;
   unsigned x_bytes, w_bytes;      // buffer-resource sizes
   const float *offmask;           // DCN only
-  int ldo, mask_is_prob;
+  int ldo, mask_is_prob, om_layout;
   long x_gs, w_gs, y_gs;          // grouped GEMM (gridDim.y groups, Winograd): element strides of x / w / seg[0].ptr per group
   const void *w3;                 // PREC == 2: filters pre-split into three bf16 planes [groups][3][CoutPad][Kpad]
   unsigned w3_plane;              // PREC == 2: bytes between planes (CoutPad * Kpad * 2)
@@ -512,8 +512,9 @@ void conv_igemm_f32(const KParams p) {
             if (a_iy0[i] > -(1 << 27)) {
               const int m = a_base[i];
               const float *om = p.offmask + (size_t)m * p.ldo;
-              const float dh = om[2 * tap], dw = om[2 * tap + 1];
-              mk = p.mask_is_prob ? om[18 + tap] : 1.f / (1.f + expf(-om[18 + tap]));
+              const float dh = om[p.om_layout ? 3 * tap : 2 * tap], dw = om[p.om_layout ? 3 * tap + 1 : 2 * tap + 1];
+              const float mraw = om[p.om_layout ? 3 * tap + 2 : 18 + tap];
+              mk = p.mask_is_prob ? mraw : 1.f / (1.f + expf(-mraw));
               const float h = (float)(a_iy0[i] + nx_ky[j]) + dh, w = (float)(a_ix0[i] + nx_kx[j]) + dw;
               if (h > -1.f && w > -1.f && h < (float)d.H && w < (float)d.W) {
                 const int hl = (int)floorf(h), wl = (int)floorf(w);
@@ -1280,7 +1281,7 @@ struct H2Group { const void *a2 = nullptr; unsigned a2_plane = 0; long a2_gs = 0
 
 int run_conv(const ymi_conv_desc *d, int loader, const float *offmask, int ldo, hipStream_t s, int groups = 1, long x_gs = 0,
              long w_gs = 0, long y_gs = 0, double prof_flops = -1.0, int prof_kind = -1, int split_k = 1,
-             const H2Group &h2g = H2Group(), int mask_is_prob = 0) {
+             const H2Group &h2g = H2Group(), int mask_is_prob = 0, int om_layout = 0) {
   int rc = validate(d, loader);
   // grouped launches take the fast-path epilogue only (it applies the group's output offset)
   if (rc == YMI_OK && groups > 1 &&
@@ -1303,6 +1304,7 @@ int run_conv(const ymi_conv_desc *d, int loader, const float *offmask, int ldo, 
   kp.offmask = offmask;
   kp.ldo = ldo;
   kp.mask_is_prob = mask_is_prob;
+  kp.om_layout = om_layout;
   kp.x_gs = x_gs; kp.w_gs = w_gs; kp.y_gs = y_gs;
   const bool h2 = (d->tile & YMI_TILE_H2) != 0;
   if (h2 && (d->tile & YMI_TILE_X3)) return YMI_EARG;
@@ -1490,13 +1492,14 @@ int ymi_conv2d_nhwc_f32(const ymi_conv_desc *d, void *stream) {
 int ymi_dcn_v2_forward_f32(const ymi_dcn_desc *d, void *stream) {
   if (!d || !d->offmask) return YMI_ENULL;
   if (d->ldo < 27) return YMI_ESHAPE;
+  if (d->om_layout != 0 && d->om_layout != 1) return YMI_EARG;
   if (d->conv.tile & YMI_TILE_DCNP) {        // the pipelined gather-GEMM (fp16x2 only); an explicit request it cannot honour fails
     if (!(d->conv.tile & YMI_TILE_H2) || (d->conv.tile & YMI_TILE_X3)) return YMI_EARG;
     const int rc = validate(&d->conv, 2);
     if (rc) return rc;
     return ymi_internal_dcn_h2(d, d->conv.tile & 31, (hipStream_t)stream);
   }
-  return run_conv(&d->conv, 2, d->offmask, d->ldo, (hipStream_t)stream, 1, 0, 0, 0, -1.0, -1, 1, H2Group(), d->mask_is_prob);
+  return run_conv(&d->conv, 2, d->offmask, d->ldo, (hipStream_t)stream, 1, 0, 0, 0, -1.0, -1, 1, H2Group(), d->mask_is_prob, d->om_layout);
 }
 
 int ymi_debug_set_trace(void *buf, long cap_blocks) {

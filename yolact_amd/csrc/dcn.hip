@@ -39,6 +39,7 @@ constexpr unsigned OOB = 0x80000000u;   // buffer offset >= num_records: the loa
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 struct Split2 { f16x8 h, l; };
@@ -54,6 +55,7 @@ struct DcnParams {
   int nk_split;  // chunks per K range (gridDim.y ranges; == nk without split-K); range y writes raw partial sums to y + y * y_gs
   long y_gs;
   unsigned x_bytes, om_bytes, w_plane;
+  int om_layout;
   int abl;      // diagnostics build only (env YMI_DCN_ABLATE): bit0 corner loads -> OOB (no memory access), bit1 filter DMAs -> OOB,
                 // bit2 no combine / LDS store, bit3 no MFMAs, bit4 no barrier, bit5 no vmcnt wait — wrong results by design; bit6 no residency cap
 };
@@ -70,7 +72,8 @@ constexpr int dcn_occupancy() {     // blocks per CU: LDS-limited (at most two),
                                     // per CU, anything larger one.  An ordinary convolution (PLAIN) loads one sample, not four corners,
                                     // and has no such cap (68 - 110 registers)
   constexpr int occ = (160 * 1024) / (dcn_lds_floats<WM, WN, TM, TN, RING>() * 4);
-  constexpr int nw = WM * WN, ra = (WM * TM * 32) / (8 * nw), cap = (!PLAIN && (nw > 8 || (nw == 8 && ra > 1))) ? 1 : 2;
+  constexpr int nw = WM * WN, ra = (WM * TM * 32) / (8 * nw);
+  constexpr int cap = (!PLAIN && (nw > 8 || (nw == 8 && ra > 1))) ? 1 : (WN * TN == 1 && nw <= 4) ? 4 : 2;   // (32-column tiles: small blocks)
   return occ > cap ? cap : (occ < 1 ? 1 : occ);
 }
 
@@ -165,10 +168,17 @@ void pipe_h2_k(const DcnParams p) {
     if constexpr (PLAIN) return;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-      const unsigned o = g_om[i] != OOB ? g_om[i] + 8u * tap : OOB;
-      raw[i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ors, o, 0, 0));
-      raw[i][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ors, o, 4, 0));
-      raw[i][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ors, o, 4 * 18 - 4 * tap, 0));
+      if (p.om_layout) {           // [dh_k, dw_k, mask_k] per tap: one 12-byte load (ymi_dcn_desc.om_layout = 1)
+        const unsigned o = g_om[i] != OOB ? g_om[i] + 12u * tap : OOB;
+        const u32x3 v = __builtin_bit_cast(u32x3, __builtin_amdgcn_raw_buffer_load_b96(ors, o, 0, 0));
+        const unsigned v0 = v[0], v1 = v[1], v2 = v[2];       // (scalar copies: hipcc 7.2 mis-indexes bit casts of vector elements)
+        raw[i][0] = __uint_as_float(v0); raw[i][1] = __uint_as_float(v1); raw[i][2] = __uint_as_float(v2);
+      } else {
+        const unsigned o = g_om[i] != OOB ? g_om[i] + 8u * tap : OOB;
+        raw[i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ors, o, 0, 0));
+        raw[i][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ors, o, 4, 0));
+        raw[i][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ors, o, 4 * 18 - 4 * tap, 0));
+      }
     }
   };
   const int ntaps = PLAIN ? p.taps : 9;
@@ -535,7 +545,8 @@ namespace {
 // many blocks — the small maps (35x35, 18x18 at batch 8) have too few row tiles for 256 CUs once a tile covers 256 output channels
 // (every sample gathered once for all of them) — and a second launch adds the partial sums in a fixed order and applies scale / bias /
 // residual / activation (splitk_fixup_k of csrc/conv_igemm.hip: deterministic).
-int run_pipe(const ymi_conv_desc *d, const float *offmask, int ldo, int mask_is_prob, int base_tile, int prof_kind, hipStream_t s) {
+int run_pipe(const ymi_conv_desc *d, const float *offmask, int ldo, int mask_is_prob, int om_layout, int base_tile, int prof_kind,
+             hipStream_t s) {
   const bool plain = offmask == nullptr;
   const ymi_conv_seg &g0 = d->seg[0];
   const long HoWo = (long)d->Ho * d->Wo, M = (long)d->B * HoWo;
@@ -562,7 +573,7 @@ int run_pipe(const ymi_conv_desc *d, const float *offmask, int ldo, int mask_is_
   p.x = d->x; p.offmask = offmask; p.scale_h2 = d->scale_h2; p.bias = d->bias; p.x_amax = d->x_amax;
   p.w_h2 = d->w_h2; p.y = g0.ptr; p.y_amax = d->y_amax;
   p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.ldx = d->ldx; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
-  p.stride = d->stride; p.Kpad = d->Kpad; p.ldo = ldo; p.ldy = g0.row_stride; p.act = g0.act; p.mask_is_prob = mask_is_prob;
+  p.stride = d->stride; p.Kpad = d->Kpad; p.ldo = ldo; p.ldy = g0.row_stride; p.act = g0.act; p.mask_is_prob = mask_is_prob; p.om_layout = om_layout;
   p.taps = d->kh * d->kw; p.kw = d->kw; p.pad = d->pad;
   p.res = d->res_mode == YMI_RES_ADD ? d->res : nullptr; p.res_ld = d->res_ld; p.res_after_act = d->res_after_act;
   p.M = (int)M; p.HoWo = (int)HoWo; p.tiles_n = 0; p.nk = nk; p.nk_split = (nk + S - 1) / S; p.y_gs = 0;
@@ -580,7 +591,8 @@ int run_pipe(const ymi_conv_desc *d, const float *offmask, int ldo, int mask_is_
   const int tile_id = base_tile | YMI_TILE_H2 | YMI_TILE_DCNP;
   const double flops = 2.0 * (double)M * (double)(d->cout_alg > 0 ? d->cout_alg : d->Cout) * (double)(d->kh * d->kw) *
                        (double)(d->cin_alg > 0 ? d->cin_alg : d->Cin);
-  if (base_tile < YMI_DCNP_64x128 || base_tile > YMI_DCNP_256x128_W8T) return YMI_EARG;
+  if (base_tile < YMI_DCNP_64x128 || base_tile > YMI_DCNP_64x32_W2) return YMI_EARG;
+  if (base_tile >= YMI_DCNP_128x32_W4 && d->Cout > 32) return YMI_EARG;      // one column tile: nothing to gain from re-staging the rows per 32 columns
   int rc;
   const int pr = ymi_internal_prof_begin(flops, tile_id, prof_kind, s);
   switch (base_tile) {                                   // <waves along M, waves along N, 32x32 tiles per wave along M, along N, ring>
@@ -605,7 +617,11 @@ int run_pipe(const ymi_conv_desc *d, const float *offmask, int ldo, int mask_is_
     // ordinary convolutions only — four gathered rows per thread would not fit the DCN path's register ring
     case YMI_DCNP_128x256_W8T: rc = plain ? launch_dcn_k<2, 4, 2, 2, 1, true>(p, s) : YMI_EARG; break;
     case YMI_DCNP_128x128_W4T: rc = plain ? launch_dcn_k<2, 2, 2, 2, 1, true>(p, s) : YMI_EARG; break;
-    default: rc = plain ? launch_dcn_k<4, 2, 2, 2, 1, true>(p, s) : YMI_EARG; break;   // YMI_DCNP_256x128_W8T
+    case YMI_DCNP_256x128_W8T: rc = plain ? launch_dcn_k<4, 2, 2, 2, 1, true>(p, s) : YMI_EARG; break;
+    // 32 columns: every wave a 32 x 32 tile of its own rows (Cout <= 32: the offset / mask convolution of a DCN layer)
+    case YMI_DCNP_128x32_W4: rc = plain ? launch_dcn_k<4, 1, 1, 1, 2, true>(p, s) : YMI_EARG; break;
+    case YMI_DCNP_256x32_W8: rc = plain ? launch_dcn_k<8, 1, 1, 1, 1, true>(p, s) : YMI_EARG; break;
+    default: rc = plain ? launch_dcn_k<2, 1, 1, 1, 2, true>(p, s) : YMI_EARG; break;   // YMI_DCNP_64x32_W2
   }
   if (rc == YMI_OK && S > 1)
     rc = ymi_internal_splitk_fixup(d->split_ws, M * (long)d->Cout, S, M, d->Cout, g0.row_stride, g0.ptr, d->scale, d->bias,
@@ -620,10 +636,10 @@ int run_pipe(const ymi_conv_desc *d, const float *offmask, int ldo, int mask_is_
 // validated descriptor whose tile is YMI_TILE_H2 | YMI_TILE_DCNP | YMI_DCNP_* (base_tile = the YMI_DCNP_* part).  YMI_EARG when the
 // descriptor is outside what the kernel takes.  Profiling record kind 9.
 int ymi_internal_dcn_h2(const ymi_dcn_desc *dd, int base_tile, hipStream_t s) {
-  return run_pipe(&dd->conv, dd->offmask, dd->ldo, dd->mask_is_prob, base_tile, 9, s);
+  return run_pipe(&dd->conv, dd->offmask, dd->ldo, dd->mask_is_prob, dd->om_layout, base_tile, 9, s);
 }
 
 // internal (called by ymi_conv2d_nhwc_f32): the same pipeline as an ordinary 3x3 / pad 1 or 1x1 / pad 0 convolution.  Kind 10.
 int ymi_internal_pipe_conv(const ymi_conv_desc *d, int base_tile, hipStream_t s) {
-  return run_pipe(d, nullptr, 0, 0, base_tile, 10, s);
+  return run_pipe(d, nullptr, 0, 0, 0, base_tile, 10, s);
 }

@@ -223,6 +223,21 @@ def wino_eligible(pk, res, segs, act, x_C):
     return pk.Cout % 4 == 0 and act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LEAKY01)
 
 
+def pack_offmask(conv: nn.Conv2d, device, interleave: bool) -> Packed:
+    """conv_offset_mask of a DCN layer (dcn_v2.py:107-112: 27 filters = 18 offsets | 9 mask logits) with its filter ROWS zero-padded
+    to 32 — a full 128-byte line per pixel, and Cout % 4 == 0 admits the pipelined kernel and its 32-column tiles (YMI_DCNP_*x32) —
+    and, `interleave`, permuted to [dh_k, dw_k, mask_k] per tap (ymi_dcn_desc.om_layout = 1: one 12-byte load per tap in the gather
+    kernel).  The arithmetic of the 27 real channels is untouched: same filters, same order of accumulation."""
+    w, b = conv.weight.detach().float(), conv.bias.detach().float()
+    assert w.shape[0] == 27 and conv.stride[0] == conv.stride[1] and conv.padding == (1, 1), 'conv_offset_mask of a 3x3 one-group DCN'
+    order = [c for k in range(9) for c in (2 * k, 2 * k + 1, 18 + k)] if interleave else list(range(27))
+    wp, bp = w.new_zeros((32,) + tuple(w.shape[1:])), b.new_zeros(32)
+    wp[:27], bp[:27] = w[order], b[order]
+    pk = Packed(wp, bp, None, conv.stride[0], 1, None, device)
+    pk.cout_alg = 27
+    return pk
+
+
 def pack_module(conv: nn.Conv2d, bn=None, device=None, cin_pad=None) -> Packed:
     assert conv.dilation == (1, 1) and conv.groups == 1
     assert conv.stride[0] == conv.stride[1] and conv.padding[0] == conv.padding[1]
@@ -327,6 +342,9 @@ class Plan:
         # YOLACT_AMD_WIDE_GUARD=0: keep fp16x2 tiles even on layers whose filters give away outlier input channels (tests of the
         # unguarded behaviour); default: such layers run on bf16x3 tiles (Packed.tiny_columns)
         self.wide_guard = os.environ.get('YOLACT_AMD_WIDE_GUARD', '1') == '1'
+        # DCN layers: conv_offset_mask padded to 32 filters / tap-interleaved channel order (pack_offmask); 0 = the reference's 27 / order
+        self.om_pad = os.environ.get('YOLACT_AMD_OM_PAD', '1') == '1'
+        self.om_interleave = os.environ.get('YOLACT_AMD_OM_INTERLEAVE', '1') == '1'
         self.wide_ops = set()
         self._sk_ws = {}
         self.down_on_side_stream = os.environ.get('YOLACT_AMD_DOWN_STREAM', 'B') == 'B'      # measured +1 %
@@ -427,6 +445,7 @@ class Plan:
             dd = L.DcnDesc()
             dd.conv = d
             dd.offmask, dd.ldo = dcn_offmask.ptr, dcn_offmask.C
+            dd.om_layout = 1 if (self.om_pad and self.om_interleave) else 0
             self.ops.append((self.lib.ymi_dcn_v2_forward_f32, C.pointer(dd), name, self._cur))
             self.conv_meta.append((name, dd.conv))
             if wide:
@@ -770,7 +789,8 @@ class Plan:
                 o1 = self.conv(nm + '.conv1', x, pack_module(blk.conv1, blk.bn1, dev), act=L.ACT_RELU)
                 if blk.use_dcn:
                     dcn = blk.conv2
-                    om = self.conv(nm + '.offmask', o1, pack_module(dcn.conv_offset_mask, None, dev))
+                    om = self.conv(nm + '.offmask', o1, pack_offmask(dcn.conv_offset_mask, dev, self.om_interleave) if self.om_pad
+                                   else pack_module(dcn.conv_offset_mask, None, dev))
                     pk = Packed(dcn.weight, dcn.bias, blk.bn2, dcn.stride[0], 1, None, dev)     # (stride is a pair, dcn_v2.py:62)
                     o2 = self.conv(nm + '.dcn', o1, pk, act=L.ACT_RELU, dcn_offmask=om)
                     ar.free(om)
@@ -1020,8 +1040,8 @@ class Plan:
         out = []
         for t, name in sorted(L.DCNP_TILES.items()):
             bm, bn = (int(v) for v in name[4:].split('w')[0].split('x'))
-            if (bn > 128 and d.Cout < 256) or (dcn and t in L.DCNP_PLAIN_ONLY):
-                continue
+            if (bn > 128 and d.Cout < 256) or (dcn and t in L.DCNP_PLAIN_ONLY) or (bn == 32) != (d.Cout <= 32):
+                continue                                  # (32-column tiles: the Cout <= 32 layers, and nothing else for those)
             tid = t | L.TILE_H2 | L.TILE_DCNP
             out.append(tid)
             blocks = -(-M // bm) * -(-d.Cout // bn)
