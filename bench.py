@@ -62,7 +62,7 @@ def kernel_peak(name):
     bounded by the fp32 MFMA peak, the `...x3` tiles (fp32-class products as 6 bf16 MFMAs) by bf16 peak / 6, the `...h2`
     tiles (3 fp16 MFMAs) by fp16 peak / 3."""
     tile = name.split('<', 1)[1].split(',', 1)[0] if '<' in name else ''
-    return X3_PEAK_TFLOPS if tile.endswith('x3') else H2_PEAK_TFLOPS if (tile.endswith('h2') or tile.startswith('dcnp')) \
+    return X3_PEAK_TFLOPS if tile.endswith('x3') else H2_PEAK_TFLOPS if (tile.endswith('h2') or tile.startswith('dcnp') or tile.startswith('ws')) \
         else FP32_MFMA_PEAK_TFLOPS
 
 
@@ -126,6 +126,7 @@ def roofline(net, x, reps=3):
     # record kinds: 0/1/2 = one direct conv launch (loader id), 7 = a direct 1x1 launch on the pointwise loader (kernel
     # template LOADER 3); 3 / 4 = a whole Winograd F(2x2) / F(4x4) layer (input transform + 16- / 36-group GEMM + output
     # transform, ALGORITHMIC conv FLOPs); 5 / 6 = the Winograd GEMM launch alone (the FLOPs it executes).
+    # 11 = the weight-stationary streaming kernel (csrc/wstat.hip); 12 = a 1x1 layer fused into the previous layer's output transform.
     # 9 = the pipelined DCNv2 gather-GEMM (csrc/dcn.hip: pipe_h2_k<..., PLAIN = false>), 10 = the same kernel as an ordinary 3x3 / 1x1
     # convolution (PLAIN = true).
     # 8 = the fused ResNet stem launch (layout change + 7x7 conv + BN + ReLU + max-pool; the conv's algorithmic FLOPs).
@@ -141,6 +142,13 @@ def roofline(net, x, reps=3):
     for i in range(n):
         L.check(lib.ymi_prof_read(i, C.byref(ms), C.byref(fl), C.byref(tile), C.byref(kind)))
         tname = L.TILE_NAMES.get(tile.value, '?')
+        if kind.value == 12:      # a 1x1 layer computed INSIDE the previous layer's F(4x4) output transform (ymi_wino_desc.proj_*): its
+            li += 1               # algorithmic FLOPs count for the step, its time is part of that layer's record
+            la = layers.setdefault(names[li % nl], [0.0, fl.value, ''])
+            la[0] += ms.value / reps
+            la[2] = 'fused into the output transform of the layer above (wino43_out_proj_k)'
+            tot_ms += ms.value; tot_fl += fl.value
+            continue
         # algorithmic bytes of this record and its lower-bound time (sum over layers of max(F/peak, bytes/BW))
         if kind.value in (3, 4):                     # a whole Winograd layer: remember its geometry for the GEMM record
             wino_pending = wino_bytes(descs[(li + 1) % nl], 2 * kind.value - 4)
@@ -162,7 +170,7 @@ def roofline(net, x, reps=3):
                 dd_ = descs[(li + 1) % nl]
                 nbytes += 4.0 * dd_.B * dd_.Ho * dd_.Wo * 27
         if kind.value not in (3, 4):
-            pk_ = (X3_PEAK_TFLOPS if tname.endswith('x3') else H2_PEAK_TFLOPS if (tname.endswith('h2') or tname.startswith('dcnp'))
+            pk_ = (X3_PEAK_TFLOPS if tname.endswith('x3') else H2_PEAK_TFLOPS if (tname.endswith('h2') or tname.startswith('dcnp') or tname.startswith('ws'))
                    else FP32_MFMA_PEAK_TFLOPS)
             t_m, t_h = fl.value / (pk_ * 1e12) * 1e3, nbytes / (HBM_PEAK_GBPS * 1e9) * 1e3
             bound_ms['mfma' if t_m >= t_h else 'hbm'] += max(t_m, t_h) / reps
@@ -174,6 +182,7 @@ def roofline(net, x, reps=3):
                 if kind.value in (3, 4) else 'stem_pool_k<%s,conv 7x7/2 + BN + ReLU + max-pool 3x3/2 fused>' % tname if kind.value == 8 \
                 else 'pipe_h2_k<%s,DCNv2 gather>' % tname if kind.value == 9 \
                 else 'pipe_h2_k<%s,convolution>' % tname if kind.value == 10 \
+                else 'ws_h2_k<%s,convolution>' % tname if kind.value == 11 \
                 else 'conv_igemm_f32<%s,loader%d>' % (tname, 3 if kind.value == 7 else kind.value)
             la = layers.setdefault(names[li % nl], [0.0, fl.value, lkey])
             la[0] += ms.value / reps
@@ -184,6 +193,7 @@ def roofline(net, x, reps=3):
                 ('stem_pool_k<%s,fused stem>' % tname) if kind.value == 8 else \
                 ('pipe_h2_k<%s,DCNv2 gather>' % tname) if kind.value == 9 else \
                 ('pipe_h2_k<%s,convolution>' % tname) if kind.value == 10 else \
+                ('ws_h2_k<%s,convolution>' % tname) if kind.value == 11 else \
                 'conv_igemm_f32<%s,loader%d>' % (tname, 3 if kind.value == 7 else kind.value)
             a = by_kernel.setdefault(key, [0.0, 0.0, 0, 0.0, 0.0, 0.0])
             a[0] += ms.value; a[1] += fl.value; a[2] += 1; a[3] += nbytes

@@ -146,7 +146,13 @@ enum { YMI_DCNP_64x128 = 1, YMI_DCNP_64x128_W8 = 2, YMI_DCNP_64x64 = 3, YMI_DCNP
        /* 32 output channels per block (ordinary convolutions only): the 27-channel conv_offset_mask of a DCN layer
         * (dcn_v2.py:107-112) with its filters zero-padded to 32 — the cost of such a layer is staging its input, so a block
         * spends its waves on rows, not on columns nobody needs */
-       YMI_DCNP_128x32_W4 = 17, YMI_DCNP_256x32_W8 = 18, YMI_DCNP_64x32_W2 = 19 };
+       YMI_DCNP_128x32_W4 = 17, YMI_DCNP_256x32_W8 = 18, YMI_DCNP_64x32_W2 = 19,
+       /* the weight-stationary streaming kernel of csrc/wstat.hip (ordinary convolutions with Cout <= 32 / <= 64, no residual):
+        * the filters of the block's K range stay in LDS, every wave streams its own rows from global memory straight into MFMA
+        * operand registers, no barrier in the loop.  BM x BN, _W4 / _W8 = waves per block (32 or 64 rows per wave).  The K range
+        * of a block must fit 64 KB of LDS: ymi_conv_desc.split_k >= Kpad * BN / 16384 (YMI_EARG otherwise) */
+       YMI_DCNP_WS_128x32_W4 = 20, YMI_DCNP_WS_256x32_W8 = 21, YMI_DCNP_WS_256x32_W4 = 22, YMI_DCNP_WS_512x32_W8 = 23,
+       YMI_DCNP_WS_128x64_W4 = 24, YMI_DCNP_WS_256x64_W8 = 25, YMI_DCNP_WS_256x64_W4 = 26, YMI_DCNP_WS_512x64_W8 = 27 };
 
 int ymi_abi_version(void);
 const char *ymi_strerror(int code);
@@ -198,6 +204,16 @@ typedef struct {
    * tensor: protonet's interpolate -> conv (utils/functions.py:187-206, yolact.py:588-599).  x_amax = the bound of x_up. */
   const float *x_up;
   int32_t up_relu, _pad4;
+  /* ABI 6, m = 4, nseg = 0, Cout = 256 only.  proj_w_h2 != NULL: the layer's output is consumed by ONE 1x1 convolution to
+   * proj_cout <= 32 channels (protonet's last layer, utils/functions.py:163-213: conv3x3 + ReLU -> conv1x1) and nothing else; the
+   * output transform multiplies every 4x4 tile by those filters while it is in registers / LDS and writes
+   * proj_y [B,H,W,proj_ldy] = act2(conv1x1(act(conv3x3(x)))) — `y` is not written (may be NULL), y_amax is not updated.
+   * proj_w_h2 / proj_scale_h2: the 1x1's fp16x2 filter planes [2][128][256] and scale_h2 [128] (ymi_conv_desc.w_h2 / scale_h2 of
+   * the same layer); the tile is scaled by a power of two derived from its own maximum, so no magnitude bound of y is needed. */
+  const void *proj_w_h2;
+  const float *proj_scale_h2, *proj_bias;   /* proj_bias may be NULL */
+  float *proj_y, *proj_y_amax;              /* proj_y_amax: magnitude-bound slot of proj_y, may be NULL */
+  int32_t proj_cout, proj_ldy, proj_act, _pad5;
 } ymi_wino_desc;
 int ymi_conv3x3_winograd_f32(const ymi_wino_desc *d, void *stream);
 

@@ -88,7 +88,8 @@ def build_net(meta, device=DEV):
     return net.to(device)
 
 
-def run_wino(x, weight, bias=None, bn=None, act=L.ACT_NONE, tile=L.TILE_AUTO, m=2, v_planes=False, up_from=None, up_relu=False):
+def run_wino(x, weight, bias=None, bn=None, act=L.ACT_NONE, tile=L.TILE_AUTO, m=2, v_planes=False, up_from=None, up_relu=False,
+             proj=None):
     """3x3 / stride 1 / pad 1 conv through ymi_conv3x3_winograd_f32. x: CPU NCHW. Returns CPU NCHW.
     up_from (CPU NCHW, half the size of x): the launch interpolates its input from it (ymi_wino_desc.x_up); `x` only gives the shape."""
     from yolact_amd.engine import WinoPacked
@@ -118,7 +119,21 @@ def run_wino(x, weight, bias=None, bn=None, act=L.ACT_NONE, tile=L.TILE_AUTO, m=
     if tile & L.TILE_H2:
         up, uinv = wp.h2()
         d.u_h2, d.uinv_h2, d.v_planes = up.data_ptr(), uinv.data_ptr(), 1 if v_planes else 0
+    py = None
+    if proj is not None:       # (weight [n,256,1,1], bias or None, act): the consuming 1x1 fused into the output transform; y is not written
+        pw, pb, pact = proj
+        ppk = Packed(pw, pb, None, 1, 0, None, DEV)
+        planes, sc2, _ = ppk.h2()
+        py = torch.full((B, H, W, pw.shape[0]), float('nan'), device=DEV)
+        d.proj_w_h2, d.proj_scale_h2 = planes.data_ptr(), sc2.data_ptr()
+        d.proj_bias = ppk.bias.data_ptr() if ppk.bias is not None else None
+        d.proj_y, d.proj_y_amax = py.data_ptr(), amax.data_ptr() + 4096
+        d.proj_cout, d.proj_ldy, d.proj_act = pw.shape[0], pw.shape[0], pact
+        d.y = None
     L.check(L.lib().ymi_conv3x3_winograd_f32(C.byref(d), L.stream_ptr()), 'winograd')
     torch.cuda.synchronize()
     run_wino.last_amax = amax.view(2, 1024).amax(1).cpu().tolist()
+    if py is not None:
+        assert torch.isnan(y).all()                   # the 3x3's own output was not touched
+        return nchw(py.cpu())
     return nchw(y.cpu())

@@ -209,6 +209,31 @@ def test_outlier_guard_is_silent_on_the_timed_plan():
     assert not plan.wide_ops and plan.tune_misses == 0
 
 
+def test_timed_plan_fuses_the_last_1x1_into_the_output_transform():
+    """The batch-8 plan of configs[1] runs proto.8 as F(4x4,3x3), so proto.10 (1x1, 256 -> 32) is computed inside its output
+    transform (ymi_wino_desc.proj_*; the 156 MB tensor between them is never written): the op is gone from the launch list, and the
+    prototypes equal those of the two separate launches to fp32 rounding of a 256-term sum (YOLACT_AMD_WINO_PROJ=0)."""
+    tag, config, B, size, seed, gain, img_seed = CASES[0]
+    x = synth_images(B, size, size, seed=img_seed).to(DEV)
+    net, sd = _build(config, seed, gain)
+    plan = net.plan_for(x)
+    assert any(op[0] == 'nop' and op[2].startswith('proto.10[fused into proto.8') for op in plan.ops), [op[2] for op in plan.ops if 'proto' in op[2]]
+    with torch.no_grad():
+        fused = net.forward_raw(x)['proto'].clone()
+    os.environ['YOLACT_AMD_WINO_PROJ'] = '0'
+    try:
+        net2, _ = _build(config, seed, gain)
+        plan2 = net2.plan_for(x)
+        assert not any(op[0] == 'nop' and op[2].startswith('proto.10') for op in plan2.ops)
+        with torch.no_grad():
+            two = net2.forward_raw(x)['proto']
+    finally:
+        del os.environ['YOLACT_AMD_WINO_PROJ']
+    err = ((fused - two).abs().max() / two.abs().max()).item()
+    print('fused projection vs two launches: %.2e of max|proto|' % err)
+    assert err < 2e-5
+
+
 def test_plan_is_deterministic_across_processes():
     """The default plan comes from the shipped tune table, so two fresh processes produce identical bits (the round-1
     plan timed its tiles per process: K-split tiles change the summation order, i.e. the bits)."""

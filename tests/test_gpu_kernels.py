@@ -354,6 +354,101 @@ def test_offset_mask_convolution_on_the_32_column_tiles(tile, split):
     assert torch.equal(y, run_conv(x, w, b, None, 1, 1, tile=t, split_k=split if split > 1 else 0))
 
 
+@pytest.mark.parametrize('case', [(2, 26, 22, 32, L.ACT_RELU, L.ACT_RELU, True), (1, 17, 23, 28, L.ACT_RELU, L.ACT_NONE, False),
+                                  (3, 8, 12, 4, L.ACT_NONE, L.ACT_LEAKY01, True)])
+@pytest.mark.parametrize('tile', [L.TILE_128x128 | L.TILE_H2, L.TILE_64x64])
+def test_winograd_output_transform_fused_with_the_consuming_1x1(case, tile):
+    """ymi_wino_desc.proj_*: conv3x3(256 -> 256) + act -> conv1x1(256 -> n <= 32) + act2 with the 3x3's output never written
+    (protonet's last two layers, utils/functions.py:163-213) against torch fp32 and against the two separate launches: ragged edge
+    tiles (H, W not multiples of 4), batch > 1, n < 32, with / without a bias on the 1x1; the bound reported for the projected tensor."""
+    from gpu_utils import run_wino, run_conv, rel_err
+    B, H, W, n, act, act2, pbias = case
+    g = _g(800 + H + n)
+    x = torch.randn(B, 64, H, W, generator=g)
+    w = torch.randn(256, 64, 3, 3, generator=g) / 24
+    b = torch.randn(256, generator=g) * 0.2
+    pw = torch.randn(n, 256, 1, 1, generator=g) / 16
+    pb = torch.randn(n, generator=g) * 0.1 if pbias else None
+
+    def a_(t, a):
+        return torch.relu(t) if a == L.ACT_RELU else F.leaky_relu(t, 0.1) if a == L.ACT_LEAKY01 else t
+    mid = a_(F.conv2d(x, w, b, 1, 1), act)
+    ref = a_(F.conv2d(mid, pw, pb), act2)
+    y = run_wino(x, w, b, None, act=act, tile=tile, m=4, proj=(pw, pb, act2))
+    assert rel_err(y, ref) < 3e-5
+    assert abs(run_wino.last_amax[1] - ref.abs().max().item()) <= 3e-5 * ref.abs().max().item()
+    two = run_conv(run_wino(x, w, b, None, act=act, tile=tile, m=4), pw, pb, None, 1, 0, act=act2, tile=L.TILE_64x64 | L.TILE_H2)
+    assert rel_err(y, two) < 3e-5
+    assert torch.equal(y, run_wino(x, w, b, None, act=act, tile=tile, m=4, proj=(pw, pb, act2)))
+
+
+def test_winograd_fused_projection_rejects_what_it_cannot_run():
+    from gpu_utils import run_wino
+    g = _g(3)
+    x = torch.randn(1, 32, 8, 8, generator=g)
+    pw = torch.randn(32, 256, 1, 1, generator=g)
+    with pytest.raises(RuntimeError):                                     # F(2x2): the fused kernel is the F(4x4) output transform
+        run_wino(x, torch.randn(256, 32, 3, 3, generator=g), None, None, m=2, proj=(pw, None, L.ACT_NONE))
+    with pytest.raises(RuntimeError):                                     # 128 dense channels, not 256
+        run_wino(x, torch.randn(128, 32, 3, 3, generator=g), None, None, m=4, proj=(pw[:, :128], None, L.ACT_NONE))
+    with pytest.raises(RuntimeError):                                     # 48 projected channels
+        run_wino(x, torch.randn(256, 32, 3, 3, generator=g), None, None, m=4, proj=(torch.randn(48, 256, 1, 1, generator=g), None, L.ACT_NONE))
+
+
+WS_ALL = [t | L.TILE_H2 | L.TILE_DCNP for t in sorted(L.WS_TILES)]                     # every block shape of csrc/wstat.hip
+
+
+def _ws_splits(tile, nk):
+    """K-range counts a weight-stationary tile accepts for nk chunks: its filters must fit 64 KB (16 chunks at 32 columns, 8 at 64)."""
+    cap = 16 if L.WS_TILES[tile & 31].split('x')[1].startswith('32') else 8
+    return [S for S in (1, 2, 3, 4, 5, 6, 8, 9, 12, 16) if -(-nk // S) <= cap and (S == 1 or -(-nk // S) * (S - 1) < nk)]
+
+
+@pytest.mark.parametrize('tile', WS_ALL)
+@pytest.mark.parametrize('case', [(2, 64, 19, 17, 32, 3, 1, L.ACT_RELU), (1, 128, 23, 21, 28, 3, 2, L.ACT_NONE),
+                                  (3, 256, 14, 15, 32, 1, 1, L.ACT_LEAKY01), (2, 64, 31, 29, 64, 1, 1, L.ACT_RELU),
+                                  (1, 32, 9, 10, 36, 3, 1, L.ACT_NONE), (2, 96, 12, 13, 4, 1, 2, L.ACT_RELU),
+                                  (1, 160, 40, 37, 32, 3, 1, L.ACT_NONE)])
+def test_weight_stationary_streaming_kernel(case, tile):
+    """csrc/wstat.hip (filters of the block's K range resident in LDS, activations streamed from global memory straight into MFMA
+    operand registers, no barrier in the loop) against torch fp32: 3x3 / pad 1 and 1x1, stride 1 / 2, ragged row tiles and waves
+    past the last row, odd chunk counts, K ranges that start inside a tap, Cout < the tile's columns; the fewest K ranges the
+    tile accepts and the most; bit-reproducible; the magnitude bound it reports."""
+    from gpu_utils import run_conv, rel_err
+    B, Cin, H, W, Cout, k, stride, act = case
+    if Cout > int(L.WS_TILES[tile & 31].split('x')[1].split('w')[0]):
+        pytest.skip('more output channels than the tile has columns (rejected: test_weight_stationary_kernel_rejects...)')
+    g = _g(700 + Cin + Cout + k)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    pad = 1 if k == 3 else 0
+    ref = F.conv2d(x, w, b, stride, pad)
+    ref = torch.relu(ref) if act == L.ACT_RELU else F.leaky_relu(ref, 0.1) if act == L.ACT_LEAKY01 else ref
+    splits = _ws_splits(tile, k * k * Cin // 32)
+    for S in sorted({splits[0], splits[-1]}):
+        y = run_conv(x, w, b, None, stride, pad, act=act, tile=tile, split_k=S if S > 1 else 0)
+        assert rel_err(y, ref) < 2e-5, S
+        assert abs(run_conv.last_amax[1] - ref.abs().max().item()) <= 2e-5 * ref.abs().max().item()
+        assert torch.equal(y, run_conv(x, w, b, None, stride, pad, act=act, tile=tile, split_k=S if S > 1 else 0))
+
+
+def test_weight_stationary_kernel_rejects_what_it_cannot_run():
+    from gpu_utils import run_conv
+    g = _g(9)
+    x = torch.randn(1, 64, 9, 9, generator=g)
+    t32, t64 = (L.TILE_H2 | L.TILE_DCNP | v for v in (L.DCNP_WS_128x32_W4, L.DCNP_WS_512x64_W8))
+    with pytest.raises(RuntimeError):                                     # 48 output channels on a 32-column tile
+        run_conv(x, torch.randn(48, 64, 1, 1, generator=g), None, None, 1, 0, tile=t32)
+    with pytest.raises(RuntimeError):                                     # 18 chunks of 64 columns do not fit 64 KB unsplit
+        run_conv(x, torch.randn(64, 64, 3, 3, generator=g), None, None, 1, 1, tile=t64)
+    with pytest.raises(RuntimeError):                                     # residual: not this kernel's epilogue
+        run_conv(x, torch.randn(32, 64, 1, 1, generator=g), None, None, 1, 0, tile=t32, res=torch.randn(1, 32, 9, 9, generator=g),
+                 res_mode=L.RES_ADD)
+    with pytest.raises(RuntimeError):                                     # Cout % 4 != 0
+        run_conv(x, torch.randn(30, 64, 1, 1, generator=g), None, None, 1, 0, tile=t32)
+
+
 def test_dcn_pipelined_rejects_what_it_cannot_run():
     """An explicit YMI_TILE_DCNP request outside the kernel's envelope is an error code, never a silent other kernel."""
     from gpu_utils import run_conv

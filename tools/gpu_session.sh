@@ -15,6 +15,7 @@
 #   probe        tools/split_probe.hip (register/LDS-level ceilings of the split-precision schemes)
 #   dcnref       build oracle/_ref on the box if missing, run the reference-compiled DCN parity test
 #   evalpy       the reference's unmodified eval.py against the engine (needs the scratch copy staged by tools/stage_reference.sh)
+#   envab:VAR=a,b  same-box A/B of an environment switch on the configs[1] bench
 #   plusab       A/B of the DCN offset / mask convolution layouts on configs[3];   tuneplus = re-tune configs[3] + bench with the layer table
 #   py:<file>    python <file> (a probe under tools/), output to <file basename>.log
 O=gpurun_out/$1; shift; mkdir -p $O
@@ -102,6 +103,11 @@ PY
     pipeabl) # diagnostics build of csrc/dcn.hip, then the ablation of the pipelined kernel as an ordinary convolution on representative layers
       (cd yolact_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-value -I../../include -DYMI_DIAGNOSTICS=1 -c dcn.hip -o /tmp/dcn_diag.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls *.o | grep -v '^dcn.o$') /tmp/dcn_diag.o -o ../libyolact_amd.so) > $O/pipeabl_build.log 2>&1; tail -2 $O/pipeabl_build.log
       timeout 600 python tools/pipe_probe.py --layers ${arg:-proto.8,proto.2,layer1.1.conv2,layer1.1.conv1,layer2.1.conv1,layer3.0.conv1,layer2.1.conv3} --ablate 1,2,3,4,8,12,16,15,31 > $O/pipe_ablation.txt 2>&1; grep -E "abl=|pipelined" $O/pipe_ablation.txt | cut -c1-330 ;;
+    envab) # same-box A/B of one environment switch on the configs[1] bench: envab:YOLACT_AMD_WINO_PROJ=1,0 (values alternate twice)
+      var="${st#*:}"; name="${var%%=*}"; vals="${var#*=}"
+      for rep in 1 2; do for v in ${vals//,/ }; do
+        env $name=$v timeout 300 python bench.py --steps 30 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('$name=$v', d['value'], d['ms_per_step'], 'misses', d['config']['plan']['tune_misses'])"
+      done; done | tee -a $O/envab.txt ;;
     plusab) # same-box A/B of the DCN offset / mask convolution variants on configs[3] (R50++ B=8): padded + tap-interleaved (default), padded only, the reference's 27 channels
       PB="python bench.py --config yolact_plus_resnet50_config --batch 8 --steps 20 --no-cpu-baseline --no-secondary"
       for v in "1 1" "1 0" "0 0" "1 1"; do set -- $v

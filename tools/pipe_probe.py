@@ -23,6 +23,7 @@ def main():
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--reps', type=int, default=5)
     ap.add_argument('--layers', default='')
+    ap.add_argument('--no-ws', action='store_true', help='leave out the weight-stationary streaming kernel (csrc/wstat.hip)')
     ap.add_argument('--all-cands', action='store_true', help='print every candidate, not only the best')
     ap.add_argument('--ablate', default='', help='comma list of YMI_DCN_ABLATE masks (diagnostics build): the best candidate is re-timed per mask')
     ap.add_argument('--tiles', default='', help='restrict the pipelined candidates to these names (e.g. dcnp128x256w16,dcnp160x128w10/k2)')
@@ -71,7 +72,7 @@ def main():
         if d0 is None or (args.layers and not any(k in base for k in args.layers.split(','))):
             continue
         if not (((d0.kh, d0.kw, d0.pad) in ((3, 3, 1), (1, 1, 0))) and d0.Cin % 32 == 0 and d0.nseg == 1 and d0.Cout % 4 == 0
-                and d0.seg[0].act <= L.ACT_LEAKY01 and d0.res_mode in (L.RES_NONE, L.RES_ADD) and d0.Kpad // 32 >= 4 and d0.w_h2):
+                and d0.seg[0].act <= L.ACT_LEAKY01 and d0.res_mode in (L.RES_NONE, L.RES_ADD) and d0.Kpad // 32 >= 2 and d0.w_h2):
             continue
         fl = lib.ymi_conv_flops(C.byref(d0))
         t_plan = timed(fn, arg)
@@ -92,7 +93,7 @@ def main():
             ref.copy_(ref_src)
         d.seg[0].ptr = yref.data_ptr()
         times, devmax = {}, {}
-        for cand in plan.dcnp_candidates(d):
+        for cand in plan.dcnp_candidates(d) + (plan.ws_candidates(d) if not args.no_ws else []):
             if args.tiles and tname(cand) not in args.tiles.split(','):
                 continue
             tile, S = cand & 255, cand >> 8

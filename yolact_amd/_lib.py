@@ -43,7 +43,11 @@ DCNP_TILES = {1: 'dcnp64x128', 2: 'dcnp64x128w8', 3: 'dcnp64x64', 4: 'dcnp128x12
               17: 'dcnp128x32w4', 18: 'dcnp256x32w8', 19: 'dcnp64x32w2'}
 DCNP_128x32_W4, DCNP_256x32_W8, DCNP_64x32_W2 = 17, 18, 19
 DCNP_PLAIN_ONLY = (14, 15, 16, 17, 18, 19)     # 64x64 wave tiles, 32-column tiles: ordinary convolutions only
-for _t, _n in DCNP_TILES.items():
+# the weight-stationary streaming kernel (csrc/wstat.hip): Cout <= 32 (.._x32) / <= 64 (.._x64), ordinary convolutions, no residual
+WS_TILES = {20: 'ws128x32w4', 21: 'ws256x32w8', 22: 'ws256x32w4', 23: 'ws512x32w8',
+            24: 'ws128x64w4', 25: 'ws256x64w8', 26: 'ws256x64w4', 27: 'ws512x64w8'}
+DCNP_WS_128x32_W4, DCNP_WS_512x64_W8 = 20, 27
+for _t, _n in list(DCNP_TILES.items()) + list(WS_TILES.items()):
     TILE_NAMES[_t | TILE_H2 | TILE_DCNP] = _n
 WINO_PLANES = 1024                  # tune-table flag on a Winograd GEMM tile id: V written as fp16x2 planes (ymi_wino_desc.v_planes)
 KSPLIT_TILES = (6, 7, 8, 13, 14, 15, 6 | 32, 7 | 32, 8 | 32, 6 | 64, 7 | 64, 8 | 64, 13 | 64, 14 | 64, 15 | 64)   # different (still deterministic) fp32 summation order than the unsplit tiles
@@ -76,7 +80,10 @@ class WinoDesc(C.Structure):
                 ('act', C.c_int32), ('tile', C.c_int32), ('nseg', C.c_int32), ('m', C.c_int32), ('_pad0', C.c_int32),
                 ('seg', ConvSeg * 3), ('u_x3', C.c_void_p), ('cout_alg', C.c_int32), ('v_planes', C.c_int32),
                 ('u_h2', C.c_void_p), ('uinv_h2', C.c_void_p), ('x_amax', C.c_void_p), ('y_amax', C.c_void_p),
-                ('x_up', C.c_void_p), ('up_relu', C.c_int32), ('_pad4', C.c_int32)]
+                ('x_up', C.c_void_p), ('up_relu', C.c_int32), ('_pad4', C.c_int32),
+                ('proj_w_h2', C.c_void_p), ('proj_scale_h2', C.c_void_p), ('proj_bias', C.c_void_p),
+                ('proj_y', C.c_void_p), ('proj_y_amax', C.c_void_p),
+                ('proj_cout', C.c_int32), ('proj_ldy', C.c_int32), ('proj_act', C.c_int32), ('_pad5', C.c_int32)]
 
 
 class DcnDesc(C.Structure):

@@ -1455,6 +1455,7 @@ int ymi_internal_grouped_gemm(const ymi_conv_desc *d, int groups, long x_gs, lon
 int ymi_internal_dcn_h2(const ymi_dcn_desc *dd, int base_tile, hipStream_t s);   // csrc/dcn.hip (C++ linkage: internal)
 
 int ymi_internal_pipe_conv(const ymi_conv_desc *d, int base_tile, hipStream_t s); // csrc/dcn.hip: the same pipeline, ordinary convolution
+int ymi_internal_ws_conv(const ymi_conv_desc *d, int base_tile, hipStream_t s);   // csrc/wstat.hip: weight-stationary streaming kernel (Cout <= 64)
 
 // internal (csrc/dcn.hip): the second pass of a split-K launch for a dense [M, Cout] output (Cout % 4 == 0, 16-byte aligned rows)
 int ymi_internal_splitk_fixup(const float *part, long gstride, int S, long M, int Cout, int ldy, float *y, const float *scale,
@@ -1483,6 +1484,7 @@ int ymi_conv2d_nhwc_f32(const ymi_conv_desc *d, void *stream) {
     if (!(d->tile & YMI_TILE_H2) || (d->tile & YMI_TILE_X3)) return YMI_EARG;
     const int rc = validate(d, 0);
     if (rc) return rc;
+    if ((d->tile & 31) >= YMI_DCNP_WS_128x32_W4) return ymi_internal_ws_conv(d, d->tile & 31, (hipStream_t)stream);
     return ymi_internal_pipe_conv(d, d->tile & 31, (hipStream_t)stream);
   }
   if (d->split_k > 1) return run_splitk(d, (hipStream_t)stream);

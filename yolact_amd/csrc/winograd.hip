@@ -466,6 +466,118 @@ __global__ __launch_bounds__(256) void wino43_out_k(const float *__restrict__ Mm
   if (y_amax) ymi_amax_finish(apre, am);
 }
 
+// ---- F(4x4,3x3) output transform + the 1x1 convolution that consumes it, in one launch (ymi_wino_desc.proj_*) ------------------
+// protonet ends conv3x3(256 -> 256) + ReLU -> conv1x1(256 -> 32) (utils/functions.py:163-213, yolact.py:588-599): the 3x3's output
+// at 138 x 138 x 8 is 156 MB written by the output transform and read back by a layer of 2.5 GFLOP.  Here a wave owns one 4x4 tile
+// x all 256 channels (lane = 4 channels, as in wino43_out_k), keeps scale / bias / ReLU'd values in registers, writes them to LDS as
+// the two fp16 planes of the fp16x2 arithmetic (power-of-two scale from the TILE's own maximum: exact, no tensor-wide bound
+// needed), and multiplies the [16 pixels x 256] tile by the 1x1 filters [256 x 32] (resident in LDS for the block's lifetime) on
+// v_mfma_f32_16x16x32_f16 — issued as W Y^T so that a lane ends with four consecutive output channels of one pixel.  The 3x3's
+// output never exists in memory.  LDS rows are 512 + 16 bytes: lanes of a 16-lane read phase hit 16 different bank groups.
+struct ProjArgs {
+  const void *w_h2; const float *scale_h2, *bias; float *y, *y_amax;
+  int cout, ldy, act; unsigned w_plane;
+};
+constexpr int PJ_ROW = 528, PJ_YPLANE = 16 * PJ_ROW, PJ_WPLANE = 32 * PJ_ROW, PJ_LDS = 2 * PJ_WPLANE + 4 * 2 * PJ_YPLANE;
+
+__global__ __launch_bounds__(256) void wino43_out_proj_k(const float *__restrict__ Mm, const float *__restrict__ scale,
+                                                         const float *__restrict__ bias, int Ho, int Wo, int th, int tw, long T,
+                                                         int act, const ProjArgs pp) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __shared__ __attribute__((aligned(16))) char lds[PJ_LDS];
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int lr = lane & 15, g = lane >> 4;
+  const ymi_amax_pre apre = ymi_amax_prefetch(pp.y_amax);
+  // the 1x1 filters: planes [2][CoutPad][256] fp16 -> LDS [2][32][528 B] (rows past cout are the zero padding rows of the pack)
+  for (int u = t; u < 2 * 32 * 32; u += 256) {          // 16-byte pieces: (plane, row, piece of 32)
+    const int plane = u >> 10, row = (u >> 5) & 31, pc = u & 31;
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(pp.w_h2) + (size_t)plane * pp.w_plane + (size_t)row * 512 + pc * 16);
+    *reinterpret_cast<f32x4 *>(lds + plane * PJ_WPLANE + row * PJ_ROW + pc * 16) = v;
+  }
+  __syncthreads();
+  char *ytile = lds + 2 * PJ_WPLANE + wave * (2 * PJ_YPLANE);
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+  if (scale) sc = *reinterpret_cast<const f32x4 *>(scale + lane * 4);
+  if (bias) bi = *reinterpret_cast<const f32x4 *>(bias + lane * 4);
+  const float slope = act == YMI_ACT_RELU ? 0.f : (act == YMI_ACT_LEAKY01 ? 0.1f : 1.f);
+  const float slope2 = pp.act == YMI_ACT_RELU ? 0.f : (pp.act == YMI_ACT_LEAKY01 ? 0.1f : 1.f);
+  float am = 0.f;
+  for (long tl = (long)blockIdx.x * 4 + wave; tl < T; tl += (long)gridDim.x * 4) {
+    const unsigned tu = (unsigned)tl, ru = tu / (unsigned)tw, bu = ru / (unsigned)th;
+    const int tx = (int)(tu - ru * (unsigned)tw), ty = (int)(ru - bu * (unsigned)th);
+    f32x4 o[4][4];
+    wino43_out_tile(Mm + tl * 256L + lane * 4, T * 256L, o);
+    float tm = 0.f;
+#pragma unroll
+    for (int iy = 0; iy < 4; ++iy)
+#pragma unroll
+      for (int ix = 0; ix < 4; ++ix) {
+        f32x4 v = o[iy][ix] * sc + bi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], slope * v[e]);
+        o[iy][ix] = v;
+        tm = fmaxf(tm, ymi_absmax4(v));
+      }
+    const unsigned tmb = ymi_wave_umax63(__builtin_bit_cast(unsigned, tm));
+    float sT, invT;
+    ymi_h2_scale(__builtin_bit_cast(float, (unsigned)__builtin_amdgcn_readlane((int)tmb, 63)), sT, invT);
+#pragma unroll
+    for (int iy = 0; iy < 4; ++iy)
+#pragma unroll
+      for (int ix = 0; ix < 4; ++ix) {
+        const f32x4 v = o[iy][ix] * sT;
+        f16x4 h4, l4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const _Float16 h = (_Float16)v[e];
+          h4[e] = h;
+          l4[e] = (_Float16)(v[e] - (float)h);
+        }
+        char *dst = ytile + (iy * 4 + ix) * PJ_ROW + lane * 8;
+        *reinterpret_cast<f16x4 *>(dst) = h4;
+        *reinterpret_cast<f16x4 *>(dst + PJ_YPLANE) = l4;
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const f16x8 xh = *reinterpret_cast<const f16x8 *>(ytile + lr * PJ_ROW + c * 64 + g * 16);
+      const f16x8 xl = *reinterpret_cast<const f16x8 *>(ytile + PJ_YPLANE + lr * PJ_ROW + c * 64 + g * 16);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const f16x8 wh = *reinterpret_cast<const f16x8 *>(lds + (j * 16 + lr) * PJ_ROW + c * 64 + g * 16);
+        const f16x8 wl = *reinterpret_cast<const f16x8 *>(lds + PJ_WPLANE + (j * 16 + lr) * PJ_ROW + c * 64 + g * 16);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc[j], 0, 0, 0);      // D^T[n][pixel] += W Y^T: h*l, l*h, h*h
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc[j], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                    // (the next tile's plane writes stay behind these reads)
+    // lane: output channels 16 j + 4 g .. + 3 of pixel lr = (iy, ix) = (lr >> 2, lr & 3) of the tile
+    const int oy = 4 * ty + (lr >> 2), ox = 4 * tx + (lr & 3);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = j * 16 + 4 * g;
+      if (n < pp.cout && oy < Ho && ox < Wo) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float r = acc[j][e] * (pp.scale_h2[n + e] * invT) + (pp.bias ? pp.bias[n + e] : 0.f);
+          v[e] = fmaxf(r, slope2 * r);
+        }
+        am = fmaxf(am, ymi_absmax4(v));
+        *reinterpret_cast<f32x4 *>(pp.y + (((long)bu * Ho + oy) * (long)Wo + ox) * pp.ldy + n) = v;
+      }
+    }
+  }
+  if (pp.y_amax) ymi_amax_finish(apre, am);
+#endif
+}
+
 __global__ __launch_bounds__(256) void wino43_out_seg_k(const float *__restrict__ Mm, const SegTab st,
                                                         const float *__restrict__ scale, const float *__restrict__ bias,
                                                         int Ho, int Wo, int N4, int Cout, int th, int tw, long T, long total, float *__restrict__ y_amax) {
@@ -531,7 +643,12 @@ extern "C" int ymi_conv3x3_winograd_f32(const ymi_wino_desc *d, void *stream) {
   if (!d || (!d->x && !d->x_up) || !d->u || !d->V || !d->M) return YMI_ENULL;
   if (d->x_up && (d->m != 4 || (d->H & 1) || (d->W & 1) || (((uintptr_t)d->x_up) & 15))) return YMI_ESHAPE;   // fused 2x upsampling: F(4x4) only
   if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->Cout <= 0 || d->nseg < 0 || d->nseg > 3) return YMI_EARG;
-  if (d->nseg == 0 && (!d->y || (d->Cout & 3) || d->act > YMI_ACT_LEAKY01 || d->act < 0)) return YMI_ESHAPE;
+  const bool proj = d->proj_w_h2 != nullptr;     // fused 1x1 consumer: F(4x4), 256 dense output channels, <= 32 projected ones
+  if (proj && (d->m != 4 || d->nseg != 0 || d->Cout != 256 || d->proj_cout <= 0 || d->proj_cout > 32 || (d->proj_cout & 3) ||
+               (d->proj_ldy & 3) || d->proj_ldy < d->proj_cout || d->proj_act > YMI_ACT_LEAKY01 || d->proj_act < 0))
+    return YMI_ESHAPE;
+  if (proj && (!d->proj_scale_h2 || !d->proj_y || (((uintptr_t)d->proj_w_h2) & 15) || (((uintptr_t)d->proj_y) & 15))) return YMI_ENULL;
+  if (d->nseg == 0 && ((!d->y && !proj) || (d->Cout & 3) || d->act > YMI_ACT_LEAKY01 || d->act < 0)) return YMI_ESHAPE;
   for (int k = 0; k < d->nseg; ++k) if (!d->seg[k].ptr) return YMI_ENULL;
   if (d->C & 31) return YMI_ESHAPE;
   if (d->m != 0 && d->m != 2 && d->m != 4) return YMI_EARG;
@@ -597,6 +714,21 @@ extern "C" int ymi_conv3x3_winograd_f32(const ymi_wino_desc *d, void *stream) {
                          d->Cout, th, tw, T, T * N4, d->y_amax);
     rc = ymi_launch_status();
     ymi_internal_prof_end(outer, s);
+    return rc;
+  }
+  if (proj) {          // output transform + the consuming 1x1 convolution in one launch; y (the 3x3's output) is not written
+    ProjArgs pa;
+    pa.w_h2 = d->proj_w_h2; pa.scale_h2 = d->proj_scale_h2; pa.bias = d->proj_bias; pa.y = d->proj_y; pa.y_amax = d->proj_y_amax;
+    pa.cout = d->proj_cout; pa.ldy = d->proj_ldy; pa.act = d->proj_act; pa.w_plane = (unsigned)(128L * 256 * 2);
+    const long blocks = (T + 3) / 4;
+    hipLaunchKernelGGL(wino43_out_proj_k, dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(256), 0, s, d->M, d->scale, d->bias, d->H,
+                       d->W, th, tw, T, d->act, pa);
+    rc = ymi_launch_status();
+    ymi_internal_prof_end(outer, s);
+    if (rc == YMI_OK) {      // the 1x1 layer keeps its place in the profile: a record of its algorithmic FLOPs and no duration of its own
+      const int pr = ymi_internal_prof_begin(2.0 * d->B * d->H * d->W * 256.0 * d->proj_cout, d->tile ? d->tile : YMI_TILE_64x64, 12, s);
+      ymi_internal_prof_end(pr, s);
+    }
     return rc;
   }
   if (mt == 4)

@@ -698,6 +698,9 @@ class Plan:
         mods = list(net.proto_net)
         conv_idx = [i for i, m in enumerate(mods) if isinstance(m, nn.Conv2d)]
         self.proto_patch = None
+        self.proto_patch_wino = None     # the F(4x4) descriptor that writes the proto tensor when the last 1x1 is fused into it (wino_proj)
+        self.wino_proj = None            # (op index of the 3x3 before the last 1x1, op index of that 1x1): see _tune_winograd
+        prev_conv_op = None
         held = None      # low-res source of a fusable 2x upsampling: the consuming conv's F(4x4) input transform may read IT instead
                          # of the upsampled tensor (ymi_wino_desc.x_up), so its buffer stays allocated until that conv's output
                          # has been allocated — freed earlier, the best-fit arena could hand it to the conv's own output
@@ -722,14 +725,22 @@ class Plan:
                     self.conv('proto.%d' % i, t, pk, segs=[(0, pk.Cout, a, pk.Cout, Ho * Wo * pk.Cout, None)])
                     self.proto_patch = self.ops[-1][1].contents  # seg[0].ptr set per call
                     nt = None
+                    # conv3x3(256 -> 256) + ReLU -> conv1x1(256 -> <= 32): when the 3x3 runs as F(4x4,3x3) its output transform can
+                    # multiply each tile by the 1x1's filters and write the prototypes directly (ymi_wino_desc.proj_*)
+                    if (self.h2 and prev_conv_op is not None and prev_conv_op in self.wino_alt and (pk.kh, pk.kw, pk.stride, pk.pad) == (1, 1, 1, 0)
+                            and pk.Cin == 256 and pk.Cout <= 32 and pk.Cout % 4 == 0 and a <= L.ACT_LEAKY01 and not pk.tiny_columns()
+                            and os.environ.get('YOLACT_AMD_WINO_PROJ', '1') == '1'):
+                        self.wino_proj = (prev_conv_op, len(self.ops) - 1)
                 else:
                     nt = self.conv('proto.%d' % i, t, pk, act=a)
+                    prev_conv_op = len(self.ops) - 1
                 self.free(t)
                 if held is not None:
                     self.free(held)
                     held = None
                 t = nt
             elif isinstance(m, M.InterpolateModule):
+                prev_conv_op = None
                 s = int(m.scale_factor)
                 has_relu = (i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU))
                 y = self._new(t.B, t.H * s, t.W * s, t.C, slot=t.slot)   # convex interpolation: the input's bound holds
@@ -887,6 +898,8 @@ class Plan:
         sb = C.c_void_p(self.stream_b.cuda_stream) if two else sa
         proto = torch.empty(self.proto_shape, dtype=torch.float32, device=self.device)
         self.proto_patch.seg[0].ptr = proto.data_ptr()
+        if self.proto_patch_wino is not None:
+            self.proto_patch_wino.proj_y = proto.data_ptr()
         if self.h2:                  # magnitude bounds are re-derived by every run (on the caller's stream, ahead of every op)
             self.amax[:self._nslots * AMAX_SLOT_FLOATS].zero_()
         # only a module with the reference's timer API (utils/timer.py: start / stop / env) is driven
@@ -1052,6 +1065,33 @@ class Plan:
                         out.append(tid + 256 * S)
         return out
 
+    @staticmethod
+    def ws_candidates(d):
+        """(tile + 256 * split_k) candidates of the weight-stationary streaming kernel (csrc/wstat.hip) for a descriptor it takes
+        (_pipe_ok, no residual, Cout <= 64): every block shape of the column width that covers Cout, with the K ranges that make a
+        block's filters fit its 64 KB of LDS — the fewest ranges, and a few more where that leaves the grid short of the chip."""
+        if d.res_mode != L.RES_NONE or d.Cout > 64:
+            return []
+        M, nk = d.B * d.Ho * d.Wo, d.Kpad // 32
+        out = []
+        for t, name in sorted(L.WS_TILES.items()):
+            bm, bn = (int(v) for v in name[2:].split('w')[0].split('x'))
+            if (bn == 32) != (d.Cout <= 32):
+                continue
+            cap = (64 * 1024) // (bn * 128)                # chunks of filters (bn columns x 32 k x 2 planes x 2 bytes) in 64 KB
+            blocks, n = -(-M // bm), 0
+            for S in (1, 2, 3, 4, 5, 6, 8, 9, 12, 16):
+                per = -(-nk // S)
+                if per > cap or (S > 1 and per * (S - 1) >= nk):
+                    continue
+                if n and blocks * S > 1200:                # beyond the fewest ranges: only while the grid is short of ~4 blocks per CU
+                    break
+                out.append((t | L.TILE_H2 | L.TILE_DCNP) + 256 * (S if S > 1 else 0))
+                n += 1
+                if n == 3:
+                    break
+        return out
+
     def _tune_direct(self, e0, e1, s, reps, disk, measure):
         cache = {}
         for opi, (fn, dptr, name, where) in enumerate(self.ops):
@@ -1096,7 +1136,7 @@ class Plan:
                 if is_dcn and h2_:           # the pipelined gather-GEMM of csrc/dcn.hip (fp16x2 plans)
                     cands = cands + self.dcnp_candidates(d, dcn=True)
                 if not is_dcn and h2_ and self.pipe and self._pipe_ok(d):   # the same pipelined kernel as an ordinary convolution
-                    cands = cands + self.dcnp_candidates(d)
+                    cands = cands + self.dcnp_candidates(d) + self.ws_candidates(d)     # (+ the streaming kernel for narrow outputs)
                 if not is_dcn and self._splitk_ok(d) and self.splitk:
                     # split-K candidates: big tiles whose grid alone cannot fill the chip, K cut 2 / 4 ways
                     x3 = spflag
@@ -1210,6 +1250,16 @@ class Plan:
                     wd.x_up, wd.up_relu = lo_ptr, relu
                     bfn, bargs, bname, bwhere = self.ops[bidx]
                     self.ops[bidx] = ('nop', None, bname + '[fused into ' + name + ']', bwhere)
+                if self.wino_proj is not None and self.wino_proj[0] == idx and best_m == 4 and wd.Cout == 256 and wd.nseg == 0:
+                    pidx = self.wino_proj[1]
+                    pfn, pdptr, pname, pwhere = self.ops[pidx]
+                    if pfn is lib.ymi_conv2d_nhwc_f32 and pwhere == where:
+                        pd = pdptr.contents          # the 1x1's own descriptor: filters, epilogue, output, bound slot
+                        wd.proj_w_h2, wd.proj_scale_h2, wd.proj_bias = pd.w_h2, pd.scale_h2, pd.bias
+                        wd.proj_y, wd.proj_y_amax = pd.seg[0].ptr, pd.y_amax
+                        wd.proj_cout, wd.proj_ldy, wd.proj_act = pd.Cout, pd.seg[0].row_stride, pd.seg[0].act
+                        self.ops[pidx] = ('nop', None, pname + '[fused into ' + name + ']', pwhere)
+                        self.proto_patch_wino = wd
 
     def conv_flops(self):
         return sum(self.lib.ymi_conv_flops(C.byref(d)) for _, d in self.conv_meta)
