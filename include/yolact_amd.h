@@ -426,6 +426,28 @@ typedef struct ymi_stem_desc {
 } ymi_stem_desc;
 int ymi_stem_pool_f32(const ymi_stem_desc *d, void *stream);
 
+/* -- two chained 1x1 convolutions of the first ResNet stage in one streaming launch (csrc/chain.hip) -------------------------
+ *     y = act_a(scale_a * (W_a x) + bias_a + res)      conv3 + bn3 + shortcut + ReLU of Bottleneck b   (backbone.py:49-55)
+ *     z = act_b(scale_b * (W_b y) + bias_b)            conv1 + bn1 + ReLU of Bottleneck b + 1          (backbone.py:41-43)
+ * x [M,ldx] (k_a = 64 channels), res [M,res_ld] or NULL, y [M,ldy] (n_a = 256), z [M,ldz] (n_b = 64) or NULL (then only y is
+ * computed): NHWC rows, M = B*H*W.  Filters as the fp16x2 planes of the two layers (ymi_conv_desc.w_h2 / scale_h2: planes
+ * [2][cout_pad][K]); x_amax / y_amax / z_amax as in ymi_conv_desc (x_amax required).  y is written once and never read back:
+ * the second GEMM takes it from LDS. */
+typedef struct ymi_chain_desc {
+  const float *x, *res;
+  float *y, *z;
+  const void *w_a_h2, *w_b_h2;
+  const float *scale_a_h2, *bias_a, *scale_b_h2, *bias_b;   /* biases may be NULL */
+  const float *x_amax;
+  float *y_amax, *z_amax;                                    /* may be NULL */
+  int64_t M;
+  int32_t ldx, res_ld, ldy, ldz;
+  int32_t k_a, n_a, n_b;                                     /* 64, 256, 64: the only instantiated shape */
+  int32_t cout_pad_a, cout_pad_b;                            /* rows per filter plane (engine.Packed.CoutPad) */
+  int32_t act_a, act_b, _pad0;                               /* YMI_ACT_NONE / RELU / LEAKY01 */
+} ymi_chain_desc;
+int ymi_pointwise_chain_f32(const ymi_chain_desc *d, void *stream);
+
 /* -- profiling hooks -------------------------------------------------------------------- */
 /* When enabled, every conv launch is bracketed by hipEvents on its stream; ymi_prof_read returns
  * (after synchronising) per-launch milliseconds, flops and tile ids. Used by bench.py roofline. */

@@ -395,6 +395,39 @@ def test_winograd_fused_projection_rejects_what_it_cannot_run():
         run_wino(x, torch.randn(256, 32, 3, 3, generator=g), None, None, m=4, proj=(torch.randn(48, 256, 1, 1, generator=g), None, L.ACT_NONE))
 
 
+@pytest.mark.parametrize('M', [16, 1000, 4097, 16 * 256 * 3 + 5])
+@pytest.mark.parametrize('mode', ['chain', 'chain_nores_leaky', 'tail_only'])
+def test_pointwise_chain_matches_fp64(M, mode):
+    """ymi_pointwise_chain_f32 (csrc/chain.hip): y = act(W_a x + b_a + res) [64 -> 256], z = act(W_b y + b_b) [256 -> 64] in one
+    streaming launch, y taken from LDS for the second GEMM — against fp64 on the CPU: fewer tiles than blocks, ragged last tile,
+    several tiles per block; with / without the residual and the second layer; the magnitude bounds of y and z."""
+    from gpu_utils import run_chain
+    g = _g(900 + M)
+    x = torch.randn(M, 64, generator=g) * 3
+    wa = torch.randn(256, 64, generator=g) / 8
+    ba = torch.randn(256, generator=g) * 0.3
+    res = torch.randn(M, 256, generator=g) * 2 if mode != 'chain_nores_leaky' else None
+    wb = torch.randn(64, 256, generator=g) / 16 if mode != 'tail_only' else None
+    bb = torch.randn(64, generator=g) * 0.1 if wb is not None else None
+    act = L.ACT_LEAKY01 if mode == 'chain_nores_leaky' else L.ACT_RELU
+
+    def a_(t):
+        return torch.relu(t) if act == L.ACT_RELU else F.leaky_relu(t, 0.1)
+    yr = x.double() @ wa.double().t() + ba.double()
+    yr = a_(yr + res.double() if res is not None else yr)
+    y, z = run_chain(x, wa, ba, res, wb, bb, act, act)
+    assert ((y.double() - yr).abs().max() / yr.abs().max()).item() < 5e-7
+    assert abs(run_chain.last_amax[0] - yr.abs().max().item()) <= 1e-6 * yr.abs().max().item()
+    if wb is not None:
+        zr = a_(yr @ wb.double().t() + bb.double())
+        assert ((z.double() - zr).abs().max() / zr.abs().max()).item() < 1e-6
+        assert abs(run_chain.last_amax[1] - zr.abs().max().item()) <= 2e-6 * zr.abs().max().item()
+        y2, z2 = run_chain(x, wa, ba, res, wb, bb, act, act)
+        assert torch.equal(y, y2) and torch.equal(z, z2)
+    else:
+        assert z is None
+
+
 WS_ALL = [t | L.TILE_H2 | L.TILE_DCNP for t in sorted(L.WS_TILES)]                     # every block shape of csrc/wstat.hip
 
 

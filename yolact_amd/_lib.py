@@ -112,6 +112,16 @@ class JpegInfo(C.Structure):
                 ('coef_count', C.c_int64), ('plane_bytes', C.c_int64)]
 
 
+class ChainDesc(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('res', C.c_void_p), ('y', C.c_void_p), ('z', C.c_void_p),
+                ('w_a_h2', C.c_void_p), ('w_b_h2', C.c_void_p),
+                ('scale_a_h2', C.c_void_p), ('bias_a', C.c_void_p), ('scale_b_h2', C.c_void_p), ('bias_b', C.c_void_p),
+                ('x_amax', C.c_void_p), ('y_amax', C.c_void_p), ('z_amax', C.c_void_p),
+                ('M', C.c_int64), ('ldx', C.c_int32), ('res_ld', C.c_int32), ('ldy', C.c_int32), ('ldz', C.c_int32),
+                ('k_a', C.c_int32), ('n_a', C.c_int32), ('n_b', C.c_int32), ('cout_pad_a', C.c_int32), ('cout_pad_b', C.c_int32),
+                ('act_a', C.c_int32), ('act_b', C.c_int32), ('_pad0', C.c_int32)]
+
+
 class StemDesc(C.Structure):
     _fields_ = [('x', C.c_void_p), ('y', C.c_void_p), ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('cout_pad', C.c_int32),
                 ('w_h2', C.c_void_p), ('scale_h2', C.c_void_p), ('bias', C.c_void_p), ('y_amax', C.c_void_p),
@@ -151,6 +161,7 @@ SYMBOLS = [
     ('ymi_mask_upsample_bits', C.c_int, [_P, _I, _I, _I, _I, _I, _F, _P, _P]),
     ('ymi_mask_iou_bits', C.c_int, [_P, _P, _I, _I, C.c_long, _I, _P, _P]),
     ('ymi_stem_pool_f32', C.c_int, [_P, _P]),
+    ('ymi_pointwise_chain_f32', C.c_int, [_P, _P]),
     ('ymi_mask_rle_f32', C.c_int, [_P, _I, _I, _I, _P, _P, _I, _P]),
     ('ymi_mask_rle_upsampled_f32', C.c_int, [_P, _I, _I, _I, _I, _I, _F, _P, _P, _I, _P]),
     ('ymi_rle_to_string', C.c_int, [_P, _P, _I, _I, _P, _P, _I, _P]),

@@ -103,3 +103,27 @@ __device__ __forceinline__ float ymi_amax_read(const float *slot) {
 __device__ __forceinline__ float ymi_absmax4(const f32x4 v) {
   return fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
 }
+
+// ---- gfx950's new MFMAs through wrappers that keep the destination off the source operands -------------------------------------
+// hipcc 7.2 (ROCm 7.2.0) gives v_mfma_f32_16x16x32_f16 / v_mfma_f32_32x32x16_f16 no early-clobber and no tie on vDst: whenever a
+// source operand dies at the instruction the allocator may place the result on (part of) its registers —
+//     v_mfma_f32_16x16x32_f16 v[220:223], v[90:93], v[218:221], v[222:225]          (first version of csrc/chain.hip)
+// and on the MI355X that instruction returns wrong values in lanes 48..63 of the overlapping registers, not on every execution
+// (profiles/r04_mfma_overlap.txt: 250 - 340 wrong values of 786 752, different ones per run; none once the overlap is gone).
+// The wrappers pass the result and all three sources through an empty asm statement after the instruction: they are live at the
+// same point, hence in disjoint registers.  A chain `acc = ymi_mfma16(a, b, acc)` therefore alternates between two register
+// groups; dependent MFMAs with different vDst cost wait states, so callers interleave independent accumulators.
+// tools/check_mfma_overlap.py disassembles the built objects and fails the build on any MFMA whose destination overlaps a source
+// (`make lint`, run by __graft_entry__.build()): the older kernels (conv_igemm.hip, dcn.hip: long in-place chains) are clean without
+// the wrappers and stay as they are.
+typedef _Float16 ymi_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 ymi_mfma16(const ymi_f16x8 a, const ymi_f16x8 b, const f32x4 c) {
+  f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  asm volatile("" : "+v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ f32x16 ymi_mfma32(const ymi_f16x8 a, const ymi_f16x8 b, const f32x16 c) {
+  f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  asm volatile("" : "+v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}

@@ -157,9 +157,9 @@ __global__ __launch_bounds__(NTHR) void stem_pool_k(const StemParams p) {
       const f16x8 al = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
       const f16x8 bh = *reinterpret_cast<const f16x8 *>(wrow + (16 * ks + 8 * hh) * 2);
       const f16x8 bl = *reinterpret_cast<const f16x8 *>(wrow + WPLANE + (16 * ks + 8 * hh) * 2);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+      acc = ymi_mfma32(ah, bl, acc);
+      acc = ymi_mfma32(al, bh, acc);
+      acc = ymi_mfma32(ah, bh, acc);
     }
     // ---- BN + ReLU -> stem tile (fp32); stem pixels outside the stem image = -inf (the max-pool's padding) ----------------
     const int sy0 = 2 * (ty * PH) - 1, sx0 = 2 * (tx * PW) - 1;

@@ -541,7 +541,9 @@ __global__ __launch_bounds__(256) void wino43_out_proj_k(const float *__restrict
       }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    f32x4 acc[2];
+    acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const f16x8 xh = *reinterpret_cast<const f16x8 *>(ytile + lr * PJ_ROW + c * 64 + g * 16);
@@ -550,9 +552,9 @@ __global__ __launch_bounds__(256) void wino43_out_proj_k(const float *__restrict
       for (int j = 0; j < 2; ++j) {
         const f16x8 wh = *reinterpret_cast<const f16x8 *>(lds + (j * 16 + lr) * PJ_ROW + c * 64 + g * 16);
         const f16x8 wl = *reinterpret_cast<const f16x8 *>(lds + PJ_WPLANE + (j * 16 + lr) * PJ_ROW + c * 64 + g * 16);
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc[j], 0, 0, 0);      // D^T[n][pixel] += W Y^T: h*l, l*h, h*h
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc[j], 0, 0, 0);
+        acc[j] = ymi_mfma16(wl, xh, acc[j]);      // D^T[n][pixel] += W Y^T: h*l, l*h, h*h
+        acc[j] = ymi_mfma16(wh, xl, acc[j]);
+        acc[j] = ymi_mfma16(wh, xh, acc[j]);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -189,7 +189,7 @@ void ws_h2_k(const WsParams p) {
         for (int j = 0; j < NT; ++j) {
           const f16x8 fx = pr == 1 ? fa[i].l : fa[i].h;
           const f16x8 fw = pr == 0 ? fb[j].l : fb[j].h;
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw, fx, acc[i][j], 0, 0, 0);      // D^T[cout][pixel] += W X^T
+          acc[i][j] = ymi_mfma16(fw, fx, acc[i][j]);      // D^T[cout][pixel] += W X^T
         }
   };
   const int nk_pad = ((my_nk + D - 1) / D) * D;
