@@ -126,7 +126,8 @@ def roofline(net, x, reps=3):
     # record kinds: 0/1/2 = one direct conv launch (loader id), 7 = a direct 1x1 launch on the pointwise loader (kernel
     # template LOADER 3); 3 / 4 = a whole Winograd F(2x2) / F(4x4) layer (input transform + 16- / 36-group GEMM + output
     # transform, ALGORITHMIC conv FLOPs); 5 / 6 = the Winograd GEMM launch alone (the FLOPs it executes).
-    # 11 = the weight-stationary streaming kernel (csrc/wstat.hip); 12 = a 1x1 layer fused into the previous layer's output transform.
+    # 11 = the weight-stationary streaming kernel (csrc/wstat.hip); 12 = a 1x1 layer fused into the previous layer's launch (its FLOPs, no
+    # duration of its own); 13 = ymi_pointwise_chain_f32 (csrc/chain.hip: conv3 + shortcut + ReLU -> the next block's conv1).
     # 9 = the pipelined DCNv2 gather-GEMM (csrc/dcn.hip: pipe_h2_k<..., PLAIN = false>), 10 = the same kernel as an ordinary 3x3 / 1x1
     # convolution (PLAIN = true).
     # 8 = the fused ResNet stem launch (layout change + 7x7 conv + BN + ReLU + max-pool; the conv's algorithmic FLOPs).
@@ -146,7 +147,7 @@ def roofline(net, x, reps=3):
             li += 1               # algorithmic FLOPs count for the step, its time is part of that layer's record
             la = layers.setdefault(names[li % nl], [0.0, fl.value, ''])
             la[0] += ms.value / reps
-            la[2] = 'fused into the output transform of the layer above (wino43_out_proj_k)'
+            la[2] = 'computed inside the launch of the layer above (wino43_out_proj_k / chain_h2_k)'
             tot_ms += ms.value; tot_fl += fl.value
             continue
         # algorithmic bytes of this record and its lower-bound time (sum over layers of max(F/peak, bytes/BW))
@@ -169,6 +170,9 @@ def roofline(net, x, reps=3):
             if kind.value in (2, 9):                 # DCNv2: + the 27-channel offset / mask-logit tensor the gather reads
                 dd_ = descs[(li + 1) % nl]
                 nbytes += 4.0 * dd_.B * dd_.Ho * dd_.Wo * 27
+            if kind.value == 13:                     # the chain launch also writes the next block's conv1 output (64 channels)
+                dd_ = descs[(li + 1) % nl]
+                nbytes += 4.0 * dd_.B * dd_.Ho * dd_.Wo * 64
         if kind.value not in (3, 4):
             pk_ = (X3_PEAK_TFLOPS if tname.endswith('x3') else H2_PEAK_TFLOPS if (tname.endswith('h2') or tname.startswith('dcnp') or tname.startswith('ws'))
                    else FP32_MFMA_PEAK_TFLOPS)
@@ -183,6 +187,7 @@ def roofline(net, x, reps=3):
                 else 'pipe_h2_k<%s,DCNv2 gather>' % tname if kind.value == 9 \
                 else 'pipe_h2_k<%s,convolution>' % tname if kind.value == 10 \
                 else 'ws_h2_k<%s,convolution>' % tname if kind.value == 11 \
+                else 'chain_h2_k<conv3 + shortcut + ReLU -> next conv1, one launch>' if kind.value == 13 \
                 else 'conv_igemm_f32<%s,loader%d>' % (tname, 3 if kind.value == 7 else kind.value)
             la = layers.setdefault(names[li % nl], [0.0, fl.value, lkey])
             la[0] += ms.value / reps
@@ -194,6 +199,7 @@ def roofline(net, x, reps=3):
                 ('pipe_h2_k<%s,DCNv2 gather>' % tname) if kind.value == 9 else \
                 ('pipe_h2_k<%s,convolution>' % tname) if kind.value == 10 else \
                 ('ws_h2_k<%s,convolution>' % tname) if kind.value == 11 else \
+                'chain_h2_k<pointwise chain>' if kind.value == 13 else \
                 'conv_igemm_f32<%s,loader%d>' % (tname, 3 if kind.value == 7 else kind.value)
             a = by_kernel.setdefault(key, [0.0, 0.0, 0, 0.0, 0.0, 0.0])
             a[0] += ms.value; a[1] += fl.value; a[2] += 1; a[3] += nbytes

@@ -257,3 +257,31 @@ def test_plan_is_deterministic_across_processes():
         outs.append([l for l in p.stdout.splitlines() if l.startswith('DIGEST')][-1].split())
     assert outs[0][1] == outs[1][1], 'two processes produced different head tensors'
     assert outs[0][2] == '0' and outs[1][2] == '0', 'BASELINE configs[1] must be fully covered by the shipped tune table'
+
+
+def test_timed_plan_chains_the_first_stage_pointwise_layers():
+    """The batch-8 plan of configs[1] runs conv3 (+ shortcut, ReLU) of layer0.0 / layer0.1 and conv1 of the next block as ONE
+    ymi_pointwise_chain_f32 launch each (the shipped table says it is faster); with YOLACT_AMD_CHAIN=0 the same layers are two
+    launches, and the network's outputs agree to fp32 rounding (the chain splits the 256-channel tensor with per-slice scales
+    instead of the tensor-wide one: a different, not a larger, rounding)."""
+    tag, config, B, size, seed, gain, img_seed = CASES[0]
+    x = synth_images(B, size, size, seed=img_seed).to(DEV)
+    net, sd = _build(config, seed, gain)
+    plan = net.plan_for(x)
+    names = [op[2] for op in plan.ops if op[0] is plan.lib.ymi_pointwise_chain_f32]
+    assert names == ['layer0.0.conv3+layer0.1.conv1', 'layer0.1.conv3+layer0.2.conv1'], (names, getattr(plan, 'chain_table', None))
+    with torch.no_grad():
+        a = {k: v.clone() for k, v in net.forward_raw(x).items() if k in ('loc', 'conf_logits', 'mask', 'proto')}
+    os.environ['YOLACT_AMD_CHAIN'] = '0'
+    try:
+        net2, _ = _build(config, seed, gain)
+        plan2 = net2.plan_for(x)
+        assert not any(op[0] is plan2.lib.ymi_pointwise_chain_f32 for op in plan2.ops)
+        with torch.no_grad():
+            b = net2.forward_raw(x)
+    finally:
+        del os.environ['YOLACT_AMD_CHAIN']
+    for k in a:
+        err = ((a[k] - b[k]).abs().max() / b[k].abs().max()).item()
+        print('chain vs two launches, %s: %.2e of max' % (k, err))
+        assert err < 2e-5, k
