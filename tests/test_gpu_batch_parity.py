@@ -269,7 +269,8 @@ def test_timed_plan_chains_the_first_stage_pointwise_layers():
     net, sd = _build(config, seed, gain)
     plan = net.plan_for(x)
     names = [op[2] for op in plan.ops if op[0] is plan.lib.ymi_pointwise_chain_f32]
-    assert names == ['layer0.0.conv3+layer0.1.conv1', 'layer0.1.conv3+layer0.2.conv1'], (names, getattr(plan, 'chain_table', None))
+    assert names[:2] == ['layer0.0.conv3+layer0.1.conv1', 'layer0.1.conv3+layer0.2.conv1'], (names, getattr(plan, 'chain_table', None))
+    assert names[2:] in ([], ['layer0.2.conv3'])           # (the last block's conv3 alone on the same kernel, where the table prefers it)
     with torch.no_grad():
         a = {k: v.clone() for k, v in net.forward_raw(x).items() if k in ('loc', 'conf_logits', 'mask', 'proto')}
     os.environ['YOLACT_AMD_CHAIN'] = '0'

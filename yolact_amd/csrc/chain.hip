@@ -17,11 +17,13 @@
 //   P4  GEMM 2: wave (q, i) owns z channels 16 q .. + 15 of half i; the K = 256 sum is taken slice by slice (32 channels = one
 //       producing wave), each partial sum divided by its slice's scale (exact): no block- or tensor-wide bound of y is needed
 //   P5  epilogue 2: scale / bias / ReLU / float4 store of z
-// Two LDS-only barriers per 32 pixels; the global loads of iteration i + 1 are in flight during iteration i; all memory
+// ONE LDS-only barrier per 32 pixels (operand tiles double-buffered; P4 / P5 of tile k - 1 run next to P2 / P3 of tile k); the
+// global loads of iteration i + 1 are in flight during iteration i; all memory
 // operations are unconditional buffer operations (out-of-range offsets for masked rows), so the compiler's vmcnt is exact.
 // Magnitude bounds of y and z are reported like every other launch (ymi_amax_*).  z == nullptr: GEMM 2 is skipped (conv3 alone:
 // the last block of the stage, whose consumer is not a 64-channel 1x1).
 #include "common.h"
+#include <type_traits>
 #include "../../include/yolact_amd.h"
 
 int ymi_internal_prof_begin(double flops, int tile, int kind, hipStream_t s);
@@ -37,7 +39,10 @@ constexpr int K1 = 64, N1 = 256, N2 = 64, PX = 32, NW = 8;
 constexpr int RS1 = 2 * K1 + 16;          // bytes per LDS row of a K = 64 plane (128 + 16: the 16 lanes of a read phase hit 16 bank groups)
 constexpr int RS2 = 2 * N1 + 16;          // ... of a K = 256 plane
 constexpr int A1_PLANE = PX * RS1, A2_PLANE = PX * RS2;
-constexpr int OFF_A1 = 0, OFF_A2 = OFF_A1 + 2 * A1_PLANE, OFF_SC = OFF_A2 + 2 * A2_PLANE, OFF_EP = OFF_SC + 2 * NW * 4,
+// LDS: the two operand tiles and the slice scales are DOUBLE-buffered (iteration k works in buffer k & 1), which is what lets one
+// barrier per iteration do (see the kernel): 2 x 9.2 KB + 2 x 33.8 KB + scales + conv3's per-lane epilogue constants
+constexpr int A1_BUF = 2 * A1_PLANE, A2_BUF = 2 * A2_PLANE;
+constexpr int OFF_A1 = 0, OFF_A2 = OFF_A1 + 2 * A1_BUF, OFF_SC = OFF_A2 + 2 * A2_BUF, OFF_EP = OFF_SC + 2 * (2 * NW * 4),
               CH_LDS = OFF_EP + NW * 2 * 4 * 32;   // OFF_EP: conv3's per-lane epilogue constants (scale, bias) x (wave, j, g)
 
 struct ChainParams {
@@ -129,13 +134,25 @@ __global__ __launch_bounds__(64 * NW) void chain_h2_k(const ChainParams p) {
   // LDS-only barrier: __syncthreads() would also wait for the global loads of the NEXT iteration (vmcnt(0)), i.e. expose one memory
   // round trip per tile
 #define CHAIN_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-  // One iteration = 32 pixels.  `rv`: this tile's residual vectors (requested an iteration ago), `rn`: the registers the next
-  // tile's are requested into.  The loop below runs two iterations per trip with the two register sets swapped: a copy rn -> rv
-  // at the end of an iteration would wait for every outstanding memory operation, the stores of y just issued included (seen in
-  // the ISA as s_waitcnt vmcnt(0) on the back edge).  An iteration past the last tile loads nothing and stores nothing.
+  // One iteration = 32 pixels, ONE barrier, software-pipelined over two tiles: after the barrier of iteration k the waves run
+  // GEMM 2 + epilogue 2 of tile k - 1 (operands in buffer (k - 1) & 1, published by that barrier) and GEMM 1 + epilogue 1 of tile k
+  // (t tile in buffer k & 1, written before the barrier) — two independent instruction streams for the scheduler, and half the
+  // barriers of the first version.  Buffer k & 1 is next written in iteration k + 2, after every wave has passed barrier k + 1,
+  // i.e. finished reading it.
+  // `rv`: this tile's residual vectors (requested an iteration ago), `rn`: the registers the next tile's are requested into.  The
+  // loop runs two iterations per trip with the two register sets (and the two LDS buffers) swapped: a copy rn -> rv at the end of
+  // an iteration would wait for every outstanding memory operation, the stores of y just issued included (seen in the ISA as
+  // s_waitcnt vmcnt(0) on the back edge).  Iterations past the last tile load nothing and store nothing but the last tile's z.
   float am_y = 0.f, am_z = 0.f;
   f32x4 xv;
-  auto iteration = [&](const int tile, f32x4 (&rv)[2][2], f32x4 (&rn)[2][2]) {
+  const int grid = (int)gridDim.x;
+  auto iteration = [&](const int tile, auto buf_c, f32x4 (&rv)[2][2], f32x4 (&rn)[2][2]) {
+    constexpr int BUF = decltype(buf_c)::value;
+    char *const a1 = lds + OFF_A1 + BUF * A1_BUF;
+    char *const a2w = lds + OFF_A2 + BUF * A2_BUF;
+    const char *const a2r = lds + OFF_A2 + (BUF ^ 1) * A2_BUF;
+    float *const scw = reinterpret_cast<float *>(lds + OFF_SC) + BUF * (2 * NW);
+    const float *const scr = reinterpret_cast<const float *>(lds + OFF_SC) + (BUF ^ 1) * (2 * NW);
     // P1: t tile -> planes
     {
       const f32x4 v = xv * sA;
@@ -146,14 +163,45 @@ __global__ __launch_bounds__(64 * NW) void chain_h2_k(const ChainParams p) {
         h4[e] = h;
         l4[e] = (_Float16)(v[e] - (float)h);
       }
-      char *dst = lds + OFF_A1 + xp * RS1 + xc * 8;
+      char *dst = a1 + xp * RS1 + xc * 8;
       *reinterpret_cast<f16x4 *>(dst) = h4;
       *reinterpret_cast<f16x4 *>(dst + A1_PLANE) = l4;
     }
-    xv = load_x(tile + gridDim.x);                      // next iteration's operands: in flight until its P1 / P3
-    load_res(tile + gridDim.x, rn);
+    xv = load_x(tile + grid);                           // next iteration's operands: in flight until its P1 / P3
+    load_res(tile + grid, rn);
     CHAIN_BARRIER();
-    // P2: GEMM 1 — both 16-pixel halves x this wave's two 16-channel tiles
+    if (two) {
+      // P4 (tile k - 1): GEMM 2 for pixels 16 i2 + lr, z channels 16 q2 ..: the K = 256 sum one 32-channel slice (one producing
+      // wave, one scale) at a time
+      f32x4 tot = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c0 = 0; c0 < 8; c0 += 2) {               // two slices at a time: two independent accumulators interleaved
+        f16x8 xh[2], xl[2];
+        f32x4 a2[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          xh[u] = *reinterpret_cast<const f16x8 *>(a2r + (16 * i2 + lr) * RS2 + (c0 + u) * 64 + g * 16);
+          xl[u] = *reinterpret_cast<const f16x8 *>(a2r + A2_PLANE + (16 * i2 + lr) * RS2 + (c0 + u) * 64 + g * 16);
+          a2[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+            a2[u] = ymi_mfma16(pr == 0 ? w1l[c0 + u] : w1h[c0 + u], pr == 1 ? xl[u] : xh[u], a2[u]);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) tot += a2[u] * scr[i2 * NW + c0 + u];
+      }
+      // P5: epilogue 2
+      const int tp = tile - grid, m = tp * PX + 16 * i2 + lr;
+      const bool ok = tp >= 0 && m < p.M;
+      f32x4 v = tot * sc1 + bi1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], slope_b * v[e]);
+      am_z = fmaxf(am_z, ok ? ymi_absmax4(v) : 0.f);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), zrs, ok ? (unsigned)(m * p.ldz + 16 * q2 + 4 * g) * 4u : OOB, 0, 0);
+    }
+    // P2 (tile k): GEMM 1 — both 16-pixel halves x this wave's two 16-channel tiles
     f32x4 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -164,8 +212,8 @@ __global__ __launch_bounds__(64 * NW) void chain_h2_k(const ChainParams p) {
       f16x8 xh[2], xl[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        xh[i] = *reinterpret_cast<const f16x8 *>(lds + OFF_A1 + (16 * i + lr) * RS1 + c * 64 + g * 16);
-        xl[i] = *reinterpret_cast<const f16x8 *>(lds + OFF_A1 + A1_PLANE + (16 * i + lr) * RS1 + c * 64 + g * 16);
+        xh[i] = *reinterpret_cast<const f16x8 *>(a1 + (16 * i + lr) * RS1 + c * 64 + g * 16);
+        xl[i] = *reinterpret_cast<const f16x8 *>(a1 + A1_PLANE + (16 * i + lr) * RS1 + c * 64 + g * 16);
       }
 #pragma unroll
       for (int pr = 0; pr < 3; ++pr)                    // (product-major: consecutive MFMAs belong to different accumulators)
@@ -175,7 +223,7 @@ __global__ __launch_bounds__(64 * NW) void chain_h2_k(const ChainParams p) {
           for (int j = 0; j < 2; ++j)
             acc[i][j] = ymi_mfma16(pr == 0 ? w3l[j][c] : w3h[j][c], pr == 1 ? xl[i] : xh[i], acc[i][j]);
     }
-    // P3: epilogue 1 + this wave's 16 x 32 slices of y -> planes (one power-of-two scale per slice)
+    // P3 (tile k): epilogue 1 + this wave's 16 x 32 slices of y -> planes (one power-of-two scale per slice)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int m = tile * PX + 16 * i + lr;
@@ -209,53 +257,21 @@ __global__ __launch_bounds__(64 * NW) void chain_h2_k(const ChainParams p) {
             h4[e] = h;
             l4[e] = (_Float16)(v[e] - (float)h);
           }
-          char *dst = lds + OFF_A2 + (16 * i + lr) * RS2 + (32 * wave + 16 * j + 4 * g) * 2;
+          char *dst = a2w + (16 * i + lr) * RS2 + (32 * wave + 16 * j + 4 * g) * 2;
           *reinterpret_cast<f16x4 *>(dst) = h4;
           *reinterpret_cast<f16x4 *>(dst + A2_PLANE) = l4;
         }
-        if (lane == 0) reinterpret_cast<float *>(lds + OFF_SC)[i * NW + wave] = invT;
+        if (lane == 0) scw[i * NW + wave] = invT;
       }
-    }
-    CHAIN_BARRIER();
-    if (two) {
-      // P4: GEMM 2 for pixels 16 i2 + lr, z channels 16 q2 ..: the K = 256 sum one 32-channel slice (one producing wave, one
-      // scale) at a time
-      f32x4 tot = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int c0 = 0; c0 < 8; c0 += 2) {               // two slices at a time: two independent accumulators interleaved
-        f16x8 xh[2], xl[2];
-        f32x4 a2[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          xh[u] = *reinterpret_cast<const f16x8 *>(lds + OFF_A2 + (16 * i2 + lr) * RS2 + (c0 + u) * 64 + g * 16);
-          xl[u] = *reinterpret_cast<const f16x8 *>(lds + OFF_A2 + A2_PLANE + (16 * i2 + lr) * RS2 + (c0 + u) * 64 + g * 16);
-          a2[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int pr = 0; pr < 3; ++pr)
-#pragma unroll
-          for (int u = 0; u < 2; ++u)
-            a2[u] = ymi_mfma16(pr == 0 ? w1l[c0 + u] : w1h[c0 + u], pr == 1 ? xl[u] : xh[u], a2[u]);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) tot += a2[u] * reinterpret_cast<const float *>(lds + OFF_SC)[i2 * NW + c0 + u];
-      }
-      // P5: epilogue 2
-      const int m = tile * PX + 16 * i2 + lr;
-      const bool ok = m < p.M;
-      f32x4 v = tot * sc1 + bi1;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], slope_b * v[e]);
-      am_z = fmaxf(am_z, ok ? ymi_absmax4(v) : 0.f);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), zrs, ok ? (unsigned)(m * p.ldz + 16 * q2 + 4 * g) * 4u : OOB, 0, 0);
     }
   };
   int tile = blockIdx.x;
   f32x4 ra[2][2], rb[2][2];
   xv = load_x(tile);
   load_res(tile, ra);
-  for (; tile < ntiles; tile += 2 * gridDim.x) {
-    iteration(tile, ra, rb);
-    iteration(tile + gridDim.x, rb, ra);
+  for (; tile < ntiles + (two ? grid : 0); tile += 2 * grid) {      // (+ one iteration for the last tile's second layer)
+    iteration(tile, std::integral_constant<int, 0>{}, ra, rb);
+    iteration(tile + grid, std::integral_constant<int, 1>{}, rb, ra);
   }
 #undef CHAIN_BARRIER
   if (p.y_amax) ymi_amax_finish(apre_y, am_y);

@@ -1020,64 +1020,74 @@ class Plan:
     def _fuse_pointwise_chains(self, e0, e1, s, reps, disk, measure):
         """conv3 (1x1, 64 -> 256, + shortcut, ReLU) of a first-stage bottleneck directly followed by conv1 (1x1, 256 -> 64, ReLU) of
         the next one -> ONE ymi_pointwise_chain_f32 launch (csrc/chain.hip: the 256-channel tensor is written once and never read
-        back), where that is measured faster than the two launches.  The decision is a table entry like every other choice
-        ('chain(B, H, W)': [1 | 0, ms of the two launches, ms of the chain]); YOLACT_AMD_CHAIN=0 keeps the two launches."""
+        back); a conv3 of that shape WITHOUT such a successor (the last block of the stage) -> the same streaming kernel with its
+        second layer switched off.  Either only where measured faster than the launches it replaces: the decision is a table entry
+        like every other choice ('chain(B, H, W)' / 'chain1(B, H, W)': [1 | 0, ms of the plan's launches, ms of the chain launch]);
+        YOLACT_AMD_CHAIN=0 keeps the plan's launches."""
         self.chain_table = []
         if not self.h2 or os.environ.get('YOLACT_AMD_CHAIN', '1') != '1':
             return
         lib = self.lib
+
+        def timed(run):
+            run()
+            best = 1e30
+            for _ in range(2):
+                e0.record()
+                for _ in range(reps):
+                    run()
+                e1.record()
+                e1.synchronize()
+                best = min(best, e0.elapsed_time(e1) / reps)
+            return best
         i = 0
-        while i + 1 < len(self.ops):
-            (f3, p3, n3, w3), (f1, p1, n1, w1) = self.ops[i], self.ops[i + 1]
+        while i < len(self.ops):
+            f3, p3, n3, w3 = self.ops[i]
             i += 1
-            if f3 is not lib.ymi_conv2d_nhwc_f32 or f1 is not lib.ymi_conv2d_nhwc_f32 or w3 != w1:
+            if f3 is not lib.ymi_conv2d_nhwc_f32 or (i - 1) in self.wide_ops:
                 continue
-            if (i - 1) in self.wide_ops or i in self.wide_ops:
-                continue
-            d3, d1 = p3.contents, p1.contents
+            d3 = p3.contents
             M = d3.B * d3.Ho * d3.Wo
             if not ((d3.kh, d3.kw, d3.stride, d3.pad, d3.Cin, d3.Cout, d3.nseg) == (1, 1, 1, 0, 64, 256, 1)
-                    and (d1.kh, d1.kw, d1.stride, d1.pad, d1.Cin, d1.Cout, d1.nseg) == (1, 1, 1, 0, 256, 64, 1)
-                    and d3.res_mode == L.RES_ADD and not d3.res_after_act and d1.res_mode == L.RES_NONE
-                    and d1.x == d3.seg[0].ptr and d1.ldx == d3.seg[0].row_stride and d3.seg[0].n0 == 0 and d1.seg[0].n0 == 0
-                    and d3.seg[0].act <= L.ACT_LEAKY01 and d1.seg[0].act <= L.ACT_LEAKY01 and d3.w_h2 and d1.w_h2 and d3.x_amax
-                    and M * max(d3.seg[0].row_stride, d3.res_ld) < (1 << 29)):
+                    and d3.res_mode == L.RES_ADD and not d3.res_after_act and d3.seg[0].n0 == 0 and d3.seg[0].act <= L.ACT_LEAKY01
+                    and d3.w_h2 and d3.x_amax and M * max(d3.seg[0].row_stride, d3.res_ld) < (1 << 29)):
                 continue
+            pair = False
+            if i < len(self.ops) and self.ops[i][0] is lib.ymi_conv2d_nhwc_f32 and self.ops[i][3] == w3 and i not in self.wide_ops:
+                d1 = self.ops[i][1].contents
+                pair = ((d1.kh, d1.kw, d1.stride, d1.pad, d1.Cin, d1.Cout, d1.nseg) == (1, 1, 1, 0, 256, 64, 1)
+                        and d1.res_mode == L.RES_NONE and d1.x == d3.seg[0].ptr and d1.ldx == d3.seg[0].row_stride
+                        and d1.seg[0].n0 == 0 and d1.seg[0].act <= L.ACT_LEAKY01 and bool(d1.w_h2))
             cd = L.ChainDesc()
-            cd.x, cd.res, cd.y, cd.z = d3.x, d3.res, d3.seg[0].ptr, d1.seg[0].ptr
+            cd.x, cd.res, cd.y = d3.x, d3.res, d3.seg[0].ptr
             cd.w_a_h2, cd.scale_a_h2, cd.bias_a = d3.w_h2, d3.scale_h2, d3.bias
-            cd.w_b_h2, cd.scale_b_h2, cd.bias_b = d1.w_h2, d1.scale_h2, d1.bias
-            cd.x_amax, cd.y_amax, cd.z_amax = d3.x_amax, d3.y_amax, d1.y_amax
-            cd.M, cd.ldx, cd.res_ld, cd.ldy, cd.ldz = M, d3.ldx, d3.res_ld, d3.seg[0].row_stride, d1.seg[0].row_stride
+            cd.x_amax, cd.y_amax = d3.x_amax, d3.y_amax
+            cd.M, cd.ldx, cd.res_ld, cd.ldy = M, d3.ldx, d3.res_ld, d3.seg[0].row_stride
             cd.k_a, cd.n_a, cd.n_b, cd.cout_pad_a, cd.cout_pad_b = 64, 256, 64, 256, 128
-            cd.act_a, cd.act_b = d3.seg[0].act, d1.seg[0].act
+            cd.act_a = d3.seg[0].act
+            name = n3
+            if pair:
+                f1, p1, n1, w1 = self.ops[i]
+                cd.z, cd.ldz, cd.z_amax, cd.act_b = d1.seg[0].ptr, d1.seg[0].row_stride, d1.y_amax, d1.seg[0].act
+                cd.w_b_h2, cd.scale_b_h2, cd.bias_b = d1.w_h2, d1.scale_h2, d1.bias
+                name = n3 + '+' + n1
             cptr = C.pointer(cd)
-            key = 'chain' + str((d3.B, d3.Ho, d3.Wo)) + self.mode_key
+            key = ('chain' if pair else 'chain1') + str((d3.B, d3.Ho, d3.Wo)) + self.mode_key
             ent = disk.get(key)
             if ent is None:
                 self.tune_misses += 1
                 if not measure or lib.ymi_pointwise_chain_f32(cptr, s) != 0:
                     continue
-
-                def timed(run):
-                    run()
-                    best = 1e30
-                    for _ in range(2):
-                        e0.record()
-                        for _ in range(reps):
-                            run()
-                        e1.record()
-                        e1.synchronize()
-                        best = min(best, e0.elapsed_time(e1) / reps)
-                    return best
-                t_two = timed(lambda: (f3(p3, s), f1(p1, s)))
+                t_plan = timed((lambda: (f3(p3, s), f1(p1, s))) if pair else (lambda: f3(p3, s)))
                 t_one = timed(lambda: lib.ymi_pointwise_chain_f32(cptr, s))
-                ent = disk[key] = [1 if t_one < 0.97 * t_two else 0, round(t_two, 4), round(t_one, 4)]
-            self.chain_table.append((n3 + '+' + n1, ent[0], ent[1], ent[2]))
+                ent = disk[key] = [1 if t_one < 0.97 * t_plan else 0, round(t_plan, 4), round(t_one, 4)]
+            self.chain_table.append((name, ent[0], ent[1], ent[2]))
             if ent[0] and lib.ymi_pointwise_chain_f32(cptr, s) == 0:
                 self.keepalive.append(cd)
-                self.ops[i - 1] = (lib.ymi_pointwise_chain_f32, cptr, n3 + '+' + n1, w3)
-                self.ops[i] = ('nop', None, n1 + '[fused into ' + n3 + ']', w1)
+                self.ops[i - 1] = (lib.ymi_pointwise_chain_f32, cptr, name, w3)
+                if pair:
+                    self.ops[i] = ('nop', None, n1 + '[fused into ' + n3 + ']', w1)
+                    i += 1
 
     def _apply_choice(self, fn, dptr, where, val, s):
         """Install a table value (tile id + 256 * split_k) in a descriptor; returns the launch status of one run."""
