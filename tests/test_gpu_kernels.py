@@ -32,6 +32,12 @@ def test_conv_plain(shape, tile):
     if (tile & L.TILE_DCNP) and Cout % 4:
         pytest.skip('the pipelined kernel (csrc/dcn.hip) stores float4 rows: Cout % 4 == 0 (an explicit request is refused, see '
                     'test_dcn_pipelined_rejects_what_it_cannot_run)')
+    if tile & L.TILE_DCNP:
+        base = tile & 31
+        cols = 32 if L.DCNP_128x32_W4 <= base <= L.DCNP_64x32_W2 else int(L.WS_TILES[base].split('x')[1].split('w')[0]) if base in L.WS_TILES else None
+        if cols is not None and (Cout > cols or (base in L.WS_TILES and k * k * Cin // 32 * cols * 128 > 65536)):
+            pytest.skip('32- / 64-column tiles: narrower than this layer, or (weight-stationary) its filters exceed 64 KB unsplit — refused '
+                        'with YMI_EARG (test_weight_stationary_kernel_rejects_what_it_cannot_run)')
     g = _g(B * 1000 + Cin + Cout + k)
     x = torch.randn(B, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
