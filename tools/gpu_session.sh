@@ -103,6 +103,11 @@ PY
     pipeabl) # diagnostics build of csrc/dcn.hip, then the ablation of the pipelined kernel as an ordinary convolution on representative layers
       (cd yolact_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-value -I../../include -DYMI_DIAGNOSTICS=1 -c dcn.hip -o /tmp/dcn_diag.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls *.o | grep -v '^dcn.o$') /tmp/dcn_diag.o -o ../libyolact_amd.so) > $O/pipeabl_build.log 2>&1; tail -2 $O/pipeabl_build.log
       timeout 600 python tools/pipe_probe.py --layers ${arg:-proto.8,proto.2,layer1.1.conv2,layer1.1.conv1,layer2.1.conv1,layer3.0.conv1,layer2.1.conv3} --ablate 1,2,3,4,8,12,16,15,31 > $O/pipe_ablation.txt 2>&1; grep -E "abl=|pipelined" $O/pipe_ablation.txt | cut -c1-330 ;;
+    envab1) # the same at batch 1 (100 steps)
+      var="${st#*:}"; name="${var%%=*}"; vals="${var#*=}"
+      for rep in 1 2; do for v in ${vals//,/ }; do
+        env $name=$v timeout 300 python bench.py --batch 1 --steps 100 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('B=1 $name=$v', d['value'], d['ms_per_step'], 'misses', d['config']['plan']['tune_misses'])"
+      done; done | tee -a $O/envab1.txt ;;
     envab) # same-box A/B of one environment switch on the configs[1] bench: envab:YOLACT_AMD_WINO_PROJ=1,0 (values alternate twice)
       var="${st#*:}"; name="${var%%=*}"; vals="${var#*=}"
       for rep in 1 2; do for v in ${vals//,/ }; do
