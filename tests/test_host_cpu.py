@@ -132,13 +132,15 @@ def test_struct_layout_matches_c_compiler(tmp_path):
     from yolact_amd import _lib as L
     src = tmp_path / 'sz.c'
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu '
-                   '%%zu %%zu %%zu %%zu\\n",'
+                   '%%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu\\n",'
                    'sizeof(ymi_conv_seg),sizeof(ymi_conv_desc),sizeof(ymi_dcn_desc),sizeof(ymi_detect_desc),'
                    'offsetof(ymi_conv_desc,seg),offsetof(ymi_conv_desc,B),offsetof(ymi_detect_desc,scores_t),'
                    'offsetof(ymi_dcn_desc,offmask),sizeof(ymi_wino_desc),offsetof(ymi_wino_desc,u_x3),'
                    'sizeof(ymi_jpeg_info),offsetof(ymi_jpeg_info,coef_count),offsetof(ymi_jpeg_info,dw),'
                    'offsetof(ymi_wino_desc,x_up),offsetof(ymi_wino_desc,up_relu),'
-                   'sizeof(ymi_stem_desc),offsetof(ymi_stem_desc,kpad));return 0;}'
+                   'sizeof(ymi_stem_desc),offsetof(ymi_stem_desc,kpad),'
+                   'offsetof(ymi_dcn_desc,om_layout),offsetof(ymi_wino_desc,proj_w_h2),offsetof(ymi_wino_desc,proj_cout),'
+                   'sizeof(ymi_chain_desc),offsetof(ymi_chain_desc,M),offsetof(ymi_chain_desc,act_a));return 0;}'
                    % os.path.join(ROOT, 'include', 'yolact_amd.h'))
     exe = tmp_path / 'sz'
     subprocess.run(['gcc', str(src), '-o', str(exe)], check=True)
@@ -147,7 +149,9 @@ def test_struct_layout_matches_c_compiler(tmp_path):
             L.ConvDesc.seg.offset, L.ConvDesc.B.offset, L.DetectDesc.scores_t.offset, L.DcnDesc.offmask.offset,
             ctypes.sizeof(L.WinoDesc), L.WinoDesc.u_x3.offset, ctypes.sizeof(L.JpegInfo), L.JpegInfo.coef_count.offset,
             L.JpegInfo.dw.offset, L.WinoDesc.x_up.offset, L.WinoDesc.up_relu.offset,
-            ctypes.sizeof(L.StemDesc), L.StemDesc.kpad.offset]
+            ctypes.sizeof(L.StemDesc), L.StemDesc.kpad.offset,
+            L.DcnDesc.om_layout.offset, L.WinoDesc.proj_w_h2.offset, L.WinoDesc.proj_cout.offset,
+            ctypes.sizeof(L.ChainDesc), L.ChainDesc.M.offset, L.ChainDesc.act_a.offset]
     assert got == want, (got, want)
 
 
@@ -366,3 +370,60 @@ def test_data_parallel_world8_uneven_shards_gloo():
         p.join(240)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def test_round4_entries_validate_their_descriptors_before_any_launch():
+    """ymi_pointwise_chain_f32, the fused-projection form of ymi_conv3x3_winograd_f32, ymi_dcn_desc.om_layout and the 32-column /
+    weight-stationary tile requests: bad descriptors get the documented codes without a GPU (validation precedes every HIP call)."""
+    from yolact_amd import _lib as L
+    lib = L.lib()
+    assert lib.ymi_pointwise_chain_f32(None, None) == -3
+    buf = (ctypes.c_float * 64)()
+    p16 = (ctypes.addressof(buf) + 15) & ~15
+    c = L.ChainDesc()
+    assert lib.ymi_pointwise_chain_f32(ctypes.byref(c), None) == -3      # every pointer NULL
+    c.x, c.y, c.w_a_h2, c.scale_a_h2, c.x_amax = p16, p16, p16, p16, p16
+    c.M, c.ldx, c.ldy, c.k_a, c.n_a, c.n_b, c.cout_pad_a = 100, 64, 256, 64, 128, 64, 256
+    assert lib.ymi_pointwise_chain_f32(ctypes.byref(c), None) == -1      # only 64 -> 256 (-> 64) is instantiated
+    c.n_a, c.ldy = 256, 250
+    assert lib.ymi_pointwise_chain_f32(ctypes.byref(c), None) == -2      # row pitch below the channel count / not a multiple of 4
+    c.ldy, c.z, c.ldz = 256, p16, 64
+    assert lib.ymi_pointwise_chain_f32(ctypes.byref(c), None) == -3      # second layer requested without its filters
+    w = L.WinoDesc()
+    w.u, w.V, w.M, w.x, w.proj_w_h2 = p16, p16, p16, p16, p16
+    w.B, w.H, w.W, w.C, w.Cout, w.m = 1, 8, 8, 32, 256, 2
+    assert lib.ymi_conv3x3_winograd_f32(ctypes.byref(w), None) == -2    # fused projection: F(4x4) only
+    w.m, w.Cout = 4, 128
+    assert lib.ymi_conv3x3_winograd_f32(ctypes.byref(w), None) == -2    # ... of a 256-channel layer
+    w.Cout, w.proj_cout, w.proj_ldy = 256, 48, 48
+    assert lib.ymi_conv3x3_winograd_f32(ctypes.byref(w), None) == -2    # ... to at most 32 channels
+    w.proj_cout, w.proj_ldy = 32, 32
+    assert lib.ymi_conv3x3_winograd_f32(ctypes.byref(w), None) == -3    # ... with its scale vector and output
+    dd = L.DcnDesc()
+    dd.offmask, dd.ldo, dd.om_layout = p16, 32, 2
+    assert lib.ymi_dcn_v2_forward_f32(ctypes.byref(dd), None) == -1     # unknown channel order of the offset / mask tensor
+    dd.ldo, dd.om_layout = 20, 0
+    assert lib.ymi_dcn_v2_forward_f32(ctypes.byref(dd), None) == -2     # fewer than 27 channels per pixel
+
+
+def test_mfma_overlap_lint_flags_what_it_should(tmp_path):
+    """tools/check_mfma_overlap.py (the post-build ISA lint): a destination over part of SrcB / SrcC or on SrcA is
+    flagged; an accumulator updated in place (vDst == SrcC) and disjoint operands are not; llvm-objdump's trailing comments are
+    ignored."""
+    import subprocess
+    import sys
+    asm = tmp_path / 'k.s'
+    asm.write_text('\n'.join([
+        '0000000000001900 <_Z6kernelv>:',
+        '\tv_mfma_f32_16x16x32_f16 v[220:223], v[90:93], v[218:221], v[222:225]   // 000000001904: D3D50000',
+        '\tv_mfma_f32_16x16x32_f16 v[134:137], v[50:53], v[138:141], v[134:137]',
+        '\tv_mfma_f32_32x32x16_f16 v[0:15], v[118:121], v[0:3], 0',
+        '\tv_mfma_f32_16x16x32_f16 v[4:7], v[4:7], v[8:11], v[12:15]',
+        '\tv_mfma_f32_32x32x16_f16 a[0:15], v[118:121], v[0:3], a[0:15]',
+        '\tv_mfma_f32_16x16x32_f16 v[20:23], v[30:33], v[40:43], 0', '']))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_mfma_overlap.py'), str(asm)], capture_output=True, text=True)
+    assert r.returncode == 1 and '4 offending MFMA instruction(s)' in r.stdout, r.stdout
+    assert r.stdout.count('srcB') == 2 and r.stdout.count('srcC') == 1 and r.stdout.count('srcA') == 1
+    ok = tmp_path / 'ok.s'
+    ok.write_text('\tv_mfma_f32_16x16x32_f16 v[134:137], v[50:53], v[138:141], v[134:137]\n')
+    assert subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_mfma_overlap.py'), str(ok)]).returncode == 0

@@ -16,6 +16,7 @@
 #   dcnref       build oracle/_ref on the box if missing, run the reference-compiled DCN parity test
 #   evalpy       the reference's unmodified eval.py against the engine (needs the scratch copy staged by tools/stage_reference.sh)
 #   envab:VAR=a,b  same-box A/B of an environment switch on the configs[1] bench
+#   chainpmc     wave-state and LDS counters of the pointwise-chain kernel
 #   plusab       A/B of the DCN offset / mask convolution layouts on configs[3];   tuneplus = re-tune configs[3] + bench with the layer table
 #   py:<file>    python <file> (a probe under tools/), output to <file basename>.log
 O=gpurun_out/$1; shift; mkdir -p $O
@@ -99,6 +100,12 @@ PY
       (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-include-regex mask_upsample -f csv -d $R/$O/uppmc1 -- bash -c "cd $R && YOLACT_AMD_UPSAMPLE=${arg:-rowsnt} python tools/upsample_probe.py --reps 3" > $R/$O/uppmc1.log 2>&1)
       (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM SQ_WAIT_INST_LDS --kernel-include-regex mask_upsample -f csv -d $R/$O/uppmc2 -- bash -c "cd $R && YOLACT_AMD_UPSAMPLE=${arg:-rowsnt} python tools/upsample_probe.py --reps 3" > $R/$O/uppmc2.log 2>&1)
       for k in 1 2; do python tools/pmc_summary.py $O/uppmc$k > $O/pmc_upsample_p$k.tsv 2> $O/uppmc$k.err; cat $O/pmc_upsample_p$k.tsv | cut -c1-420; done
+      find $O -name "*counter_collection.csv" -size +4M -delete ;;
+    chainpmc) # wave-state / LDS counters of the pointwise-chain kernel (csrc/chain.hip) at 138 x 138 x 8
+      PCMD="python tools/chain_probe.py --reps 3"
+      (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-include-regex chain_h2_k -f csv -d $R/$O/chainpmc1 -- bash -c "cd $R && $PCMD" > $R/$O/chainpmc1.log 2>&1)
+      (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE --kernel-include-regex chain_h2_k -f csv -d $R/$O/chainpmc2 -- bash -c "cd $R && $PCMD" > $R/$O/chainpmc2.log 2>&1)
+      for k in 1 2; do python tools/pmc_summary.py $O/chainpmc$k > $O/pmc_chain_p$k.tsv 2> $O/chainpmc$k.err; cat $O/pmc_chain_p$k.tsv | cut -c1-420; done
       find $O -name "*counter_collection.csv" -size +4M -delete ;;
     pipeabl) # diagnostics build of csrc/dcn.hip, then the ablation of the pipelined kernel as an ordinary convolution on representative layers
       (cd yolact_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-value -I../../include -DYMI_DIAGNOSTICS=1 -c dcn.hip -o /tmp/dcn_diag.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls *.o | grep -v '^dcn.o$') /tmp/dcn_diag.o -o ../libyolact_amd.so) > $O/pipeabl_build.log 2>&1; tail -2 $O/pipeabl_build.log
