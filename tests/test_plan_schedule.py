@@ -201,3 +201,52 @@ def test_fused_upsample_source_outlives_its_consumer(config, size, B):
             continue
         _r, w = _accesses(plan, op, bufs)
         assert not any(_conflict(lo, x) for x in w), (plan.ops[i][2], 'writes the low-res source of the fused upsampling')
+
+
+def test_offset_mask_filters_are_padded_and_tap_interleaved():
+    """engine.pack_offmask: conv_offset_mask's 27 filters (dcn_v2.py:107-112: 18 offsets, then 9 mask logits) become 32 rows — row
+    3k = dh_k, 3k + 1 = dw_k, 3k + 2 = mask_k (ymi_dcn_desc.om_layout = 1), rows 27 .. 31 zero — with the bias permuted the same way;
+    without interleaving the reference's order is kept.  The filters' VALUES are untouched (same arithmetic per channel)."""
+    import torch.nn as nn
+    from yolact_amd.engine import pack_offmask
+    torch.manual_seed(3)
+    conv = nn.Conv2d(64, 27, 3, stride=2, padding=1)
+    w = conv.weight.detach().permute(0, 2, 3, 1).reshape(27, -1)         # the engine's K order: (ky, kx, c)
+    for inter in (True, False):
+        pk = pack_offmask(conv, None, inter)
+        assert (pk.Cout, pk.cout_alg, pk.stride, pk.pad, pk.kh, pk.kw) == (32, 27, 2, 1, 3, 3)
+        rows = pk._wp_host[:32, :w.shape[1]]
+        order = [c for k in range(9) for c in (2 * k, 2 * k + 1, 18 + k)] if inter else list(range(27))
+        assert torch.equal(rows[:27], w[order]) and rows[27:].abs().max() == 0
+        assert torch.equal(pk.bias.cpu()[:27], conv.bias.detach()[order]) and pk.bias.cpu()[27:].abs().max() == 0
+
+
+def test_narrow_tile_candidates_follow_their_envelopes():
+    """Plan.dcnp_candidates / Plan.ws_candidates (pure host logic): 32-column tiles are offered to Cout <= 32 layers and to nothing
+    else; a weight-stationary candidate always carries enough K ranges for its filters to fit 64 KB of LDS, every range non-empty;
+    layers with a residual or more than 64 channels get no weight-stationary candidate."""
+    from yolact_amd import _lib as L
+    from yolact_amd.engine import Plan
+
+    def desc(B, H, Cin, Cout, k, res=L.RES_NONE):
+        d = L.ConvDesc()
+        d.B, d.H, d.W, d.Ho, d.Wo, d.Cin, d.Cout = B, H, H, H, H, Cin, Cout
+        d.kh = d.kw = k
+        d.stride, d.pad, d.Kpad, d.nseg, d.res_mode = 1, k // 2, k * k * Cin, 1, res
+        return d
+    names = lambda cands: {L.TILE_NAMES[c & 255] for c in cands}          # noqa: E731
+    narrow = {'dcnp128x32w4', 'dcnp256x32w8', 'dcnp64x32w2'}
+    assert names(Plan.dcnp_candidates(desc(8, 69, 128, 32, 3))) == narrow
+    assert not (names(Plan.dcnp_candidates(desc(8, 69, 128, 128, 3))) & narrow)
+    for d in (desc(8, 69, 128, 32, 3), desc(8, 35, 256, 32, 3), desc(8, 18, 512, 32, 3), desc(8, 138, 256, 32, 1), desc(8, 138, 64, 64, 1),
+              desc(1, 138, 256, 64, 1)):
+        cands = Plan.ws_candidates(d)
+        assert cands, (d.Cin, d.Cout)
+        for c in cands:
+            name, S = L.TILE_NAMES[c & 255], max(c >> 8, 1)
+            cols = int(name[2:].split('x')[1].split('w')[0])
+            nk = d.Kpad // 32
+            per = -(-nk // S)
+            assert (cols == 32) == (d.Cout <= 32)
+            assert per * cols * 128 <= 65536 and (S == 1 or per * (S - 1) < nk), (name, S, nk)
+    assert Plan.ws_candidates(desc(8, 138, 64, 256, 1)) == [] and Plan.ws_candidates(desc(8, 138, 256, 64, 1, L.RES_ADD)) == []

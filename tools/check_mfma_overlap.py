@@ -4,8 +4,9 @@ without being identical to it.
 
 hipcc 7.2 (ROCm 7.2.0) allocates v_mfma_f32_16x16x32_f16 with vDst PARTIALLY overlapping SrcC / SrcB (seen in csrc/chain.hip:
 `v_mfma_f32_16x16x32_f16 v[220:223], v[90:93], v[218:221], v[222:225]`); on the MI355X that instruction produced wrong values in
-the overlapping registers, nondeterministically (profiles/r04_mfma_overlap.txt).  The kernels avoid it by construction (every
-accumulator starts as an opaque zero of its own, so its MFMAs stay in the tied form: csrc/common.h YMI_ACC_ZERO), and `make lint`
+the overlapping registers, nondeterministically (profiles/r04_mfma_overlap.txt).  The kernels that use the new MFMAs go through
+wrappers that keep the result and all three sources live at one point, hence in disjoint registers (csrc/common.h ymi_mfma16 /
+ymi_mfma32), and `make lint`
 runs this scan over the disassembly of every built object so that a compiler or source change that brings the pattern back is
 caught before it reaches the GPU.
 

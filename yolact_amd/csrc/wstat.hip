@@ -13,10 +13,11 @@
 //     contiguous bytes of the pixel's channel vector — two buffer_load_dwordx4 straight into the registers the MFMA reads (after
 //     the fp16 split); 4 lanes cover the pixel's 128-byte line of the chunk, a wave instruction touches 16 lines;
 //   * no barrier after the filter copy: every wave streams its own rows, D chunks of loads in flight in a register ring, at its
-//     own pace (the pipelined kernel's chunk barrier couples 2 .. 16 waves per 32-deep step; at 6 .. 12 MFMAs per step that
-//     coupling, not the memory pipe, was the cost: dcnp64x32w2 reached 5.6 TB/s of im2col bytes, profiles/r04_plus_offmask.txt);
+//     own pace (the pipelined kernel's chunk barrier couples 2 .. 16 waves per 32-deep step, 6 .. 12 MFMAs each);
 //   * the MFMA is issued as D^T = W X^T (filters as the A operand): a lane ends up with FOUR CONSECUTIVE output channels of one
 //     pixel, so the epilogue is float4 scale / bias / activation / store with no transposition.
+// Measured (profiles/r04_ws_probe.txt): a draw with the 32-column tiles of the pipelined kernel — these launches take 16 .. 30 us, of
+// which launch, ramp, tail and the split-K second pass are most; the tuner picks per shape.
 // Arithmetic: the fp16x2 scheme of the other tiles (x * s = h + l, s a power of two from the tensor's magnitude bound; products
 // h*l, l*h, h*h; fp32 accumulation), same filter planes, same scale_h2.
 #include "common.h"
