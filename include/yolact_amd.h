@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define YMI_ABI_VERSION 6
+#define YMI_ABI_VERSION 7
 
 /* negative return codes (ymi_strerror) */
 #define YMI_EFORMAT (-4)       /* corrupt or truncated input stream (ymi_jpeg_*) */
@@ -447,6 +447,39 @@ typedef struct ymi_chain_desc {
   int32_t act_a, act_b, _pad0;                               /* YMI_ACT_NONE / RELU / LEAKY01 */
 } ymi_chain_desc;
 int ymi_pointwise_chain_f32(const ymi_chain_desc *d, void *stream);
+
+/* -- workspace sizes (ABI 7) ------------------------------------------------------------------------------------------------
+ * The library never allocates device memory (SURVEY 8(b) "ownership": the reference's extension allocates its own outputs and
+ * scratch, dcn_v2_cuda.cu:89-91,165-170; here the CALLER does).  A host that is not the Python shim asks this function how many
+ * BYTES a workspace needs instead of re-deriving the formulas in the comments above.  `what` selects the workspace, `desc` points
+ * at the descriptor of the call it belongs to (only shape fields are read, pointers may be NULL).  Returns the size in bytes
+ * (>= 0; 0 = the call needs no such workspace in this configuration) or a negative YMI_E* code. */
+enum {
+  YMI_WS_WINO_V = 1,        /* desc: ymi_wino_desc      -> ymi_wino_desc.V  = G*T*C floats, T = B*ceil(H/m)*ceil(W/m), G = (m+2)^2 */
+  YMI_WS_WINO_M = 2,        /* desc: ymi_wino_desc      -> ymi_wino_desc.M  = G*T*ceil(Cout/4)*4 floats */
+  YMI_WS_SPLITK = 3,        /* desc: ymi_conv_desc      -> ymi_conv_desc.split_ws = split_k * B*Ho*Wo * Cout floats (0 when split_k <= 1) */
+  YMI_WS_MASK_IOU = 4,      /* desc: ymi_mask_iou_shape -> ymi_mask_iou_f32's ws = A*B + A + B floats */
+  YMI_WS_JPEG_COEFS = 5,    /* desc: ymi_jpeg_info filled by ymi_jpeg_parse -> int16 coefficient buffer (host, and its device copy) */
+  YMI_WS_JPEG_PLANES = 6,   /* desc: ymi_jpeg_info      -> ymi_jpeg_reconstruct_bgr_u8's planes_ws */
+  YMI_WS_DETECT_SCORES_T = 7,   /* desc: ymi_detect_desc -> scores_t  [B,C-1,P] floats */
+  YMI_WS_DETECT_PER_PRIOR = 8,  /* desc: ymi_detect_desc -> keep / maxsc / argmax: [B,P] 4-byte elements EACH */
+  YMI_WS_DETECT_CAND = 9,       /* desc: ymi_detect_desc -> cand_score / cand_prior: [B,(C-1)*top_k] 4-byte elements EACH */
+  YMI_WS_DETECT_REC = 10,       /* desc: ymi_detect_desc -> out_rec [B, 1 + cap*(6+D)] floats, cap = cross_class ? top_k : max_det */
+  YMI_WS_AMAX_SLOT = 11,        /* desc: NULL            -> one magnitude-bound slot (x_amax / y_amax): YMI_AMAX_SUB * YMI_AMAX_STRIDE floats */
+  YMI_WS_RLE_COUNTS = 12        /* desc: ymi_rle_shape   -> ymi_mask_rle_f32's counts [N,cap] uint32 (cap = h*w + 1 covers every mask) */
+};
+typedef struct { int32_t A, B; int64_t n; } ymi_mask_iou_shape;
+typedef struct { int32_t N, h, w, cap; } ymi_rle_shape;      /* cap <= 0: the safe capacity h*w + 1 */
+int64_t ymi_workspace_bytes(int what, const void *desc);
+
+/* -- box calibration (ABI 7; csrc/calib.hip) ------------------------------------------------------------------------------------
+ * Two fixed micro-workloads the caller times (events on `stream`) right before a benchmark, so that a throughput number can be
+ * attributed to the box or to the code (bench.py `box_calibration`).  Not on the product path.
+ * ymi_calib_mfma_f16: `blocks` x 4 waves, each `iters` x 4 register-resident v_mfma_f32_32x32x16_f16 on random-mantissa operands;
+ *   *flops = the fp16 FLOPs executed.  ymi_calib_hbm_copy: dst[i] = src[i] over n_floats (n % 4 == 0, 16-byte aligned), float4
+ *   lanes; *bytes = read + written. */
+int ymi_calib_mfma_f16(float *out, int blocks, int iters, double *flops, void *stream);
+int ymi_calib_hbm_copy(const float *src, float *dst, long n_floats, double *bytes, void *stream);
 
 /* -- profiling hooks -------------------------------------------------------------------- */
 /* When enabled, every conv launch is bracketed by hipEvents on its stream; ymi_prof_read returns

@@ -427,3 +427,53 @@ def test_mfma_overlap_lint_flags_what_it_should(tmp_path):
     ok = tmp_path / 'ok.s'
     ok.write_text('\tv_mfma_f32_16x16x32_f16 v[134:137], v[50:53], v[138:141], v[134:137]\n')
     assert subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_mfma_overlap.py'), str(ok)]).returncode == 0
+
+
+def test_workspace_bytes_query_matches_what_the_engine_allocates():
+    """ymi_workspace_bytes (ABI 7; SURVEY 8(b) "ownership: a ymi_workspace_bytes(op, shape...) query per op"): host code, no GPU.
+    Every selector against the formula the Python engine itself allocates with (engine.Plan._wino_op, _apply_choice,
+    layers/box_utils.mask_iou, Detect._workspace, parallel records), the error codes, and the JPEG sizes against ymi_jpeg_parse."""
+    from yolact_amd import _lib as L
+    lib = L.lib()
+    wb = lambda what, d: lib.ymi_workspace_bytes(what, ctypes.byref(d) if d is not None else None)
+    for m, B, H, W, Cin, Cout in ((4, 8, 138, 138, 256, 256), (2, 8, 18, 18, 512, 512), (4, 1, 69, 69, 256, 351), (0, 2, 5, 5, 256, 30)):
+        d = L.WinoDesc()
+        d.m, d.B, d.H, d.W, d.C, d.Cout = m, B, H, W, Cin, Cout
+        mm = m or 2
+        T, G = B * -(-H // mm) * -(-W // mm), (mm + 2) ** 2
+        assert wb(L.WS_WINO_V, d) == 4 * G * T * Cin
+        assert wb(L.WS_WINO_M, d) == 4 * G * T * (-(-Cout // 4) * 4)
+    d = L.WinoDesc()
+    d.m, d.B, d.H, d.W, d.C, d.Cout = 3, 1, 8, 8, 32, 32
+    assert wb(L.WS_WINO_V, d) == -1
+    c = L.ConvDesc()
+    c.B, c.Ho, c.Wo, c.Cout, c.split_k = 8, 35, 35, 1024, 4
+    assert wb(L.WS_SPLITK, c) == 4 * 4 * 8 * 35 * 35 * 1024
+    c.split_k = 1
+    assert wb(L.WS_SPLITK, c) == 0
+    s = L.MaskIouShape(100, 7, 550 * 550)
+    assert wb(L.WS_MASK_IOU, s) == 4 * (100 * 7 + 100 + 7)
+    dd = L.DetectDesc()
+    dd.B, dd.P, dd.C, dd.D, dd.top_k, dd.max_det, dd.cross_class = 8, 19248, 81, 32, 200, 100, 0
+    assert wb(L.WS_DETECT_SCORES_T, dd) == 4 * 8 * 80 * 19248
+    assert wb(L.WS_DETECT_PER_PRIOR, dd) == 4 * 8 * 19248
+    assert wb(L.WS_DETECT_CAND, dd) == 4 * 8 * 80 * 200
+    assert wb(L.WS_DETECT_REC, dd) == 4 * 8 * (1 + 100 * 38)        # 15.2 KB per image: the payload of the one gather
+    dd.cross_class = 1
+    assert wb(L.WS_DETECT_REC, dd) == 4 * 8 * (1 + 200 * 38)
+    assert wb(L.WS_AMAX_SLOT, None) == 16 * 64 * 4
+    r = L.RleShape(100, 550, 550, 0)
+    assert wb(L.WS_RLE_COUNTS, r) == 4 * 100 * (550 * 550 + 1)
+    r.cap = 4096
+    assert wb(L.WS_RLE_COUNTS, r) == 4 * 100 * 4096
+    assert wb(L.WS_WINO_V, None) == -3 and wb(99, r) == -1
+    # JPEG: the sizes ymi_jpeg_parse reports are the ones the query returns
+    import numpy as np
+    z = np.load(os.path.join(ROOT, 'tests', 'golden', 'jpeg.npz'), allow_pickle=True)
+    key = [k for k in z.files if k.startswith('jpg_')]
+    assert key
+    for k in key[:5]:
+        data = bytes(z[k].tobytes())
+        info = L.JpegInfo()
+        assert lib.ymi_jpeg_parse(data, len(data), ctypes.byref(info)) == 0
+        assert wb(L.WS_JPEG_COEFS, info) == 2 * info.coef_count and wb(L.WS_JPEG_PLANES, info) == info.plane_bytes

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libyolact_amd.so')
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 ACT_NONE, ACT_RELU, ACT_LEAKY01, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 RES_NONE, RES_ADD, RES_BILINEAR = 0, 1, 2
@@ -128,6 +128,18 @@ class StemDesc(C.Structure):
                 ('kpad', C.c_int32), ('_pad0', C.c_int32)]
 
 
+class MaskIouShape(C.Structure):
+    _fields_ = [('A', C.c_int32), ('B', C.c_int32), ('n', C.c_int64)]
+
+
+class RleShape(C.Structure):
+    _fields_ = [('N', C.c_int32), ('h', C.c_int32), ('w', C.c_int32), ('cap', C.c_int32)]
+
+
+# ymi_workspace_bytes selectors (include/yolact_amd.h YMI_WS_*)
+(WS_WINO_V, WS_WINO_M, WS_SPLITK, WS_MASK_IOU, WS_JPEG_COEFS, WS_JPEG_PLANES, WS_DETECT_SCORES_T, WS_DETECT_PER_PRIOR,
+ WS_DETECT_CAND, WS_DETECT_REC, WS_AMAX_SLOT, WS_RLE_COUNTS) = range(1, 13)
+
 EFORMAT, EUNSUPPORTED = -4, -5
 
 # every symbol include/yolact_amd.h declares: (name, restype, argtypes)
@@ -172,6 +184,9 @@ SYMBOLS = [
     ('ymi_coco_poly_fill_u8', C.c_int, [_P, _I, _I, _I, _P]),
     ('ymi_coco_rle_fill_u8', C.c_int, [_P, C.c_long, _I, _I, _P]),
     ('ymi_coco_rle_string_fill_u8', C.c_int, [C.c_char_p, C.c_long, _I, _I, _P]),
+    ('ymi_workspace_bytes', C.c_int64, [_I, _P]),
+    ('ymi_calib_mfma_f16', C.c_int, [_P, _I, _I, C.POINTER(C.c_double), _P]),
+    ('ymi_calib_hbm_copy', C.c_int, [_P, _P, C.c_long, C.POINTER(C.c_double), _P]),
     ('ymi_debug_set_trace', C.c_int, [_P, C.c_long]),
     ('ymi_prof_enable', C.c_int, [_I]),
     ('ymi_prof_count', C.c_int, []),
