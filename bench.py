@@ -453,7 +453,7 @@ def cpu_baseline(sd, size, batch=8, budget_s=14.0):
         naff = ncpu
     default_threads = torch.get_num_threads()
     x = synth_images(batch, size, size, seed=1234)           # the very batch the GPU path is timed on
-    cands = sorted({t for t in (4, 8, 16, 32, 64, 128) if 1 <= t <= naff})
+    cands = sorted({t for t in (4, 8, 16, 32, 64, 128) if 1 <= t <= naff} | {max(1, min(naff, 4))})   # (never empty: a 1 - 3 CPU mask gets its own size)
 
     def one_batch():
         t0 = time.perf_counter()
@@ -488,7 +488,7 @@ def cpu_baseline(sd, size, batch=8, budget_s=14.0):
                       % (batch, size, size, len(sweep), 3 * len(runs), dt, torch.__version__)}
 
 
-def secondary_lines(net, x, size, steps=10):
+def secondary_lines(net, x, size, steps=10, config=CONFIG):
     """The reference's FPS definitions next to the headline (SURVEY 8(d) "Secondary"): (a) the same batch
     with postprocess() to size x size inside the step (one lincomb + one upsample launch for the whole batch), (b) batch 1
     end to end exactly like eval.py:264-281 prep_benchmark — forward, Detect, postprocess, the top-k (5) `.cpu().numpy()`
@@ -530,7 +530,11 @@ def secondary_lines(net, x, size, steps=10):
         preds = net(x1)
         t = postprocess(preds, size, size, crop_masks=True, score_threshold=0)
         classes, scores, boxes, masks = [v[:5] for v in t]
-        scores.cpu().numpy(); classes.cpu().numpy(); boxes.cpu().numpy(); masks.cpu().numpy()
+        if isinstance(scores, list):                 # YOLACT++ (eval.py:270-272): [box scores, box scores * maskiou]
+            scores[0].cpu().numpy(); scores[1].cpu().numpy()
+        else:
+            scores.cpu().numpy()
+        classes.cpu().numpy(); boxes.cpu().numpy(); masks.cpu().numpy()
         torch.cuda.synchronize()
     t1 = timed(step_ref_fps, 4 * steps)
     out['reference_fps_definition_batch1'] = {
@@ -700,10 +704,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        per_rank_ms, gather_us = None, None
         if have_pg:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            mine_t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            every = [torch.zeros_like(mine_t) for _ in range(world)]
+            dist.all_gather(every, mine_t)                       # every rank's own wall time of the timed region
+            per_rank_ms = [round(float(v.item()) / args.steps * 1e3, 3) for v in every]
+            t = mine_t.clone()
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
+            # the collective alone: the record gather of the last step repeated 50 times, host-paired wall time
+            # per call (launch + RCCL kernel + completion), after the timed region
+            last = parallel.pack_records(net.forward_device(x))
+            torch.cuda.synchronize()
+            dist.barrier()
+            tg = time.perf_counter()
+            for _ in range(50):
+                gatherer(last, args.batch, force_collective=True)
+            torch.cuda.synchronize()
+            gather_us = round((time.perf_counter() - tg) / 50 * 1e6, 1)
 
         result = None
         if rank == 0:
@@ -734,6 +753,9 @@ def main():
                 'gathered_records': got['n'],
                 'collective': ('dist.gather over the nccl (RCCL) backend, %d rank(s)' % dist.get_world_size()) if have_pg
                               else 'none (RCCL init failed: %s)' % rccl_error,
+                'per_rank_ms_per_step': per_rank_ms,            # each rank's own clock over the timed region (value uses the MAX)
+                'gather_us': gather_us,                         # the record gather alone, host-paired, 50 back-to-back calls
+                'record_bytes_per_image': 4 * int(parallel.pack_records(net.forward_device(x)).shape[1]),
                 'roofline': rf,
             }
             if rf['engine']['h2_share_of_time'] > 0:
@@ -762,8 +784,8 @@ def main():
                 for k, (ms, fl, kern) in layers.items():
                     print('%-22s %8.3f ms %8.2f GFLOP %7.1f TF/s  %s' % (k, ms, fl / 1e9, fl / ms / 1e9, kern),
                           file=sys.stderr)
-            if world == 1 and not args.no_secondary and not getattr(yolact_amd.CONFIGS[args.config], 'use_maskiou', False):
-                result['secondary'] = secondary_lines(net, x, size)
+            if world == 1 and not args.no_secondary:
+                result['secondary'] = secondary_lines(net, x, size, config=args.config)
         if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == CONFIG:
             result['cpu_baseline'] = cpu_baseline(sd, size, args.batch)
     if have_pg:

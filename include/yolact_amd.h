@@ -432,7 +432,11 @@ int ymi_stem_pool_f32(const ymi_stem_desc *d, void *stream);
  * x [M,ldx] (k_a = 64 channels), res [M,res_ld] or NULL, y [M,ldy] (n_a = 256), z [M,ldz] (n_b = 64) or NULL (then only y is
  * computed): NHWC rows, M = B*H*W.  Filters as the fp16x2 planes of the two layers (ymi_conv_desc.w_h2 / scale_h2: planes
  * [2][cout_pad][K]); x_amax / y_amax / z_amax as in ymi_conv_desc (x_amax required).  y is written once and never read back:
- * the second GEMM takes it from LDS. */
+ * the second GEMM takes it from LDS.
+ * ALIASING: y and z must not overlap each other, res or (for y) x.  z MAY be x exactly in place — z == x and ldz == ldx — and in no
+ * other overlapping form: a block reads x rows [32 t, 32 t + 32) before it writes the same rows of z and no other block touches
+ * them; any other overlap lets one block's z rows land on x rows another block has not read yet (engine.Plan checks this before
+ * it fuses two launches into this one; the library does not). */
 typedef struct ymi_chain_desc {
   const float *x, *res;
   float *y, *z;

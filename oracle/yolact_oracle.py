@@ -228,18 +228,24 @@ def forward_raw(x: Tensor, sd: Dict[str, Tensor], cfg) -> Dict[str, Tensor]:
     feats = fpn(sel, sd, cfg.fpn.num_downsample)
     for i, t in enumerate(feats):
         stages['P%d' % (i + 3)] = t
-    proto = make_net_forward(feats[cfg.mask_proto_src], sd, 'proto_net', cfg.mask_proto_net, include_last_relu=False)
-    proto = F.relu(proto)                                    # cfg.mask_proto_prototype_activation
-    proto = proto.permute(0, 2, 3, 1).contiguous()           # yolact.py:599
+    emb = bool(getattr(cfg, 'eval_mask_branch', True))       # eval.py:1067-1068: --detect sets cfg.eval_mask_branch = False
+    proto = None
+    if emb:                                                  # yolact.py:579-580: no prototypes without the mask branch
+        proto = make_net_forward(feats[cfg.mask_proto_src], sd, 'proto_net', cfg.mask_proto_net, include_last_relu=False)
+        proto = F.relu(proto)                                # cfg.mask_proto_prototype_activation
+        proto = proto.permute(0, 2, 3, 1).contiguous()       # yolact.py:599
     A = sum(len(a) for a in bb.pred_aspect_ratios[0]) * len(bb.pred_scales[0])
-    C, D = cfg.num_classes, proto.shape[-1]
+    C, D = cfg.num_classes, int(sd['prediction_layers.0.mask_layer.weight'].shape[0]) // A
     locs, confs, masks, priors = [], [], [], []
     B = x.shape[0]
     for lvl, f in enumerate(feats):
         u = make_net_forward(f, sd, 'prediction_layers.0.upfeature', cfg.extra_head_net)
         locs.append(_conv(u, sd, 'prediction_layers.0.bbox_layer', 1, 1).permute(0, 2, 3, 1).reshape(B, -1, 4))
         confs.append(_conv(u, sd, 'prediction_layers.0.conf_layer', 1, 1).permute(0, 2, 3, 1).reshape(B, -1, C))
-        masks.append(torch.tanh(_conv(u, sd, 'prediction_layers.0.mask_layer', 1, 1).permute(0, 2, 3, 1).reshape(B, -1, D)))
+        if emb:
+            masks.append(torch.tanh(_conv(u, sd, 'prediction_layers.0.mask_layer', 1, 1).permute(0, 2, 3, 1).reshape(B, -1, D)))
+        else:                                                # yolact.py:172-175: zero coefficients, no activation (:189)
+            masks.append(torch.zeros(B, locs[-1].shape[1], D))
         priors.append(make_priors(f.shape[2], f.shape[3], bb.pred_scales[lvl], bb.pred_aspect_ratios[lvl],
                                   cfg.max_size, bb.use_pixel_scales, bb.preapply_sqrt, bb.use_square_anchors))
     out = dict(loc=torch.cat(locs, 1), conf_logits=torch.cat(confs, 1), mask=torch.cat(masks, 1),
@@ -316,7 +322,7 @@ def detect(raw: Dict[str, Tensor], cfg, cross_class=False) -> List[Optional[Dict
     for b in range(raw['loc'].shape[0]):
         r = detect_image(raw['conf'][b], raw['loc'][b], raw['mask'][b], raw['priors'], cfg.nms_conf_thresh,
                          cfg.nms_thresh, cfg.nms_top_k, cfg.max_num_detections, cross_class)
-        if r is not None:
+        if r is not None and raw.get('proto') is not None:       # detection.py:73-74
             r['proto'] = raw['proto'][b]
         out.append(r)
     return out
@@ -364,7 +370,11 @@ def postprocess(det: Optional[Dict[str, Tensor]], w: int, h: int, cfg, sd=None, 
                 det[key] = det[key][k]
         if det['score'].shape[0] == 0:
             return None
-    classes, boxes, scores, coef, proto = det['class'], det['box'].clone(), det['score'], det['mask'], det['proto']
+    classes, boxes, scores, coef, proto = det['class'], det['box'].clone(), det['score'], det['mask'], det.get('proto')
+    if not bool(getattr(cfg, 'eval_mask_branch', True)):     # output_utils.py:58,97-122: boxes only, `masks` stays the coefficient rows
+        x1, x2 = sanitize(boxes[:, 0], boxes[:, 2], w)
+        y1, y2 = sanitize(boxes[:, 1], boxes[:, 3], h)
+        return classes, scores, torch.stack([x1, y1, x2, y2], 1).long(), coef
     masks = torch.sigmoid(proto @ coef.t())
     if crop_masks:
         masks = crop(masks, boxes)

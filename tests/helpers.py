@@ -12,7 +12,9 @@ from yolact_amd.config import CONFIGS
 from yolact_amd.utils.synth import synth_images, synth_state_dict
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-ALL_CASES = ['r50_dense', 'r50_sparse', 'r50_empty', 'r101_base', 'darknet53', 'im700', 'plus_r50', 'r50_cc', 'r50_few']
+ALL_CASES = ['r50_dense', 'r50_sparse', 'r50_empty', 'r101_base', 'darknet53', 'im700', 'plus_r50', 'r50_cc', 'r50_few',
+             'plus_base', 'im400', 'plus_r50_b2']      # round 5: yolact_plus_base (R101++, dcn_interval 3), yolact_im400, a YOLACT++ batch of 2
+NOMASK_CASE = 'r50_nomask'                             # eval.py --detect: cfg.eval_mask_branch = False (zero coefficients, no prototypes)
 
 
 @functools.lru_cache(maxsize=None)
@@ -24,7 +26,10 @@ def load_golden(name):
 
 
 def case_cfg(meta):
-    return CONFIGS[meta['config']].copy()
+    cfg = CONFIGS[meta['config']].copy()
+    if 'eval_mask_branch' in meta:
+        cfg.eval_mask_branch = bool(meta['eval_mask_branch'])
+    return cfg
 
 
 def case_state_dict(meta):

@@ -31,6 +31,8 @@ CASES = [
     ('configs4_im700_b8', 'yolact_im700_config', 8, 700, 5, 0.04, 3234),       # per-GPU share of configs[4]
     ('configs3_plus_r50_b8', 'yolact_plus_resnet50_config', 8, 550, 6, 0.04, 4234),
     ('darknet53_b8', 'yolact_darknet53_config', 8, 550, 4, 0.04, 5234),        # named in north_star
+    ('plus_base_b8', 'yolact_plus_base_config', 8, 550, 9, 0.04, 6234),        # the published YOLACT++ R101 row (README.md:80; data/config.py:772-792)
+    ('im400_b8', 'yolact_im400_config', 8, 400, 10, 0.04, 7234),               # data/config.py:706
 ]
 
 

@@ -51,6 +51,30 @@ def test_world1_nccl_gather_roundtrip_equals_detect_finish():
                 assert torch.equal(a['detection']['box'], r['detection']['box'])
                 assert torch.equal(a['detection']['class'], r['detection']['class'])
                 assert a['detection']['proto'].shape == r['detection']['proto'].shape
+        # masks='bits' (round 5): the owners' bit-packed masks ride a second gather (forced through the real collective here);
+        # every detection of the global batch carries its final masks, local (prototypes present) or remote (prototypes None)
+        import os
+        from yolact_amd.layers.output_utils import postprocess, postprocess_bits
+        os.environ['YOLACT_AMD_FORCE_GATHER'] = '1'
+        try:
+            shm = net.forward_sharded(x, masks='bits', mask_size=(97, 131))
+        finally:
+            os.environ.pop('YOLACT_AMD_FORCE_GATHER', None)
+        torch.cuda.synchronize()
+        for b, (a, r) in enumerate(zip(shm, ref0)):
+            if r['detection'] is None:
+                assert a['detection'] is None
+                continue
+            assert a['mask_size'] == (97, 131)
+            classes, scores, boxes, masks = postprocess(ref0, 131, 97, batch_idx=b)
+            c1, s1, b1, bits1 = postprocess_bits(shm, 131, 97, batch_idx=b)                 # local form: recomputed from the prototypes
+            assert torch.equal(a['detection']['mask_bits'], bits1) and a['detection']['mask_bits'].dtype == torch.int64
+            assert torch.equal(parallel.unpack_mask_bits(bits1, 97, 131), masks)
+            a['detection']['proto'] = None                                                  # as if computed on another rank
+            c2, s2, b2, bits2 = postprocess_bits(shm, 131, 97, batch_idx=b)
+            assert torch.equal(bits2, bits1) and torch.equal(b2, boxes) and torch.equal(c2, classes) and torch.equal(s2, scores)
+            with pytest.raises(RuntimeError, match='assembled for'):
+                postprocess_bits(shm, 550, 550, batch_idx=b)
         same = parallel.gather_records(rec, dst=0)                         # world 1, not forced: passthrough
         assert same is rec
         got = parallel.gather_records(rec, dst=0, force_collective=True)   # the real collective, one rank

@@ -18,7 +18,7 @@ def _make_net(config):
     return Yolact()
 
 
-@pytest.mark.parametrize('name', ['r50_dense', 'r101_base', 'darknet53', 'im700', 'plus_r50'])
+@pytest.mark.parametrize('name', ['r50_dense', 'r101_base', 'darknet53', 'im700', 'plus_r50', 'plus_base', 'im400'])
 def test_state_dict_layout_equals_reference(name):
     """Our parameter containers expose exactly the reference's keys and shapes, so reference
     checkpoints load unchanged."""
@@ -477,3 +477,153 @@ def test_workspace_bytes_query_matches_what_the_engine_allocates():
         info = L.JpegInfo()
         assert lib.ymi_jpeg_parse(data, len(data), ctypes.byref(info)) == 0
         assert wb(L.WS_JPEG_COEFS, info) == 2 * info.coef_count and wb(L.WS_JPEG_PLANES, info) == info.plane_bytes
+
+
+def _gloo_mask_worker(rank, world, port, q):
+    """World-2 data-parallel step WITH the mask gather (round 5): every rank 'computes' its shard (deterministic stand-ins for
+    forward_device / postprocess_bits_batch — there is no GPU here), the records and the bit-packed masks reach rank 0 through the
+    two fixed-capacity gathers, and rank 0 feeds EVERY image of the global batch through prep_metrics-shaped code
+    (eval.py:376-440: mask IoU of each image's detections against its ground truth) — local and remote images alike."""
+    import torch.distributed as dist
+    from yolact_amd import parallel
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
+    B, cap, D, h, w = 5, 6, 4, 9, 13                       # 5 images over 2 ranks = 3 + 2 (uneven), 117 pixels = 2 words per mask
+    W64 = (h * w + 63) // 64
+
+    def image_masks(b):                                    # the "true" final masks of global image b: [n_b, h, w] float {0,1}
+        g = torch.Generator().manual_seed(500 + b)
+        n = 1 + (b * 2) % cap
+        return (torch.rand(n, h, w, generator=g) > 0.5).float()
+
+    def pack(m):                                           # float masks -> bits, the layout of ymi_mask_upsample_bits
+        n = m.shape[0]
+        flat = torch.zeros(n, W64 * 64, dtype=torch.int64)
+        flat[:, :h * w] = m.reshape(n, -1).to(torch.int64)
+        return (flat.view(n, W64, 64) << torch.arange(64, dtype=torch.int64)).sum(-1)
+
+    class FakeNet:
+        class detect:
+            top_k, use_cross_class_nms = 200, False
+
+        def forward_device(self, x):
+            lo = int(x[0, 0, 0, 0])                        # the global index of the shard's first image rides in the pixels
+            b = x.shape[0]
+            g = torch.Generator().manual_seed(900 + lo)
+            out = dict(count=torch.tensor([image_masks(lo + i).shape[0] for i in range(b)], dtype=torch.int32),
+                       box=torch.rand(b, cap, 4, generator=g), score=torch.rand(b, cap, generator=g),
+                       cls=torch.randint(0, 80, (b, cap), generator=g), coef=torch.rand(b, cap, D, generator=g),
+                       proto=torch.rand(b, 3, 3, D, generator=g), lo=lo)
+            return out
+    net = FakeNet()
+    x = torch.arange(B, dtype=torch.float32).view(B, 1, 1, 1).expand(B, 3, 4, 4).contiguous()
+
+    def masks_fn(out):
+        if out is None:
+            return torch.zeros(0, cap, W64, dtype=torch.int64)
+        bits = torch.zeros(out['count'].shape[0], cap, W64, dtype=torch.int64)
+        for i in range(bits.shape[0]):
+            m = image_masks(out['lo'] + i)
+            bits[i, :m.shape[0]] = pack(m)
+        return bits
+    import yolact_amd.parallel as P
+    P._cap_of = lambda fd: cap                              # (the stand-in has no config)
+    g1, g2 = parallel.RecordGatherer(0), parallel.RecordGatherer(0)
+    for step in range(2):                                   # twice into the same persistent buffers
+        rec, mine, bits = parallel.sharded_forward(net.forward_device, x, D, g1, 0, masks_fn=masks_fn, mask_gatherer=g2)
+        lo, hi = parallel.shard_range(B, rank, world)
+        if rank != 0:
+            assert rec is None and bits is None
+            continue
+        assert rec.shape[0] == B and bits.shape == (B, cap, W64) and bits.dtype == torch.int64
+        res = parallel.assemble_sharded(rec, mine, lo, hi, D, net='net', bits=bits, mask_size=(h, w))
+        assert len(res) == B
+        for b in range(B):                                  # prep_metrics-shaped: IoU of every image's masks against its ground truth
+            det = res[b]['detection']
+            truth = image_masks(b)
+            assert res[b]['mask_size'] == (h, w) and det['mask_bits'].shape == (truth.shape[0], W64)
+            assert (det['proto'] is None) == (b >= hi)      # local images keep their prototypes, remote ones carry only the bits
+            masks = parallel.unpack_mask_bits(det['mask_bits'], h, w)
+            assert torch.equal(masks, truth), 'image %d: gathered masks differ' % b
+            gt = truth[:1]
+            inter = masks.view(masks.shape[0], -1) @ gt.view(1, -1).t()
+            iou = inter / (masks.view(masks.shape[0], -1).sum(1, keepdim=True) + gt.sum() - inter)
+            assert abs(float(iou[0, 0]) - 1.0) < 1e-6 and iou.shape == (truth.shape[0], 1)
+        q.put(True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_mask_gather_world2_gloo():
+    """forward_sharded's masks='bits' half on CPU / gloo, world 2, uneven shards: the root ends with a USABLE global batch."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_mask_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True and q.get(timeout=5) is True
+
+
+def test_yolact_replicates_for_data_parallel():
+    """eval.py:661 wraps the net in nn.DataParallel (CustomDataParallel, eval.py:630-634); replicate() makes one shallow copy of the
+    module per device (nn.Module._replicate_for_data_parallel).  No GPU here, so this is the CPU half: the copy carries what
+    forward() needs, shares the plan cache and the Detect object, and owns NO lock that would serialise replicas of different
+    devices (tests/test_gpu_round5.py runs real replicas on the MI355X)."""
+    import threading
+    net = _make_net('yolact_resnet50_config')
+    rep = net._replicate_for_data_parallel()
+    assert type(rep) is type(net) and rep is not net
+    assert rep._plans is net._plans and rep.detect is net.detect and rep._run_locks is net._run_locks
+    a, b = torch.device('cuda', 0), torch.device('cuda', 1)
+    assert rep._run_lock_for(a) is net._run_lock_for(a) and net._run_lock_for(a) is not net._run_lock_for(b)
+    assert isinstance(net._run_lock_for(b), type(threading.Lock()))
+    # a replica whose children were replaced by per-device copies (what replicate() does next) still resolves its structure
+    for name in ('backbone', 'fpn', 'proto_net', 'prediction_layers'):
+        assert name in rep._modules
+    assert rep.mask_dim == net.mask_dim and rep.backbone_selected == net.backbone_selected and rep.cfg is net.cfg
+    wrapped = torch.nn.DataParallel(net)                     # no GPU: DataParallel degrades to calling the module itself
+    assert wrapped.module is net
+    with pytest.raises(RuntimeError, match='must live on the GPU'):
+        wrapped(torch.zeros(1, 3, 64, 64))
+
+
+def test_outlier_guard_needs_an_amplifying_producer_not_just_tiny_columns():
+    """Packed.tiny_columns (round-4 advisor, medium): a layer leaves the fp16x2 tiles only when a tiny filter column sits on a channel
+    that its PRODUCER amplifies — the BN-folded outlier signature the stress test plants — and no longer on tiny columns alone, which
+    is also what dead (weight-decayed) input channels of real checkpoints look like.  CPU plans, no launches."""
+    import warnings
+    from test_gpu_batch_parity import _plant_outlier_channels
+    from yolact_amd.engine import Plan
+    from yolact_amd.utils.synth import synth_state_dict
+    net = _make_net('yolact_resnet50_config')
+    sd = synth_state_dict([(k, tuple(v.shape)) for k, v in net.state_dict().items()], seed=0, conf_gain=0.04)
+    old = os.environ.get('YOLACT_AMD_SPLIT')
+    os.environ['YOLACT_AMD_SPLIT'] = '2'
+    try:
+        def wide_layers(state):
+            net.load_state_dict_compat(state)
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter('always')
+                plan = Plan(net, 2, 550, 550, torch.device('cpu'))
+            return plan.wide_layers, [x for x in w if 'OUTLIER' in str(x.message)]
+        clean, warned = wide_layers(sd)
+        assert clean == [] and not warned
+        planted, _ = _plant_outlier_channels({k: v.clone() for k, v in sd.items()}, 12)
+        wide, warned = wide_layers(planted)
+        assert len(wide) >= 10 and any(n.startswith('fpn.lat') for n in wide) and 'proto.2' in wide
+        assert len(warned) == 1 and 'layer1.1.conv1' in str(warned[0].message)  # the demotion is SAID, once per plan
+        dead = {k: v.clone() for k, v in sd.items()}
+        for key in ('backbone.layers.1.1.conv1.weight', 'fpn.lat_layers.1.weight', 'proto_net.2.weight', 'backbone.layers.2.3.conv2.weight'):
+            dead[key][:, [3, 17, 40]] *= 2.0 ** -16                              # dead input channels: tiny columns, ordinary producers
+        wide, warned = wide_layers(dead)
+        assert wide == [] and not warned
+    finally:
+        if old is None:
+            os.environ.pop('YOLACT_AMD_SPLIT', None)
+        else:
+            os.environ['YOLACT_AMD_SPLIT'] = old

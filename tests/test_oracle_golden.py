@@ -3,7 +3,7 @@ by oracle/make_golden.py from /root/reference).  CPU only."""
 import pytest
 import torch
 
-from helpers import ALL_CASES, check_digest, load_golden, match_detections, oracle_run, unpack_masks
+from helpers import ALL_CASES, NOMASK_CASE, check_digest, load_golden, match_detections, oracle_run, unpack_masks
 
 
 @pytest.mark.parametrize('name', ALL_CASES)
@@ -75,3 +75,29 @@ def test_cross_class_case_is_the_references_cc_fast_nms():
     for b in range(meta['B']):
         assert cfg.max_num_detections < meta['n'][b] <= cfg.nms_top_k
         assert dets[b]['score'].shape[0] == meta['n'][b]
+
+
+def test_detect_only_mode_matches_reference():
+    """r50_nomask: the reference run with cfg.eval_mask_branch = False (what eval.py --detect sets, eval.py:1067-1068): the heads
+    return ZERO coefficients (yolact.py:172-175), no prototypes are computed (:579-580), the detection dicts carry no 'proto'
+    (detection.py:73-74) and postprocess returns classes / scores / integer boxes with the coefficient rows as its 4th value
+    (output_utils.py:58,97-122).  Pins that branch of the oracle."""
+    from oracle import yolact_oracle as O
+    meta, arrays, cfg, sd, raw, dets = oracle_run(NOMASK_CASE)
+    assert meta['eval_mask_branch'] is False and cfg.eval_mask_branch is False
+    assert raw['proto'] is None and 'dg_proto' not in meta
+    for k, t in raw['stages'].items():
+        check_digest(t.permute(0, 2, 3, 1), meta, arrays, k, rtol=2e-5, atol=2e-5)
+    for k in ('loc', 'conf', 'priors'):
+        check_digest(raw[k], meta, arrays, k, rtol=2e-5, atol=2e-5)
+    assert meta['dg_mask']['abssum'] == 0.0 and float(raw['mask'].abs().sum()) == 0.0
+    w, h = meta['post']
+    for b in range(meta['B']):
+        assert 'proto' not in dets[b]
+        ref = {k: torch.from_numpy(arrays['det%d_%s' % (b, k)]) for k in ('box', 'mask', 'class', 'score')}
+        assert not match_detections(dets[b], ref, score_tol=1e-6, box_tol=1e-6, coef_tol=1e-6)
+        classes, scores, boxes, masks = O.postprocess(dets[b], w, h, cfg, sd)
+        assert torch.equal(classes, torch.from_numpy(arrays['post%d_class' % b]))
+        assert torch.equal(boxes, torch.from_numpy(arrays['post%d_box' % b]))
+        assert torch.allclose(scores, torch.from_numpy(arrays['post%d_score' % b]), atol=1e-6)
+        assert torch.equal(masks, torch.from_numpy(arrays['post%d_maskraw' % b])) and masks.shape == (meta['n'][b], 32)

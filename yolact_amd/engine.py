@@ -140,20 +140,50 @@ class Packed:
         self.scale = scale.to(device).contiguous() if scale is not None else None
         self.bias = shift.to(device).contiguous() if shift is not None else None
 
-    def tiny_columns(self, binades=10):
-        """True when some input channel is weighted >= 2^binades less than the typical one (column maximum over filters and taps
-        against the median column maximum; all-zero padding columns ignored).  That is the signature of a layer whose input
-        carries OUTLIER channels that the filters compensate (BN-folded checkpoints): the typical channels then sit that many
-        binades below the tensor's magnitude bound, and the fp16x2 tiles — ONE power-of-two scale per activation tensor — keep the
-        low piece of a value normal only 15 binades below the bound (tests/test_gpu_batch_parity.py
-        test_outlier_channels_end_to_end_at_batch8: 2^12 outliers 9e-6, 2^14 3e-5, 2^16 1.3e-4 of the head tensors).  Such layers run
-        on the bf16x3 tiles instead (bf16 has the fp32 exponent range: no scale, no dependence on the bound)."""
-        if getattr(self, '_tiny_cols', None) is None:
-            w = self._wp_host[:self.Cout, :self.kh * self.kw * self.Cin].abs().float().cpu()
-            col = w.view(self.Cout, self.kh * self.kw, self.Cin).amax(dim=(0, 1))
-            nz = col[col > 0]
-            self._tiny_cols = bool(nz.numel() > 8 and (nz.min() * float(2 ** binades) < nz.median()).item())
-        return self._tiny_cols
+    def tiny_columns(self, binades=10, in_gain=None):
+        """True when this layer looks like the CONSUMER OF COMPENSATED OUTLIER CHANNELS: some input channel is weighted >= 2^binades
+        less than the typical one (column maximum over filters and taps against the median column maximum; all-zero padding columns
+        ignored) AND — `in_gain`, the per-channel gain of the launches that PRODUCE the input tensor (Packed.out_gain, carried on
+        engine.T) — that very channel is amplified by its producer >= 2^(binades - 4) over the typical channel.  Both halves are the
+        signature of a BN-folded checkpoint with outlier channels (a huge gamma / sigma on the producer, the inverse folded into the
+        consumer's filters): the typical channels then sit that many binades below the tensor's magnitude bound, and the fp16x2
+        tiles — ONE power-of-two scale per activation tensor — keep the low piece of a value normal only 15 binades below the bound
+        (tests/test_gpu_batch_parity.py test_outlier_channels_end_to_end_at_batch8: 2^12 outliers 9e-6, 2^14 3e-5, 2^16
+        1.3e-4 of the head tensors).  Such layers run on the bf16x3 tiles instead (bf16 has the fp32 exponent range: no scale, no
+        dependence on the bound).
+        Tiny columns ALONE are not enough (round-4 advisor): weight decay drives the filters of DEAD input channels to zero in real
+        checkpoints — same column signature, ordinary activations, no precision problem — and demoting those layers would silently
+        cost them the fp16x2 tiles, Winograd and every fusion.  Without producer information (in_gain None) the weights-only test is
+        kept, conservatively."""
+        w = self._wp_host[:self.Cout, :self.kh * self.kw * self.Cin].abs().float().cpu()
+        col = w.view(self.Cout, self.kh * self.kw, self.Cin).amax(dim=(0, 1))
+        nzm = col > 0
+        if int(nzm.sum()) <= 8:
+            return False
+        tiny = nzm & (col * float(2 ** binades) < col[nzm].median())
+        if not bool(tiny.any()):
+            return False
+        if in_gain is None:
+            return True
+        g = in_gain.detach().float().cpu().flatten()
+        if g.numel() < self.Cin:                                     # (channel padding of the consumer: padded channels carry no data)
+            g = torch.nn.functional.pad(g, (0, self.Cin - g.numel()))
+        g = g[:self.Cin]
+        pos = g[g > 0]
+        if pos.numel() == 0:
+            return True
+        return bool((tiny & (g >= pos.median() * float(2 ** max(binades - 4, 1)))).any())
+
+    def out_gain(self):
+        """[Cout] per-output-channel gain of this layer: max|w[n, :]| x |folded BN scale[n]| (1 without BN) — how strongly the launch
+        amplifies each channel it writes.  Consumers compare it across channels (tiny_columns): an outlier channel of a BN-folded
+        checkpoint shows up as a gain far above the median."""
+        if getattr(self, '_out_gain', None) is None:
+            g = self._wp_host[:self.Cout].abs().amax(dim=1).float().cpu()
+            if self.scale is not None:
+                g = g * self.scale.detach().abs().float().cpu()
+            self._out_gain = g
+        return self._out_gain
 
     def w3(self):
         """[3][CoutPad][Kpad] bf16 planes of the same filters for the bf16x3 tiles (built on first use)."""
@@ -246,11 +276,12 @@ def pack_module(conv: nn.Conv2d, bn=None, device=None, cin_pad=None) -> Packed:
 
 class T:
     """An NHWC activation living in an arena buffer."""
-    __slots__ = ('buf', 'B', 'H', 'W', 'C', 'slot')
+    __slots__ = ('buf', 'B', 'H', 'W', 'C', 'slot', 'gain')
 
-    def __init__(self, buf, B, H, W, C, slot=None):
+    def __init__(self, buf, B, H, W, C, slot=None, gain=None):
         self.buf, self.B, self.H, self.W, self.C = buf, B, H, W, C
         self.slot = slot          # index of the tensor's magnitude bound in Plan.amax (fp16x2 tiles), None: not tracked
+        self.gain = gain          # [C] per-channel gain of the launches that write this tensor (Packed.out_gain; host tensor), None: unknown
 
     @property
     def ptr(self):
@@ -346,6 +377,7 @@ class Plan:
         self.om_pad = os.environ.get('YOLACT_AMD_OM_PAD', '1') == '1'
         self.om_interleave = os.environ.get('YOLACT_AMD_OM_INTERLEAVE', '1') == '1'
         self.wide_ops = set()
+        self.wide_layers = []       # names of the layers the outlier-channel guard took off the fp16x2 tiles (warned about once, below)
         self._sk_ws = {}
         self.down_on_side_stream = os.environ.get('YOLACT_AMD_DOWN_STREAM', 'B') == 'B'      # measured +1 %
         self.wino_alt, self._wino_packed, self._wino_ws = {}, {}, {}
@@ -355,6 +387,13 @@ class Plan:
         self.param_stamp = None
         self.tune_misses = 0
         self._build()
+        if self.wide_layers:
+            import warnings
+            warnings.warn('yolact_amd: %d layer(s) consume compensated OUTLIER channels (tiny filter columns on channels their producer '
+                          'amplifies, Packed.tiny_columns) and run on bf16x3 / exact-fp32 tiles instead of fp16x2, without Winograd and '
+                          'the fp16x2-only fusions: %s.  YOLACT_AMD_WIDE_GUARD=0 keeps fp16x2 (at reduced accuracy for such checkpoints).'
+                          % (len(self.wide_layers), ', '.join(self.wide_layers[:12]) + (' ...' if len(self.wide_layers) > 12 else '')),
+                          RuntimeWarning, stacklevel=2)
         self._bind_wino_workspaces()
         self.sections = [None if op[0] in ('record', 'wait', 'detect', 'nop') else self.section_of(op[2]) for op in self.ops]
 
@@ -368,8 +407,8 @@ class Plan:
             return self.arena_b
         return self.arena
 
-    def _new(self, B, H, W, C, slot=None) -> T:
-        return T(self._arena().alloc(B * H * W * C), B, H, W, C, slot)
+    def _new(self, B, H, W, C, slot=None, gain=None) -> T:
+        return T(self._arena().alloc(B * H * W * C), B, H, W, C, slot, gain)
 
     def _slot(self):
         """A fresh magnitude-bound slot (index into self.amax)."""
@@ -410,7 +449,15 @@ class Plan:
         d.cin_alg = pk.cin_alg
         d.cout_alg = pk.cout_alg
         # fp16x2 plans: a layer whose filters give away outlier input channels runs on the bf16x3 tiles (Packed.tiny_columns)
-        wide = self.h2 and self.wide_guard and pk.Cin % 32 == 0 and pk.tiny_columns()
+        wide = self.h2 and self.wide_guard and pk.Cin % 32 == 0 and pk.tiny_columns(in_gain=x.gain)
+        pk.wide = wide
+        if wide:
+            self.wide_layers.append(name)
+        # the gain this launch gives each channel it writes; a shortcut / FPN sum inherits the larger of its two sources
+        og = pk.out_gain()
+        if res is not None and res.gain is not None and res.gain.numel() == og.numel():
+            og = torch.maximum(og, res.gain)
+        self.last_out_gain = og
         if (self.split or wide) and dcn_offmask is None:
             d.w_x3 = pk.w3().data_ptr()
         yslot = self._slot()                    # fp16x2 plans: every launch records the magnitude bound of what it writes
@@ -429,6 +476,7 @@ class Plan:
         if segs is None:
             y = out if out is not None else self._new(x.B, Ho, Wo, pk.Cout)
             y.slot = yslot
+            y.gain = og
             d.nseg = 1
             d.seg[0] = L.ConvSeg(0, pk.Cout, act, pk.Cout, Ho * Wo * pk.Cout, y.ptr)
         else:
@@ -645,6 +693,7 @@ class Plan:
                 # one bound PER HALF (segment k raises slot k of consecutive slots): the two halves are different tensors — a large
                 # proto_net[0] channel must not coarsen the fp16x2 scale of the head's input (round-4 outlier stress test)
                 u.slot, t0.slot = self.last_yslot, self.last_yslot + 1
+                u.gain, t0.gain = self.last_out_gain[:cu.out_channels], self.last_out_gain[cu.out_channels:]
                 self._merged_p3 = t0
             else:
                 for k, pk in enumerate(up_pk):
@@ -728,7 +777,7 @@ class Plan:
                     # conv3x3(256 -> 256) + ReLU -> conv1x1(256 -> <= 32): when the 3x3 runs as F(4x4,3x3) its output transform can
                     # multiply each tile by the 1x1's filters and write the prototypes directly (ymi_wino_desc.proj_*)
                     if (self.h2 and prev_conv_op is not None and prev_conv_op in self.wino_alt and (pk.kh, pk.kw, pk.stride, pk.pad) == (1, 1, 1, 0)
-                            and pk.Cin == 256 and pk.Cout <= 32 and pk.Cout % 4 == 0 and a <= L.ACT_LEAKY01 and not pk.tiny_columns()
+                            and pk.Cin == 256 and pk.Cout <= 32 and pk.Cout % 4 == 0 and a <= L.ACT_LEAKY01 and not getattr(pk, 'wide', False)
                             and os.environ.get('YOLACT_AMD_WINO_PROJ', '1') == '1'):
                         self.wino_proj = (prev_conv_op, len(self.ops) - 1)
                 else:
@@ -743,7 +792,7 @@ class Plan:
                 prev_conv_op = None
                 s = int(m.scale_factor)
                 has_relu = (i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU))
-                y = self._new(t.B, t.H * s, t.W * s, t.C, slot=t.slot)   # convex interpolation: the input's bound holds
+                y = self._new(t.B, t.H * s, t.W * s, t.C, slot=t.slot, gain=t.gain)   # convex interpolation: the input's bound (and gain) holds
                 self.call(lib.ymi_bilinear_nhwc_f32, t.ptr, y.ptr, t.B, t.H, t.W, t.C, y.H, y.W,
                           C.c_float(1.0 / s), C.c_float(1.0 / s), 1 if has_relu else 0, name='proto.interp')
                 if s == 2 and os.environ.get('YOLACT_AMD_FUSED_UPSAMPLE', '1') == '1':
@@ -765,7 +814,7 @@ class Plan:
             B, H, W = self.B, self.H, self.W
             Hs, Ws = out_size(H, 7, 2, 3), out_size(W, 7, 2, 3)
             Hp, Wp = out_size(Hs, 3, 2, 1), out_size(Ws, 3, 2, 1)
-            x = self._new(B, Hp, Wp, 64, slot=self._slot())
+            x = self._new(B, Hp, Wp, 64, slot=self._slot(), gain=pk0.out_gain())
             planes, sc2, winv = pk0.h2()
             sd = L.StemDesc()
             sd.y, sd.B, sd.H, sd.W, sd.cout_pad, sd.kpad = x.ptr, B, H, W, pk0.CoutPad, pk0.Kpad
@@ -780,7 +829,7 @@ class Plan:
             stem = self.conv('stem', x4, pk0, act=L.ACT_RELU)
             ar.free(x4)
             Hp, Wp = out_size(stem.H, 3, 2, 1), out_size(stem.W, 3, 2, 1)
-            x = self._new(stem.B, Hp, Wp, stem.C, slot=stem.slot)        # max-pooling cannot raise the magnitude bound
+            x = self._new(stem.B, Hp, Wp, stem.C, slot=stem.slot, gain=stem.gain)        # max-pooling cannot raise the magnitude bound
             self.call(lib.ymi_maxpool3x3s2_nhwc_f32, stem.ptr, x.ptr, stem.B, stem.H, stem.W, stem.C, Hp, Wp, name='maxpool')
             ar.free(stem)
         outs = []
@@ -878,7 +927,7 @@ class Plan:
                 self._done_event = torch.cuda.Event()
             self._done_event.record(torch.cuda.current_stream(self.device))
 
-    def run(self, x: torch.Tensor, detect=None, timer=None):
+    def run(self, x: torch.Tensor, detect=None, timer=None, skip_proto=False):
         """x [B,3,H,W] fp32 contiguous on the plan's device. Returns (proto, detect_result): the fresh proto tensor
         and whatever `detect(stream_ptr)` returned (None without a callback).  loc/conf/coef are the plan's persistent
         head buffers.  `detect` is invoked at the point of the op list where every head has been written; its
@@ -886,7 +935,7 @@ class Plan:
         tensors are allocated by the caller's ambient stream — they are only consumed after the final join.
         `timer`: the reference's utils.timer module (or None): the op ranges are bracketed with its section names.
         The arena, the head buffers and the Winograd workspaces are shared by every run of this plan: callers serialise
-        run() on the host (Yolact._run_lock) and consecutive runs are ordered on the device by an event, so two user
+        run() on the host (Yolact._run_lock_for(device)) and consecutive runs are ordered on the device by an event, so two user
         streams cannot overlap on the same buffers."""
         lib = self.lib
         cur = torch.cuda.current_stream(self.device)
@@ -896,10 +945,14 @@ class Plan:
         sa = C.c_void_p(cur.cuda_stream)
         two = self.two_streams and self.overlap
         sb = C.c_void_p(self.stream_b.cuda_stream) if two else sa
-        proto = torch.empty(self.proto_shape, dtype=torch.float32, device=self.device)
-        self.proto_patch.seg[0].ptr = proto.data_ptr()
-        if self.proto_patch_wino is not None:
-            self.proto_patch_wino.proj_y = proto.data_ptr()
+        # skip_proto: cfg.eval_mask_branch is False at call time (eval.py --detect, eval.py:1067-1068): the reference computes no
+        # prototypes (yolact.py:579-580) — the protonet's launches are left out of the op loop and None is returned for them
+        proto = None
+        if not skip_proto:
+            proto = torch.empty(self.proto_shape, dtype=torch.float32, device=self.device)
+            self.proto_patch.seg[0].ptr = proto.data_ptr()
+            if self.proto_patch_wino is not None:
+                self.proto_patch_wino.proj_y = proto.data_ptr()
         if self.h2:                  # magnitude bounds are re-derived by every run (on the caller's stream, ahead of every op)
             self.amax[:self._nslots * AMAX_SLOT_FLOATS].zero_()
         # only a module with the reference's timer API (utils/timer.py: start / stop / env) is driven
@@ -907,14 +960,14 @@ class Plan:
             timer = None
         self._sec = None
         try:
-            det = self._dispatch(x, cur, sa, sb, two, detect, timer)
+            det = self._dispatch(x, cur, sa, sb, two, detect, timer, skip_proto)
         finally:
             if timer is not None and self._sec is not None:   # a failed launch must not leave a reference timer running
                 timer.stop(self._sec)
         self.mark_done()
         return proto, det
 
-    def _dispatch(self, x, cur, sa, sb, two, detect, timer):
+    def _dispatch(self, x, cur, sa, sb, two, detect, timer, skip_proto=False):
         """The flat op loop of run(): C-ABI launches on the two streams, event records / waits, the Detect callback."""
         lib = self.lib
         det = None
@@ -934,7 +987,7 @@ class Plan:
                     rc = lib.ymi_nchw_to_nhwc4_amax_f32(x.data_ptr(), a[1], a[2], a[3], a[4], a[5], self.in_amax[2], s)
                 else:
                     rc = lib.ymi_nchw_to_nhwc4_f32(x.data_ptr(), a[1], a[2], a[3], a[4], a[5], s)
-            elif fn == 'nop':
+            elif fn == 'nop' or (skip_proto and nsec == 'proto'):
                 continue
             elif fn == 'stem':
                 args.x = x.data_ptr()
@@ -1071,6 +1124,20 @@ class Plan:
                 cd.z, cd.ldz, cd.z_amax, cd.act_b = d1.seg[0].ptr, d1.seg[0].row_stride, d1.y_amax, d1.seg[0].act
                 cd.w_b_h2, cd.scale_b_h2, cd.bias_b = d1.w_h2, d1.scale_h2, d1.bias
                 name = n3 + '+' + n1
+            if pair:
+                # aliasing contract of ymi_pointwise_chain_f32 (include/yolact_amd.h): z must not overlap y or the residual, and may
+                # alias the INPUT x only exactly in place (same base, same row stride): every block reads x tile T before it writes
+                # z tile T and nobody else touches those rows.  The arena normally hands conv1's output the buffer conv3's input
+                # just freed, which is that case; any other overlap (a z that landed in a buffer of another layout) is not fused.
+                def span(ptr, ld):
+                    return (int(ptr), int(ptr) + 4 * M * int(ld))
+
+                def overlap(a, b):
+                    return a[0] < b[1] and b[0] < a[1]
+                zs, xs = span(cd.z, cd.ldz), span(cd.x, cd.ldx)
+                in_place = int(cd.z) == int(cd.x) and cd.ldz == cd.ldx
+                if overlap(zs, span(cd.y, cd.ldy)) or overlap(zs, span(cd.res, cd.res_ld)) or (overlap(zs, xs) and not in_place):
+                    continue
             cptr = C.pointer(cd)
             key = ('chain' if pair else 'chain1') + str((d3.B, d3.Ho, d3.Wo)) + self.mode_key
             ent = disk.get(key)
@@ -1331,8 +1398,20 @@ class Plan:
                         wd.proj_w_h2, wd.proj_scale_h2, wd.proj_bias = pd.w_h2, pd.scale_h2, pd.bias
                         wd.proj_y, wd.proj_y_amax = pd.seg[0].ptr, pd.y_amax
                         wd.proj_cout, wd.proj_ldy, wd.proj_act = pd.Cout, pd.seg[0].row_stride, pd.seg[0].act
-                        self.ops[pidx] = ('nop', None, pname + '[fused into ' + name + ']', pwhere)
-                        self.proto_patch_wino = wd
+                        # proj_y is patched per call (NULL here): validate the fused descriptor with ONE launch into a scratch
+                        # prototype tensor; if the library rejects it the two separate launches stay (round-4 advisor: every other
+                        # fusion is validated before it is installed — an unvalidated one would make every forward raise)
+                        scratch = torch.empty(self.proto_shape, dtype=torch.float32, device=self.device)
+                        wd.proj_y = scratch.data_ptr()
+                        rc = lib.ymi_conv3x3_winograd_f32(C.byref(wd), s)
+                        torch.cuda.synchronize(self.device)
+                        wd.proj_y = None
+                        if rc != 0:
+                            wd.proj_w_h2 = None
+                            self.wino_proj_rejected = rc
+                        else:
+                            self.ops[pidx] = ('nop', None, pname + '[fused into ' + name + ']', pwhere)
+                            self.proto_patch_wino = wd
 
     def conv_flops(self):
         return sum(self.lib.ymi_conv_flops(C.byref(d)) for _, d in self.conv_meta)
@@ -1343,4 +1422,4 @@ class _Borrowed(T):
     __slots__ = ()
 
     def __init__(self, t: T):
-        super().__init__(t.buf, t.B, t.H, t.W, t.C, t.slot)
+        super().__init__(t.buf, t.B, t.H, t.W, t.C, t.slot, t.gain)

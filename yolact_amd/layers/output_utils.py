@@ -36,8 +36,18 @@ def _lowres_masks(det_output, w, h, batch_idx, interpolation_mode, visualize_lin
         if dets['score'].size(0) == 0:
             return None
     classes, boxes, scores, coef = dets['class'], dets['box'], dets['score'], dets['mask']
-    if not (is_lincomb(cfg) and cfg.eval_mask_branch):
+    if not is_lincomb(cfg):
         raise NotImplementedError('only mask_type.lincomb is on the hot path')
+    if not cfg.eval_mask_branch:
+        # output_utils.py:58,97-122 with cfg.eval_mask_branch False (eval.py --detect, eval.py:1067-1068): neither mask branch runs;
+        # classes / scores / integer boxes are returned and the 4th value stays what dets['mask'] holds (the coefficient rows)
+        L.require_cuda(boxes, "dets['box']")
+        with torch.cuda.device(boxes.device):
+            boxes_c = boxes.contiguous().float()
+            boxes_px = torch.empty(boxes_c.shape[0], 4, dtype=torch.int64, device=boxes.device)
+            L.check(L.lib().ymi_boxes_to_pixels(boxes_c.data_ptr(), boxes_px.data_ptr(), int(boxes_c.shape[0]), w, h, L.stream_ptr()),
+                    'ymi_boxes_to_pixels')
+        return classes, scores, boxes_px, None
     if interpolation_mode != 'bilinear':
         raise NotImplementedError("interpolation_mode %r (eval.py always uses 'bilinear')" % interpolation_mode)
     if visualize_lincomb:
@@ -75,6 +85,8 @@ def postprocess(det_output, w, h, batch_idx=0, interpolation_mode='bilinear', vi
     if r is None:
         return [torch.Tensor()] * 4
     classes, scores, boxes_px, masks_lo = r
+    if masks_lo is None:                       # cfg.eval_mask_branch False: boxes only (see _lowres_masks)
+        return classes, scores, boxes_px, det_output[batch_idx]['detection']['mask']
     N, ph, pw = masks_lo.shape
     with torch.cuda.device(masks_lo.device):
         masks = torch.empty(N, h, w, device=masks_lo.device)
@@ -99,6 +111,8 @@ def postprocess_rle(det_output, w, h, batch_idx=0, crop_masks=True, score_thresh
     if r is None:
         return [], [], [], []
     classes, scores, boxes_px, masks_lo = r
+    if masks_lo is None:
+        raise RuntimeError('postprocess_rle: cfg.eval_mask_branch is False (eval.py --detect): there are no masks to encode')
     if fused:
         return classes, scores, boxes_px, rle_encode_lowres(masks_lo, h, w, 0.5)
     N, ph, pw = masks_lo.shape
@@ -115,10 +129,36 @@ def postprocess_bits(det_output, w, h, batch_idx=0, crop_masks=True, score_thres
     that upsamples and thresholds the prototype-resolution masks (the float kernel's arithmetic: every bit equals the pixel
     `postprocess` would have written).  3.8 MB instead of 121 MB per image at 550 x 550; layers.box_utils.mask_iou_bits scores
     them against bit-packed ground truth with popcounts, bit-identical to mask_iou on the float masks.  Empty: ([], [], [], None)."""
+    rec = det_output[batch_idx]
+    dets = rec['detection']
+    if dets is not None and dets.get('proto') is None and 'mask_bits' in dets:
+        # a detection gathered from another rank by Yolact.forward_sharded(masks='bits'): its masks were assembled where its
+        # prototypes live (postprocess_bits_batch) and arrived as bits for the size `mask_size`
+        if tuple(rec.get('mask_size', ())) != (h, w):
+            raise RuntimeError('postprocess_bits: the gathered masks were assembled for (h, w) = %s, not %s'
+                               % (rec.get('mask_size'), (h, w)))
+        if score_threshold > 0:
+            keep = dets['score'] > score_threshold
+            for k in dets:
+                if k != 'proto':
+                    dets[k] = dets[k][keep]
+            if dets['score'].size(0) == 0:
+                return [], [], [], None
+        boxes = dets['box'].contiguous().float()
+        if boxes.is_cuda:
+            with torch.cuda.device(boxes.device):
+                boxes_px = torch.empty(boxes.shape[0], 4, dtype=torch.int64, device=boxes.device)
+                L.check(L.lib().ymi_boxes_to_pixels(boxes.data_ptr(), boxes_px.data_ptr(), int(boxes.shape[0]), w, h, L.stream_ptr()),
+                        'ymi_boxes_to_pixels')
+        else:
+            raise RuntimeError('postprocess_bits: gathered detections must live on the GPU (there is no CPU path)')
+        return dets['class'], dets['score'], boxes_px, dets['mask_bits']
     r = _lowres_masks(det_output, w, h, batch_idx, 'bilinear', False, crop_masks, score_threshold)
     if r is None:
         return [], [], [], None
     classes, scores, boxes_px, masks_lo = r
+    if masks_lo is None:
+        raise RuntimeError('postprocess_bits: cfg.eval_mask_branch is False (eval.py --detect): there are no masks to pack')
     N, ph, pw = masks_lo.shape
     W64 = (h * w + 63) // 64
     with torch.cuda.device(masks_lo.device):
@@ -128,18 +168,32 @@ def postprocess_bits(det_output, w, h, batch_idx=0, crop_masks=True, score_thres
     return classes, scores, boxes_px, bits
 
 
-def postprocess_batch(dev_out, w, h, crop_masks=True):
+def postprocess_batch(dev_out, w, h, crop_masks=True, net=None):
     """postprocess() for a whole batch with NO per-image Python loop and no host synchronisation: the fixed-capacity
     device outputs of `Yolact.forward_device` (count [B], box [B,cap,4], score, cls, coef [B,cap,D], proto [B,ph,pw,D])
     go through ONE lincomb+sigmoid+crop launch and ONE upsample+threshold launch (output_utils.py:69-99 per image in the
     reference).  Returns fixed-capacity tensors: classes [B,cap] i64, scores [B,cap], boxes [B,cap,4] i64 pixels,
     masks [B,cap,h,w] f32 {0,1}, count [B] i32; rows >= count[b] are unspecified.  `masks[b, :count[b]]` equals what
-    postprocess(preds, w, h, batch_idx=b) returns bit for bit (same kernels)."""
+    postprocess(preds, w, h, batch_idx=b) returns bit for bit (same kernels).
+
+    YOLACT++ (cfg.use_maskiou; output_utils.py:79-88, yolact.py:363-375): FastMaskIoUNet runs ONCE over all B * cap cropped
+    prototype-resolution masks (one chain of six launches for the batch instead of one per image; `net` = the model that owns
+    maskiou_net, default dev_out['net']) and 'scores' follows the reference's structure: [box scores, box scores * maskiou]
+    (two [B,cap] tensors) with cfg.rescore_mask and not cfg.rescore_bbox, the product alone with rescore_bbox (what eval.py's
+    prep_display forces, eval.py:147-152).  Row (b, i < count[b]) equals the per-image postprocess() bit for bit.
+
+    cfg.eval_mask_branch False (eval.py --detect): 'masks' is None, boxes / classes / scores as usual (output_utils.py:58,97-122)."""
     cfg = active_cfg()
-    if not (is_lincomb(cfg) and cfg.eval_mask_branch) or act_name(cfg.mask_proto_mask_activation) != 'sigmoid':
+    if not is_lincomb(cfg) or act_name(cfg.mask_proto_mask_activation) != 'sigmoid':
         raise NotImplementedError('only mask_type.lincomb with sigmoid masks is on the hot path')
-    if getattr(cfg, 'use_maskiou', False):
-        raise NotImplementedError('YOLACT++ mask re-scoring runs per image: use postprocess()')
+    if not cfg.eval_mask_branch:
+        box, count = dev_out['box'], dev_out['count']
+        L.require_cuda(box, "dev_out['box']")
+        B, cap = box.shape[0], box.shape[1]
+        with torch.cuda.device(box.device):
+            boxes_px = torch.empty(B, cap, 4, dtype=torch.int64, device=box.device)
+            L.check(L.lib().ymi_boxes_to_pixels(box.data_ptr(), boxes_px.data_ptr(), B * cap, w, h, L.stream_ptr()), 'ymi_boxes_to_pixels')
+        return {'classes': dev_out['cls'], 'scores': dev_out['score'], 'boxes': boxes_px, 'masks': None, 'count': count}
     proto, coef, box, count = dev_out['proto'], dev_out['coef'], dev_out['box'], dev_out['count']
     L.require_cuda(proto, "dev_out['proto']")
     B, ph, pw, D = proto.shape
@@ -148,16 +202,58 @@ def postprocess_batch(dev_out, w, h, crop_masks=True):
     lib = L.lib()
     with torch.cuda.device(dev):
         s = L.stream_ptr()
-        masks_lo = torch.empty(B, cap, ph, pw, device=dev)
+        use_miou = bool(getattr(cfg, 'use_maskiou', False))
+        # (YOLACT++: rows past count[b] also go through FastMaskIoUNet, so they must hold numbers, not uninitialised memory)
+        masks_lo = (torch.zeros if use_miou else torch.empty)(B, cap, ph, pw, device=dev)
         L.check(lib.ymi_lincomb_crop_batch_f32(proto.data_ptr(), coef.data_ptr(), box.data_ptr(), count.data_ptr(),
                                                masks_lo.data_ptr(), B, cap, ph, pw, D, 1 if crop_masks else 0, s),
                 'ymi_lincomb_crop_batch_f32')
+        scores = dev_out['score']
+        if use_miou:
+            net = net if net is not None else dev_out.get('net')
+            if net is None:
+                raise RuntimeError('postprocess_batch: cfg.use_maskiou needs the model that owns maskiou_net (net=...)')
+            miou = net.maskiou_forward(masks_lo.view(B * cap, ph, pw)).view(B, cap, -1)            # [B, cap, 80]
+            miou = torch.gather(miou, 2, dev_out['cls'].clamp(0, miou.shape[2] - 1).unsqueeze(-1)).squeeze(-1)
+            if cfg.rescore_mask:
+                scores = scores * miou if cfg.rescore_bbox else [scores, scores * miou]
         masks = torch.empty(B, cap, h, w, device=dev)
         L.check(lib.ymi_mask_upsample_batch_f32(masks_lo.data_ptr(), count.data_ptr(), masks.data_ptr(), B, cap, ph, pw, h,
                                                 w, C.c_float(0.5), s), 'ymi_mask_upsample_batch_f32')
         boxes_px = torch.empty(B, cap, 4, dtype=torch.int64, device=dev)
         L.check(lib.ymi_boxes_to_pixels(box.data_ptr(), boxes_px.data_ptr(), B * cap, w, h, s), 'ymi_boxes_to_pixels')
-    return {'classes': dev_out['cls'], 'scores': dev_out['score'], 'boxes': boxes_px, 'masks': masks, 'count': count}
+    return {'classes': dev_out['cls'], 'scores': scores, 'boxes': boxes_px, 'masks': masks, 'count': count}
+
+
+def postprocess_bits_batch(dev_out, w, h, crop_masks=True):
+    """postprocess_bits for a whole fixed-capacity batch (the data-parallel mask path: yolact_amd.parallel / Yolact.forward_sharded
+    with masks='bits'): ONE lincomb + sigmoid + crop launch and ONE upsample + threshold-into-bits launch for all B * cap
+    detections.  Returns {'classes', 'scores', 'boxes' [B,cap,4] i64, 'bits' int64 [B, cap, ceil(h*w/64)], 'count', 'size': (h, w)};
+    bits[b, i < count[b]] equals what postprocess_bits(preds, w, h, batch_idx=b) returns, rows past count[b] are all-zero words.
+    3.8 MB per image at 550 x 550 and cap 100 instead of the 121 MB of float masks — the form in which masks travel to the
+    gather root ("masks are assembled where the prototypes live and only gathered if the caller needs them")."""
+    cfg = active_cfg()
+    if not (is_lincomb(cfg) and cfg.eval_mask_branch) or act_name(cfg.mask_proto_mask_activation) != 'sigmoid':
+        raise NotImplementedError('only mask_type.lincomb with sigmoid masks (and cfg.eval_mask_branch) has masks to pack')
+    proto, coef, box, count = dev_out['proto'], dev_out['coef'], dev_out['box'], dev_out['count']
+    L.require_cuda(proto, "dev_out['proto']")
+    B, ph, pw, D = proto.shape
+    cap = coef.shape[1]
+    dev = proto.device
+    lib = L.lib()
+    W64 = (h * w + 63) // 64
+    with torch.cuda.device(dev):
+        s = L.stream_ptr()
+        masks_lo = torch.zeros(B, cap, ph, pw, device=dev)          # rows past count[b] stay zero -> all-zero bit rows
+        L.check(lib.ymi_lincomb_crop_batch_f32(proto.data_ptr(), coef.data_ptr(), box.data_ptr(), count.data_ptr(),
+                                               masks_lo.data_ptr(), B, cap, ph, pw, D, 1 if crop_masks else 0, s),
+                'ymi_lincomb_crop_batch_f32')
+        bits = torch.empty(B, cap, W64, dtype=torch.int64, device=dev)
+        L.check(lib.ymi_mask_upsample_bits(masks_lo.data_ptr(), B * cap, ph, pw, h, w, C.c_float(0.5), bits.data_ptr(), s),
+                'ymi_mask_upsample_bits')
+        boxes_px = torch.empty(B, cap, 4, dtype=torch.int64, device=dev)
+        L.check(lib.ymi_boxes_to_pixels(box.data_ptr(), boxes_px.data_ptr(), B * cap, w, h, s), 'ymi_boxes_to_pixels')
+    return {'classes': dev_out['cls'], 'scores': dev_out['score'], 'boxes': boxes_px, 'bits': bits, 'count': count, 'size': (h, w)}
 
 
 MEANS = (103.94, 116.78, 123.68)     # data/config.py:28-29, BGR order

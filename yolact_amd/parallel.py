@@ -6,6 +6,13 @@ The reference's only multi-GPU inference path is nn.DataParallel batch splitting
 no collective inside the network; weights are replicated by each rank loading the same checkpoint.
 Record per image: count + cap x (box 4, score 1, class 1, coef D) fp32  (15.2 KB at cap=100, D=32) — latency-bound,
 so a single direct gather (every sender on its own xGMI link to the root) is the right collective, not a ring.
+The count and the class ids travel AS fp32 inside the record (one dtype, one buffer, written by the Detect kernel itself):
+exact for every integer below 2^24, and a count is <= 200, a class id <= 80.
+
+Masks (round 5).  The prototypes stay on the rank that computed them; when the caller on the gather root needs the masks of the
+WHOLE batch (eval.py's prep_metrics / COCO dump over a global batch), every owner assembles its images' masks where the
+prototypes live and ships them as BITS (output_utils.postprocess_bits_batch: int64 [cap, ceil(h*w/64)] per image, 3.8 MB at
+550 x 550) through a second fixed-capacity gather — `sharded_forward(..., masks_fn=...)`, `Yolact.forward_sharded(masks='bits')`.
 """
 from __future__ import annotations
 
@@ -48,17 +55,6 @@ def unpack_records(rec: torch.Tensor, D: int) -> List[Optional[Dict[str, torch.T
         r = body[b, :n]
         out.append({'box': r[:, :4], 'score': r[:, 4], 'class': r[:, 5].to(torch.int64), 'mask': r[:, 6:]})
     return out
-
-
-def pad_records(rec: torch.Tensor, rows: int) -> torch.Tensor:
-    """Pad a rank's [b, L] records to `rows` rows with count-0 records (an uneven last shard, e.g. 13 images over 4
-    ranks = 4,4,4,1): every rank must contribute the same number of bytes to the gather."""
-    if rec.shape[0] == rows:
-        return rec
-    if rec.shape[0] > rows:
-        raise ValueError('shard has %d records, expected at most %d' % (rec.shape[0], rows))
-    pad = torch.zeros(rows - rec.shape[0], rec.shape[1], dtype=rec.dtype, device=rec.device)
-    return torch.cat([rec, pad], 0)
 
 
 class RecordGatherer:
@@ -114,12 +110,18 @@ def pin_rank_affinity(local_rank: int, local_world: int):
     return mine
 
 
-def sharded_forward(forward_device, x_global: torch.Tensor, D: int, gatherer: Optional[RecordGatherer] = None, dst: int = 0):
+def sharded_forward(forward_device, x_global: torch.Tensor, D: int, gatherer: Optional[RecordGatherer] = None, dst: int = 0,
+                    masks_fn=None, mask_gatherer: Optional[RecordGatherer] = None):
     """Data-parallel forward of one GLOBAL batch (every rank holds the same x_global, or at least its own shard of it):
     rank r runs `forward_device` (Yolact.forward_device: forward + Detect, no host sync) on images shard_range(B, r, world)
     and the fixed-size detection records of all images are gathered on `dst` with the ONE collective of the path.  Returns
     (records [B, L] on dst | None elsewhere, this rank's device outputs or None for an empty shard).  The prototypes stay on
-    the rank that computed them (masks are assembled where the prototypes live)."""
+    the rank that computed them (masks are assembled where the prototypes live).
+
+    masks_fn (optional): `masks_fn(device_outputs) -> int64 [b, cap, W64]` — the bit-packed masks of this rank's images
+    (output_utils.postprocess_bits_batch(...)['bits']; an empty shard calls `masks_fn(None)` for a [0, cap, W64] tensor).  They ride
+    a SECOND fixed-capacity gather (same collective, same padding rule, persistent buffers of `mask_gatherer`) and the function
+    returns a third value: the gathered bits [B, cap, W64] on dst, None elsewhere."""
     world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
     rank = dist.get_rank() if world > 1 else 0
     B = int(x_global.shape[0])
@@ -133,23 +135,53 @@ def sharded_forward(forward_device, x_global: torch.Tensor, D: int, gatherer: Op
         rec = torch.zeros(0, L_, dtype=torch.float32, device=x_global.device)
     g = gatherer or RecordGatherer(dst)
     allrec = g(rec, rows, n_items=B, force_collective=world > 1)
-    return allrec, out
+    if masks_fn is None:
+        return allrec, out
+    bits = masks_fn(out)                                       # [b, cap, W64] int64
+    if bits.dtype != torch.int64 or bits.dim() != 3 or bits.shape[0] != hi - lo:
+        raise ValueError('masks_fn must return int64 [%d, cap, W64] bit masks, got %s %s' % (hi - lo, bits.dtype, tuple(bits.shape)))
+    cap, W64 = int(bits.shape[1]), int(bits.shape[2])
+    mg = mask_gatherer or RecordGatherer(dst)
+    allbits = mg(bits.reshape(hi - lo, cap * W64), rows, n_items=B, force_collective=world > 1)
+    return allrec, out, (allbits.view(-1, cap, W64) if allbits is not None else None)
 
 
-def assemble_sharded(rec: torch.Tensor, mine, lo: int, hi: int, D: int, net=None):
+def assemble_sharded(rec: torch.Tensor, mine, lo: int, hi: int, D: int, net=None, bits: Optional[torch.Tensor] = None,
+                     mask_size=None):
     """dst side of Yolact.forward_sharded: the gathered records [B, L] -> the list the reference's Detect returns for the global
     batch ({'detection': {...} | None, 'net': net} per image).  `rec` is first DETACHED from the gatherer's persistent receive
     buffer (clone; 15 KB per image): unpack_records slices without copying, and the next step overwrites that buffer in place
     while callers may still hold — or asynchronously postprocess — this step's results.  `proto` is this rank's own prototype
     tensor for images lo .. hi-1 and None for detections computed elsewhere (masks are assembled where the prototypes live,
-    SURVEY 8(e); postprocess() refuses a None with a clear error)."""
+    SURVEY 8(e); postprocess() refuses a None with a clear error).
+
+    bits [B, cap, W64] (the second gather of sharded_forward) + mask_size (h, w): EVERY detection also carries
+    `mask_bits` int64 [n, W64] — its final binary masks at (h, w), assembled by its owner — and the per-image record carries
+    `mask_size`; output_utils.postprocess_bits(out, w, h, batch_idx=b) then works for every image of the global batch, local or
+    remote, and layers.box_utils.mask_iou_bits scores them against bit-packed ground truth."""
     rec = rec.clone()
+    if bits is not None:
+        bits = bits.clone()                       # detached from the gatherer's persistent receive buffer, like the records
     out = []
     for b, det in enumerate(unpack_records(rec, D)):
         if det is not None:
             det['proto'] = mine['proto'][b - lo] if (mine is not None and lo <= b < hi) else None
-        out.append({'detection': det, 'net': net})
+            if bits is not None:
+                det['mask_bits'] = bits[b, :det['score'].shape[0]]
+        r = {'detection': det, 'net': net}
+        if bits is not None:
+            r['mask_size'] = tuple(mask_size)
+        out.append(r)
     return out
+
+
+def unpack_mask_bits(bits: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    """int64 [n, ceil(h*w/64)] bit masks (bit i of word j = pixel 64 j + i) -> float32 {0,1} masks [n, h, w]: the layout eval.py's
+    prep_metrics / prep_display consume (torch ops, any device) — for callers that need the float form of a gathered mask."""
+    n = bits.shape[0]
+    shifts = torch.arange(64, device=bits.device, dtype=torch.int64)
+    flat = ((bits.unsqueeze(-1) >> shifts) & 1).reshape(n, -1)[:, :h * w]
+    return flat.to(torch.float32).view(n, h, w)
 
 
 def _cap_of(forward_device):
@@ -187,11 +219,12 @@ def gather_records(rec: torch.Tensor, dst: int = 0, rows_per_rank: Optional[int]
         if int(t[0]) != -int(t[1]):
             raise RuntimeError('gather_records: ranks hold different numbers of records (%d..%d); pass rows_per_rank'
                                % (-int(t[1]), int(t[0])))
-    rec = pad_records(rec.contiguous(), rows)
-    if dist.get_rank() == dst:
-        bufs = [torch.empty_like(rec) for _ in range(world)]
-        dist.gather(rec, bufs, dst=dst)
-        out = torch.cat(bufs, 0)
-        return out if n_items is None else out[:n_items]
-    dist.gather(rec, None, dst=dst)
-    return None
+    # one code path for the collective: the persistent-buffer gatherer (round 4 kept an allocating empty_like x world + cat here)
+    g = _default_gatherers.get(dst)
+    if g is None:
+        g = _default_gatherers[dst] = RecordGatherer(dst)
+    out = g(rec.contiguous(), rows, n_items=n_items, force_collective=True)
+    return out.clone() if out is not None else None       # (callers of this function own their result; the gatherer reuses its buffer)
+
+
+_default_gatherers: Dict[int, RecordGatherer] = {}

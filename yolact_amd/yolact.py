@@ -28,7 +28,7 @@ class Yolact(nn.Module):
     def __init__(self):
         super().__init__()
         cfg = active_cfg()
-        if not (is_lincomb(cfg) and cfg.eval_mask_branch):
+        if not is_lincomb(cfg):
             raise NotImplementedError('only mask_type.lincomb configs are on the hot path (SURVEY §8)')
         for flag in ('use_prediction_module', 'use_yolo_regressors', 'use_mask_scoring', 'use_instance_coeff',
                      'use_focal_loss', 'use_objectness_score', 'mask_proto_use_grid', 'mask_proto_bias',
@@ -84,7 +84,10 @@ class Yolact(nn.Module):
                              nms_thresh=cfg.nms_thresh)
         self._plans = {}
         self._plan_lock = threading.Lock()
-        self._run_lock = threading.Lock()
+        # one launch lock PER DEVICE: a plan's arena / head buffers are shared by the forwards of one device; nn.DataParallel
+        # replicas (eval.py:630-634,661) are shallow copies that share these dictionaries and run on different devices from
+        # different threads — they must not serialise each other's launch loops
+        self._run_locks = {}
         self._ptensors = None
         # any route that rewrites parameters wholesale (nn.Module.load_state_dict included) drops the packed / BN-folded
         # copies the plans hold; in-place edits are caught by the version stamps checked in plan_for()
@@ -116,6 +119,13 @@ class Yolact(nn.Module):
                     del sd[key]
         self.load_state_dict(sd)
         self.invalidate_plans()
+
+    def _run_lock_for(self, device):
+        lk = self._run_locks.get(device)
+        if lk is None:
+            with self._plan_lock:
+                lk = self._run_locks.setdefault(device, threading.Lock())
+        return lk
 
     def invalidate_plans(self):
         with self._plan_lock:
@@ -181,12 +191,22 @@ class Yolact(nn.Module):
         x = x.detach().to(torch.float32).contiguous()
         with torch.cuda.device(x.device):
             plan = self.plan_for(x)
+            nomask = not bool(getattr(cfg, 'eval_mask_branch', True))
             # the op list carries the reference's timer sections (backbone / fpn / proto / pred_heads, yolact.py:570-607)
-            with self._run_lock:
+            with self._run_lock_for(x.device):
                 proto, dev_out = plan.run(x, detect=lambda s: self.detect.run_device(
-                    plan.loc, plan.conf, plan.coef, plan.priors, True, stream=s, conf_ld=plan.conf_ld),
-                    timer=sys.modules.get('utils.timer'))
+                    plan.loc, plan.conf, self._coef_for(plan, nomask), plan.priors, True, stream=s, conf_ld=plan.conf_ld),
+                    timer=sys.modules.get('utils.timer'), skip_proto=nomask)
             return self.detect.finish(dev_out, proto, self)
+
+    def _coef_for(self, plan, nomask):
+        """The coefficient tensor Detect gathers from: the head GEMM's output, or — cfg.eval_mask_branch False at call time, i.e.
+        eval.py --detect (eval.py:1067-1068) — the all-zero tensor the reference substitutes (yolact.py:172-175)."""
+        if not nomask:
+            return plan.coef
+        if getattr(plan, 'zero_coef', None) is None:
+            plan.zero_coef = torch.zeros_like(plan.coef)
+        return plan.zero_coef
 
     def maskiou_forward(self, masks_lo):
         """FastMaskIoUNet.forward (yolact.py:363-375) on cropped prototype-resolution masks [N,ph,pw] -> [N,80]:
@@ -226,10 +246,13 @@ class Yolact(nn.Module):
         plan = self.plan_for(x, slot)
         if os.environ.get('YOLACT_AMD_GRAPH', '0') == '1':
             return self._forward_device_graph(plan, x, slot)
-        with self._run_lock:    # a plan's arena / head buffers are shared state: one forward at a time per model
+        nomask = not bool(getattr(self.cfg, 'eval_mask_branch', True))
+        with self._run_lock_for(x.device):    # a plan's arena / head buffers are shared state: one forward at a time per model
             proto, out = plan.run(x, detect=lambda s: self.detect.run_device(
-                plan.loc, plan.conf, plan.coef, plan.priors, True, stream=s, slot=slot, conf_ld=plan.conf_ld))
+                plan.loc, plan.conf, self._coef_for(plan, nomask), plan.priors, True, stream=s, slot=slot, conf_ld=plan.conf_ld),
+                skip_proto=nomask)
         out['proto'] = proto
+        out['net'] = self                    # postprocess_batch's FastMaskIoUNet (YOLACT++) lives on the model, like dets['net']
         return out
 
     def _forward_device_graph(self, plan, x, slot):
@@ -241,7 +264,7 @@ class Yolact(nn.Module):
         key = ('graph', tuple(x.shape), x.device, slot)
         # capture and replay touch the plan's shared arena / head buffers exactly like an eager run: same host lock, and
         # the device-side ordering against the previous run (possibly on another stream) through the plan's done-event
-        with self._run_lock:
+        with self._run_lock_for(x.device):
             rec = self._plans.get(key)
             cur = torch.cuda.current_stream(x.device)
             if plan._done_event is not None:
@@ -251,6 +274,7 @@ class Yolact(nn.Module):
                     proto, out = plan.run(inp, detect=lambda s: self.detect.run_device(
                         plan.loc, plan.conf, plan.coef, plan.priors, True, stream=s, slot=slot, conf_ld=plan.conf_ld))
                     out['proto'] = proto
+                    out['net'] = self
                     return out
                 static_x = x.clone()
                 body(static_x)                                   # eager warm-up: workspaces, lazy module state
@@ -275,7 +299,7 @@ class Yolact(nn.Module):
         with torch.cuda.device(x.device):
             return self._forward_device_one(x)
 
-    def forward_sharded(self, x_global, dst=0):
+    def forward_sharded(self, x_global, dst=0, masks=None, mask_size=None):
         """Data-parallel inference of one global batch across the ranks of torch.distributed (one process per GPU, RCCL): this
         rank computes its contiguous share of the images (parallel.shard_range), then ONE gather of the fixed-size detection
         records brings every image's detections to `dst` (eval.py:630-634,661 is batch splitting with a no-op gather; there is
@@ -283,19 +307,44 @@ class Yolact(nn.Module):
         batch — {'detection': {...}|None, 'net': self} per image; `proto` is the prototype tensor for the images this rank
         computed itself and None for detections gathered from other ranks (assemble those masks on their own rank: every
         rank can run postprocess_batch on its forward_device output) — and None on the other ranks.  The returned tensors
-        are fresh copies: they stay valid across later calls."""
+        are fresh copies: they stay valid across later calls.
+
+        masks='bits' (round 5; eval.py:630-634,791 moves the frame to the device that holds a detection's prototypes — here the
+        MASKS move instead): every rank assembles the final binary masks of its own images at `mask_size` = (h, w) (default: the
+        input size) where their prototypes live (output_utils.postprocess_bits_batch: one lincomb and one upsample-into-bits
+        launch per shard) and a second fixed-capacity gather brings them to `dst` as bits (3.8 MB per image at 550 x 550).  Every
+        detection of the returned list then also carries `mask_bits` int64 [n, ceil(h*w/64)], the per-image record `mask_size`, and
+        `postprocess_bits(out, w, h, batch_idx=b)` / `layers.box_utils.mask_iou_bits` work for EVERY image of the global batch
+        (parallel.unpack_mask_bits gives the float form)."""
         from . import parallel
         L.require_cuda(x_global, 'input batch')
+        if masks not in (None, 'bits'):
+            raise ValueError("forward_sharded: masks must be None or 'bits', got %r" % (masks,))
         if not hasattr(self, '_gatherer') or self._gatherer.dst != dst:
             self._gatherer = parallel.RecordGatherer(dst)
-        rec, mine = parallel.sharded_forward(self.forward_device, x_global, self.mask_dim, self._gatherer, dst)
+            self._mask_gatherer = parallel.RecordGatherer(dst)
+        bits = None
+        if masks == 'bits':
+            from .layers.output_utils import postprocess_bits_batch
+            hh, ww = (int(mask_size[0]), int(mask_size[1])) if mask_size is not None else (int(x_global.shape[2]), int(x_global.shape[3]))
+            cap = parallel._cap_of(self.forward_device)
+
+            def masks_fn(out):
+                if out is None:
+                    return torch.zeros(0, cap, (hh * ww + 63) // 64, dtype=torch.int64, device=x_global.device)
+                return postprocess_bits_batch(out, ww, hh)['bits']
+            rec, mine, bits = parallel.sharded_forward(self.forward_device, x_global, self.mask_dim, self._gatherer, dst,
+                                                       masks_fn=masks_fn, mask_gatherer=self._mask_gatherer)
+        else:
+            rec, mine = parallel.sharded_forward(self.forward_device, x_global, self.mask_dim, self._gatherer, dst)
         if rec is None:
             return None
         import torch.distributed as dist
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         rank = dist.get_rank() if world > 1 else 0
         lo, hi = parallel.shard_range(int(x_global.shape[0]), rank, world)
-        return parallel.assemble_sharded(rec, mine, lo, hi, self.mask_dim, self)
+        return parallel.assemble_sharded(rec, mine, lo, hi, self.mask_dim, self, bits=bits,
+                                         mask_size=(hh, ww) if masks == 'bits' else None)
 
     def forward_raw(self, x):
         """Head outputs before Detect (for parity tests): loc, conf (logits), mask, priors, proto — clones."""
@@ -303,7 +352,7 @@ class Yolact(nn.Module):
         x = x.detach().to(torch.float32).contiguous()
         with torch.cuda.device(x.device):
             plan = self.plan_for(x)
-            with self._run_lock:
+            with self._run_lock_for(x.device):
                 proto, _ = plan.run(x)
                 out = {'loc': plan.loc.clone(), 'conf_logits': plan.conf[..., :plan.Ccls].contiguous().clone(),
                        'mask': plan.coef.clone(),
