@@ -6,8 +6,13 @@ table is keyed by layer shape incl. B), so parity at batch 1 says nothing about 
 CPU oracle (oracle/yolact_oracle.py: torch-CPU restatement pinned to the executed reference, tests/test_oracle_golden.py)
 runs on the GPU box's host cores at the bench shapes and is compared with `net.forward_raw` and `net(x)`:
 
-  heads   |loc|, |coef| <= 1e-4 absolute; conf logits and prototypes <= 1e-4 * max|ref| (north star: "masks/scores within
-          1e-4 fp32"); softmax scores <= 1e-4 absolute
+  heads   |loc|, |coef| <= 1e-4 absolute; softmax scores <= 1e-4 absolute — these are what the north star's "masks / scores
+          within 1e-4 fp32" names.  Conf LOGITS and raw PROTOTYPES are held to 1e-4 * max(1, max|ref|): that bar is LOOSER than
+          an absolute 1e-4 whenever the tensor's scale exceeds 1 (max|ref| is 10 - 60 on the synthetic weights), and it is
+          stated here because it is a choice, not an accident: both are unbounded intermediate tensors whose error the softmax /
+          sigmoid that follows contracts, and the quantities a user sees (scores, boxes, coefficients, binarised masks) carry the
+          absolute bar.  Measured errors are 1.3e-6 .. 1.8e-5 of the scale (profiles/r0*_gpu_tests_summary.txt), i.e. <= 1.1e-3
+          absolute on logits of magnitude 60 and far below 1e-4 absolute after the softmax (<= 5e-7 measured)
   Detect  margin-aware matching (oracle/margins.py): every reference decision whose margin exceeds 1e-3 is reproduced
           exactly, common detections agree to 1e-4; undecidable ones are listed
   masks   postprocess() of two images: binary masks differ from the oracle's only where its soft value is within 1e-4 of 0.5

@@ -1320,6 +1320,7 @@ class Plan:
         """Per eligible layer: best GEMM tile of the Winograd path, then Winograd vs the (already tuned) direct kernel.
         The winner replaces the op in the list."""
         lib = self.lib
+        self.wino_toggle = {}       # table key -> [(op index, direct op, Winograd op, isolated timing favours Winograd)]: tools/instep_tune.py
         wtiles = [L.TILE_64x64, L.TILE_64x128, L.TILE_128x64, L.TILE_128x128_W8, L.TILE_64x128_S3, L.TILE_32x64_K2,
                   L.TILE_128x128, L.TILE_128x128_S3, L.TILE_128x128_W8_S3, L.TILE_256x128_W8, L.TILE_256x128_W8_S3]
         if self.split:
@@ -1380,7 +1381,17 @@ class Plan:
             best_m, best_t, t_direct, t_wino, t_f2, t_f4 = memo[key]
             self.wino_table.append((name, 'F%d/%s%s' % (best_m, L.TILE_NAMES.get(int(best_t) & 255, '-'),
                                                          'p' if int(best_t) & L.WINO_PLANES else ''), t_direct, t_wino, t_f2, t_f4))
-            if best_t and (self.wino_force or t_wino < 0.97 * t_direct):
+            # 'instep|<key>' = 0 (tools/instep_tune.py, round 5): the isolated timings above favour Winograd, but measured INSIDE the step
+            # — three launches and their V / M tensors crossing the memory side between them, against one launch — the direct kernel
+            # is the faster choice for this shape: keep it.  (Decided on whole-step time with every layer of the shape toggled.)
+            instep_direct = disk.get('instep|' + key) == 0 and not self.wino_force
+            if best_t and not (self.wino_up.get(idx) is not None or (self.wino_proj is not None and self.wino_proj[0] == idx)):
+                wd_ = [a for a in alts if a.m == best_m][0]
+                wd_.tile, wd_.v_planes = int(best_t) & 255, 1 if int(best_t) & L.WINO_PLANES else 0
+                self.wino_toggle.setdefault(key, []).append(
+                    (idx, (fn, dptr, name, where), (lib.ymi_conv3x3_winograd_f32, C.pointer(wd_), name + '[wino]', where),
+                     bool(t_wino < 0.97 * t_direct)))
+            if best_t and (self.wino_force or (t_wino < 0.97 * t_direct and not instep_direct)):
                 wd = [a for a in alts if a.m == best_m][0]
                 wd.tile, wd.v_planes = int(best_t) & 255, 1 if int(best_t) & L.WINO_PLANES else 0
                 self.ops[idx] = (lib.ymi_conv3x3_winograd_f32, C.pointer(wd), name + '[wino]', where)
@@ -1412,6 +1423,12 @@ class Plan:
                         else:
                             self.ops[pidx] = ('nop', None, pname + '[fused into ' + name + ']', pwhere)
                             self.proto_patch_wino = wd
+
+    def set_winograd(self, key, on: bool):
+        """Switch every layer of one Winograd table key between its direct launch and its three Winograd launches (tools/instep_tune.py:
+        whole-step A/B of the choice the isolated timings made).  Only layers without a fused upsampling / projection are listed."""
+        for idx, direct_op, wino_op, _ in self.wino_toggle.get(key, []):
+            self.ops[idx] = wino_op if on else direct_op
 
     def conv_flops(self):
         return sum(self.lib.ymi_conv_flops(C.byref(d)) for _, d in self.conv_meta)
