@@ -240,6 +240,15 @@ int ymi_maxpool3x3s2_nhwc_f32(const float *x, float *y, int B, int H, int W, int
 int ymi_bilinear_nhwc_f32(const float *x, float *y, int B, int Hi, int Wi, int C, int Ho, int Wo,
                           float scale_h, float scale_w, int relu, void *stream);
 
+/* The FPN top-down sum as its own in-place pass (ABI 7; yolact.py:332-334: x = F.interpolate(x, size, bilinear) + lat_layer(convout)):
+ *   y [B,Ho,Wo,C] += bilinear(x [B,Hi,Wi,C] -> Ho x Wo),  C % 4 == 0, both 16-byte aligned.
+ * Same interpolation (fp32 coordinates, same expression) as the YMI_RES_BILINEAR epilogue of ymi_conv2d_nhwc_f32: a lateral
+ * convolution without residual followed by this pass equals the fused launch bit for bit.  What it buys: the lateral convolutions
+ * of the lower levels depend only on their backbone stage, so the engine launches them early on its side stream, beside the later
+ * (under-filled) backbone stages, and only this small pass stays on the critical path.  y_amax: magnitude-bound slot of the SUM
+ * (ymi_conv_desc.x_amax layout; zeroed by the caller; may be NULL). */
+int ymi_bilinear_add_nhwc_f32(const float *x, float *y, int B, int Hi, int Wi, int C, int Ho, int Wo, float *y_amax, void *stream);
+
 /* Small direct convolution for FastMaskIoUNet (yolact.py:363-375; config maskiou_net, data/config.py:785-791):
  * x [B,H,W,Cin] NHWC, w [kh*kw*Cin][CoutPad4] (k = (ky*kw+kx)*Cin + c, CoutPad4 = ceil(Cout/4)*4, zero padded),
  * y [B,Ho,Wo,Cout]; optional bias and ReLU. */

@@ -157,6 +157,7 @@ SYMBOLS = [
     ('ymi_nhwc_to_nchw_f32', C.c_int, [_P, _P, _I, _I, _I, _I, _P]),
     ('ymi_maxpool3x3s2_nhwc_f32', C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     ('ymi_bilinear_nhwc_f32', C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _I, _P]),
+    ('ymi_bilinear_add_nhwc_f32', C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     ('ymi_conv2d_direct_nhwc_f32', C.c_int, [_P, _P, _P, _P] + [_I] * 12 + [_P]),
     ('ymi_global_maxpool_nhwc_f32', C.c_int, [_P, _P, _I, _I, _I, _P]),
     ('ymi_detect_f32', C.c_int, [C.POINTER(DetectDesc), _P]),

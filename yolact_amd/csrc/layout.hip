@@ -106,6 +106,35 @@ __global__ __launch_bounds__(256) void bilinear_nhwc_k(const float *__restrict__
   }
 }
 
+// FPN top-down sum as its own pass (yolact.py:332-334: x = F.interpolate(x, size=(h, w), mode=bilinear) + lat_layer(convout)):
+// y[b,oy,ox,:] += bilinear(x -> Ho x Wo)[b,oy,ox,:] IN PLACE, the interpolation in the epilogue form of csrc/conv_igemm.hip
+// (YMI_RES_BILINEAR: same coordinates, same expression), so lateral-conv launch + this pass == the fused launch bit for bit.  Raises
+// the magnitude-bound slot of the SUM (fp16x2 consumers scale by it).
+__global__ __launch_bounds__(256) void bilinear_add_k(const float *__restrict__ x, float *__restrict__ y, int Hi, int Wi, int C4, int Ho,
+                                                       int Wo, float sh, float sw, long total, float *__restrict__ amax) {
+  const ymi_amax_pre apre = ymi_amax_prefetch(amax);
+  float am = 0.f;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256u) {
+    const unsigned pu = i / (unsigned)C4, ru = pu / (unsigned)Wo, bu = ru / (unsigned)Ho;
+    const int c4 = (int)(i - pu * (unsigned)C4), ox = (int)(pu - ru * (unsigned)Wo), oy = (int)(ru - bu * (unsigned)Ho);
+    const long b = bu;
+    int y0, y1, x0, x1; float ly, lx;
+    bl_coord(oy, sh, Hi, y0, y1, ly);
+    bl_coord(ox, sw, Wi, x0, x1, lx);
+    const float *img = x + (b * Hi * Wi * C4 + c4) * 4;
+    const f32x4 v00 = *reinterpret_cast<const f32x4 *>(img + (long)(y0 * Wi + x0) * C4 * 4);
+    const f32x4 v01 = *reinterpret_cast<const f32x4 *>(img + (long)(y0 * Wi + x1) * C4 * 4);
+    const f32x4 v10 = *reinterpret_cast<const f32x4 *>(img + (long)(y1 * Wi + x0) * C4 * 4);
+    const f32x4 v11 = *reinterpret_cast<const f32x4 *>(img + (long)(y1 * Wi + x1) * C4 * 4);
+    const f32x4 rv = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+    f32x4 *dst = reinterpret_cast<f32x4 *>(y + (long)i * 4);
+    const f32x4 o = *dst + rv;
+    *dst = o;
+    am = fmaxf(am, ymi_absmax4(o));
+  }
+  if (amax) ymi_amax_finish(apre, am);
+}
+
 inline int grid_for(long total) {
   long g = (total + 255) / 256;
   const long cap = 256L * 8;  // 8 blocks per CU, grid-stride the rest
@@ -184,6 +213,16 @@ int ymi_bilinear_nhwc_f32(const float *x, float *y, int B, int Hi, int Wi, int C
   if (total >= (1L << 31)) return YMI_ESHAPE;
   hipLaunchKernelGGL(bilinear_nhwc_k, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, Hi, Wi, C / 4,
                      Ho, Wo, sh, sw, relu, total);
+  return ymi_launch_status();
+}
+
+int ymi_bilinear_add_nhwc_f32(const float *x, float *y, int B, int Hi, int Wi, int C, int Ho, int Wo, float *y_amax, void *stream) {
+  if (!x || !y) return YMI_ENULL;
+  if (C % 4 != 0 || B <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || ((((uintptr_t)x) | ((uintptr_t)y)) & 15)) return YMI_ESHAPE;
+  const long total = (long)B * Ho * Wo * (C / 4);
+  if (total >= (1L << 31)) return YMI_ESHAPE;
+  hipLaunchKernelGGL(bilinear_add_k, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, Hi, Wi, C / 4, Ho, Wo,
+                     (float)Hi / (float)Ho, (float)Wi / (float)Wo, total, y_amax);
   return ymi_launch_status();
 }
 

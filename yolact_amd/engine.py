@@ -560,6 +560,36 @@ class Plan:
     def call(self, fn, *args, name=''):
         self.ops.append((fn, args, name, self._cur))
 
+    # ---- FPN laterals of the lower levels, launched EARLY on the side stream (round 5) ------------------------------------------------
+    # lat_layers[i](C_j) depends only on backbone stage j (yolact.py:324-334); the top-down sum x_j = up(x_{j+1}) + lat(C_j) needs the
+    # level above, i.e. the END of the backbone.  Fused in the lateral's epilogue (YMI_RES_BILINEAR) both sit on the critical path
+    # behind C5; split, the lateral GEMMs of C3 / C4 run on stream B beside the later backbone stages — whose 35 x 35 / 18 x 18 launches
+    # leave a fifth to a third of the CUs idle — and only ymi_bilinear_add_nhwc_f32 (a 20 us stream) stays behind C5.  Bit-identical
+    # (same interpolation, same association).  YOLACT_AMD_EARLY_LAT=0 keeps the fused epilogue.
+    def _stage_done(self, li, t):
+        sel = self.net.backbone_selected
+        if not self._early_lat_on or li not in sel or sel.index(li) >= len(sel) - 1:
+            return
+        self._pending_lat.append((li, t))
+
+    def _flush_early_laterals(self):
+        sel = self.net.backbone_selected
+        n = len(sel)
+        for li, t in self._pending_lat:
+            j = sel.index(li)
+            i = n - 1 - j
+            # B may only start behind what A has issued SO FAR: the stage output is complete, and the projection shortcut the
+            # side stream computed for the block just finished has been consumed (its buffer went back to B's pool and may be the
+            # very one this lateral's output gets: tests/test_plan_schedule.py)
+            self.record('latgo%d' % i)
+            self.on('B')
+            self.wait('latgo%d' % i)
+            raw = self.conv('fpn.lat%d' % i, t, pack_module(self.net.fpn.lat_layers[i], device=self.device))
+            self.record('lat%d' % i)
+            self.on('A')
+            self.early_lat[j] = raw
+        self._pending_lat = []
+
     # stream control (no-ops in single-stream mode): ops emitted after on('B') go to the side stream
     def on(self, which):
         self._cur = which if self.two_streams else 'A'
@@ -580,6 +610,8 @@ class Plan:
         lib = self.lib
         ar = self.arena
 
+        self.early_lat, self._pending_lat = {}, []
+        self._early_lat_on = self.two_streams and os.environ.get('YOLACT_AMD_EARLY_LAT', '1') == '1'
         bb = net.backbone
         # ResNet stem (fp16x2 plans): layout change + 7x7/2 conv + BN + ReLU + 3x3/2 max-pool in ONE launch straight from the NCHW
         # input (csrc/stem.hip: 0.107 vs 0.168 ms for the three launches at batch 8, 0.020 vs 0.035 at batch 1, bit-identical (see the test for the exact statement)
@@ -599,6 +631,7 @@ class Plan:
             outs = self._resnet(bb, x4)
         else:
             outs = self._darknet(bb, x4)
+        self._flush_early_laterals()           # (anything still pending: a stage whose successor has no block to hide behind)
         sel = [outs[i] for i in net.backbone_selected]
         for i, t in enumerate(outs):
             if i not in net.backbone_selected and t is not None:
@@ -612,7 +645,17 @@ class Plan:
         for i in range(n):
             j = n - 1 - i
             pk = pack_module(fpn.lat_layers[i], device=dev)
-            if prev is None:
+            if j in self.early_lat and prev is not None:
+                raw = self.early_lat[j]                 # lat(C_j), computed on B long ago; the sum happens here, in place
+                self.wait('lat%d' % i)
+                slot = self._slot()
+                self.call(lib.ymi_bilinear_add_nhwc_f32, prev.ptr, raw.ptr, raw.B, prev.H, prev.W, raw.C, raw.H, raw.W,
+                          self._slot_ptr(slot) if self.h2 else None, name='fpn.add%d' % i)
+                raw.slot = slot
+                if raw.gain is not None and prev.gain is not None and raw.gain.numel() == prev.gain.numel():
+                    raw.gain = torch.maximum(raw.gain, prev.gain)
+                sums[j] = raw
+            elif prev is None:
                 sums[j] = self.conv('fpn.lat%d' % i, sel[j], pk)
             else:
                 sums[j] = self.conv('fpn.lat%d' % i, sel[j], pk, res=prev, res_mode=L.RES_BILINEAR)
@@ -874,8 +917,11 @@ class Plan:
                     ar.free(res)
                 ar.free(x)
                 x = y
+                if bi == 0:                     # behind this stage's projection shortcut on B: the previous stages' FPN laterals
+                    self._flush_early_laterals()
             # stage output: still needed by the FPN, so the next stage only borrows it
             outs.append(x)
+            self._stage_done(li, x)
             x = _Borrowed(x)
         return outs
 
@@ -902,7 +948,10 @@ class Plan:
                 ar.free(a)
                 ar.free(x)
                 x = y
+                if bi == 0:
+                    self._flush_early_laterals()
             outs.append(x)
+            self._stage_done(li, x)
             x = _Borrowed(x)
         return outs
 

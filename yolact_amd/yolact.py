@@ -137,7 +137,20 @@ class Yolact(nn.Module):
         pt = self._ptensors
         if pt is None:
             pt = self._ptensors = [t for t in list(self.parameters()) + list(self.buffers())]
+            if not any(True for _ in self.parameters()):      # a DataParallel replica: its weights are plain attributes
+                pt += [w for m in self.modules() for w in (getattr(m, 'weight', None), getattr(m, 'bias', None)) if torch.is_tensor(w)]
         return sum(t._version for t in pt)
+
+    def _weights_device(self):
+        """Where the weights live.  An nn.DataParallel replica (torch.nn.parallel.replicate, eval.py:630-634,661) keeps its broadcast
+        parameter copies as PLAIN tensor attributes — replica.parameters() is empty — so fall back to the first conv's weight."""
+        for p in self.parameters():
+            return p.device
+        for m in self.modules():
+            w = getattr(m, 'weight', None)
+            if torch.is_tensor(w):
+                return w.device
+        raise RuntimeError('Yolact: no weights found')
 
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)   # .cuda()/.to(): packed filters must be rebuilt on the new device
@@ -184,7 +197,7 @@ class Yolact(nn.Module):
         L.require_cuda(x, 'input batch')
         if x.dim() != 4 or x.shape[1] != 3:
             raise ValueError('expected [B,3,H,W], got %s' % (tuple(x.shape),))
-        if next(self.parameters()).device != x.device:
+        if self._weights_device() != x.device:
             raise RuntimeError('model and input live on different devices')
         cfg = self.cfg                    # read at call time, like the reference (yolact.py:566-568)
         cfg._tmp_img_h, cfg._tmp_img_w = int(x.shape[2]), int(x.shape[3])
