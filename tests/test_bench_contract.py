@@ -1,5 +1,5 @@
-"""The bench.py output contract, checked on the committed result of the last GPU session (profiles/r04_bench.json): the
-keys the driver and the judge read, their types, and the internal consistency of the roofline block."""
+"""The bench.py output contract, checked on the committed result of the last GPU session (profiles/r05_bench.json): the
+keys the driver and the judge read, their types, and the internal consistency of the roofline and calibration blocks."""
 import json
 import os
 import subprocess
@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _load():
-    with open(os.path.join(ROOT, 'profiles', 'r04_bench.json')) as f:
+    with open(os.path.join(ROOT, 'profiles', 'r05_bench.json')) as f:
         return json.loads(f.read())
 
 
@@ -35,19 +35,27 @@ def test_top_level_fields():
 
 
 def test_roofline_block():
-    r = _load()['roofline']
-    assert r['bound'] in ('hbm', 'mfma') and r['unit'] in ('GB/s', 'TFLOP/s')
+    b = _load()
+    r = b['roofline']
+    # top level (VERDICT r4 #1b): SURVEY 8(d)'s whole-path figure — algorithmic conv GFLOP of a step / the TIMED step, against the
+    # matrix-pipe peak of the precision used
+    assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and r['peak'] in (157.3, 416.7, 833.3)
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and 0 < r['frac'] <= 1.0
-    # the dominant kernel is described on ITS roof: HBM (algorithmic GB/s vs 8 TB/s) or the matrix pipe at the peak of the tile it runs
-    assert (r['bound'] == 'hbm') == (r['unit'] == 'GB/s')
-    m, hb = r['mfma'], r['hbm']
-    assert m['peak'] in (157.3, 416.7, 833.3) and ('h2' in r['kernel']) == (m['peak'] == 833.3) and ('x3' in r['kernel']) == (m['peak'] == 416.7)
-    assert hb['peak'] == 8000.0 and abs(hb['frac'] - hb['achieved'] / 8000.0) < 1e-3
+    ac = r['all_conv']
+    assert abs(ac['gflop_per_step'] - 8 * 118.28) < 1.0  # SURVEY 8(d): 118.28 GFLOP per image
+    assert abs(r['achieved'] - ac['gflop_per_step'] / b['ms_per_step']) / r['achieved'] < 2e-3
+    assert abs(r['achieved'] - 118.28 * b['value'] / 1e3) / r['achieved'] < 2e-3        # = GFLOP per image x images/s (one GPU)
     assert r['traffic'] is None or r['traffic'] > 0
     assert isinstance(r['traffic_source'], str) and ('static' in r['traffic_source'] or r['traffic'] is None)
-    # matrix-pipe view: achieved = FLOPs per launch / average launch duration; HBM view: algorithmic bytes per launch likewise
-    assert abs(m['achieved'] - r['flops_per_launch'] / (r['avg_launch_ms'] * 1e-3) / 1e12) / m['achieved'] < 0.01
-    assert abs(hb['achieved'] - hb['alg_bytes_per_launch'] / (r['avg_launch_ms'] * 1e-3) / 1e9) / hb['achieved'] < 0.01
+    # the dominant kernel (largest summed duration) on ITS matrix-pipe fraction; its algorithmic-bytes view is a sub-key
+    d = r['dominant_kernel']
+    assert d['kernel'] == r['kernel'] and d['bound'] == 'mfma' and d['unit'] == 'TFLOP/s'
+    assert d['peak'] in (157.3, 416.7, 833.3) and (('h2' in d['kernel']) or ('dcnp' in d['kernel'])) == (d['peak'] == 833.3)
+    assert abs(d['frac'] - d['achieved'] / d['peak']) < 1e-3 and 0 < d['frac'] <= 1.0
+    assert abs(d['achieved'] - d['flops_per_launch'] / (d['avg_launch_ms'] * 1e-3) / 1e12) / d['achieved'] < 0.01
+    hb = d['hbm_view']
+    assert hb['peak'] == 8000.0 and abs(hb['frac'] - hb['achieved'] / 8000.0) < 1e-3
+    assert abs(hb['achieved'] - hb['alg_bytes_per_launch'] / (d['avg_launch_ms'] * 1e-3) / 1e9) / hb['achieved'] < 0.01
     # step-level bound: sum over launches of max(FLOPs / tile peak, algorithmic bytes / 8 TB/s) <= the measured serialised time
     bs = r['bound_sum']
     assert abs(r['bound_sum_ms'] - (bs['mfma_bound_launches_ms'] + bs['hbm_bound_launches_ms'])) < 2e-3
@@ -55,13 +63,26 @@ def test_roofline_block():
     assert r['kernel'] in r['per_kernel']
     dom = max(r['per_kernel'].items(), key=lambda kv: kv[1]['ms_per_step'])[0]
     assert dom == r['kernel']                            # "dominant" = largest summed duration
-    ac = r['all_conv']
-    assert abs(ac['gflop_per_step'] - 8 * 118.28) < 1.0  # SURVEY 8(d): 118.28 GFLOP per image
     assert abs(ac['tflops'] - ac['gflop_per_step'] / ac['ms_per_step']) < 0.5
     assert 0 < r['engine']['frac'] <= 1.0
     for k, v in r['per_kernel'].items():
         assert 0 < v['frac'] <= 1.0 and abs(v['frac'] - v['tflops'] / v['peak']) < 2e-3, k
         assert v['bound'] in ('hbm', 'mfma') and 0 < v['bound_frac'] <= 1.0
+
+
+def test_box_calibration_block():
+    """VERDICT r4 #1a: a fixed fp16-MFMA loop and an HBM copy timed right before the timed region, next to what the box reports about
+    its clocks — so that two runs can be told apart as 'the box' or 'the code'."""
+    b = _load()
+    c = b['box_calibration']
+    assert 1000.0 < c['mfma_f16_tflops'] <= 2600.0 and abs(c['mfma_f16_frac_of_2500'] - c['mfma_f16_tflops'] / 2500.0) < 1e-3
+    assert 2000.0 < c['hbm_copy_GBps'] <= 8000.0 and abs(c['hbm_copy_frac_of_8000'] - c['hbm_copy_GBps'] / 8000.0) < 1e-3
+    assert c['compute_units'] == 256 and isinstance(c['power_state'], dict) and 'source' in c['power_state']
+    assert abs(c['value_if_box_delivered_2000_tflops'] - b['value'] * 2000.0 / c['mfma_f16_tflops']) < 0.5
+    assert b['per_rank_ms_per_step'] is not None and len(b['per_rank_ms_per_step']) == b['n_gpus']
+    assert b['gather_us'] > 0 and b['record_bytes_per_image'] == 4 * (1 + 100 * 38)
+    brk = b['secondary']['reference_fps_definition_batch1']['breakdown_ms']
+    assert brk['bytes_copied'] >= 5 * 550 * 550 * 4 and all(brk[k] > 0 for k in brk)
 
 
 def test_cpu_baseline_block():

@@ -151,3 +151,35 @@ def test_data_parallel_replicas_run_the_engine():
     dp = torch.nn.DataParallel(net, device_ids=[0])
     one = dp(x)
     assert torch.equal(one[0]['detection']['box'], ref[0]['detection']['box'])
+
+
+def test_early_fpn_laterals_are_bit_identical(monkeypatch):
+    """YOLACT_AMD_EARLY_LAT=1: lateral convolution without residual on the side stream + ymi_bilinear_add_nhwc_f32 == the fused
+    YMI_RES_BILINEAR epilogue of the default plan, bit for bit, on every head tensor of the batch-2 golden plan."""
+    from gpu_utils import build_net
+    from helpers import load_golden
+    meta, _ = load_golden('r50_dense')
+    x = case_images(meta).to(DEV)
+    ref = build_net(meta).forward_raw(x)
+    monkeypatch.setenv('YOLACT_AMD_EARLY_LAT', '1')
+    net = build_net(meta)
+    got = net.forward_raw(x)
+    plan = net.plan_for(x)
+    assert any(op[2] == 'fpn.add1' for op in plan.ops) and any(op[2] == 'fpn.add2' for op in plan.ops)
+    for k in ('loc', 'conf_logits', 'mask', 'proto'):
+        assert torch.equal(got[k], ref[k]), k
+
+
+def test_bilinear_add_kernel_matches_torch():
+    import ctypes as C
+    from yolact_amd import _lib as L
+    g = torch.Generator().manual_seed(3)
+    for (B, Hi, Wi, Cc, Ho, Wo) in ((2, 18, 18, 256, 35, 35), (1, 35, 35, 64, 69, 69), (3, 5, 7, 8, 9, 13)):
+        x = torch.randn(B, Hi, Wi, Cc, generator=g).to(DEV)
+        y = torch.randn(B, Ho, Wo, Cc, generator=g).to(DEV)
+        want = y + torch.nn.functional.interpolate(x.permute(0, 3, 1, 2), (Ho, Wo), mode='bilinear', align_corners=False).permute(0, 2, 3, 1)
+        amax = torch.zeros(16 * 64, device=DEV)
+        L.check(L.lib().ymi_bilinear_add_nhwc_f32(x.data_ptr(), y.data_ptr(), B, Hi, Wi, Cc, Ho, Wo, amax.data_ptr(), L.stream_ptr()))
+        assert (y - want).abs().max().item() < 2e-6 * max(1.0, want.abs().max().item())
+        assert abs(float(amax.max()) - float(y.abs().max())) == 0.0
+    assert L.lib().ymi_bilinear_add_nhwc_f32(x.data_ptr(), y.data_ptr(), 1, 5, 7, 6, 9, 13, None, L.stream_ptr()) == -2

@@ -250,3 +250,21 @@ def test_narrow_tile_candidates_follow_their_envelopes():
             assert (cols == 32) == (d.Cout <= 32)
             assert per * cols * 128 <= 65536 and (S == 1 or per * (S - 1) < nk), (name, S, nk)
     assert Plan.ws_candidates(desc(8, 138, 64, 256, 1)) == [] and Plan.ws_candidates(desc(8, 138, 256, 64, 1, L.RES_ADD)) == []
+
+
+@pytest.mark.parametrize('config,size', [('yolact_resnet50_config', 550), ('yolact_darknet53_config', 550), ('yolact_plus_base_config', 550)])
+def test_early_lateral_plan_is_race_free(config, size, monkeypatch):
+    """YOLACT_AMD_EARLY_LAT=1 (round 5, opt-in): the FPN laterals of the lower levels run on the side stream beside the later backbone
+    stages and the top-down sum becomes an in-place pass on the main stream.  The first version of this schedule had a real race —
+    the lateral's output landed in the pool buffer of the projection shortcut that the main stream's conv3 was still reading — and
+    this checker is what found it."""
+    from yolact_amd.engine import Plan
+    monkeypatch.setenv('YOLACT_AMD_EARLY_LAT', '1')
+    plan = Plan(_make_net(config), 2, size, size, torch.device('cpu'), dry_two_streams=True)
+    names = [op[2] for op in plan.ops]
+    assert 'fpn.add1' in names and 'fpn.add2' in names
+    lat = {op[2]: op[3] for op in plan.ops if isinstance(op[2], str) and op[2].startswith('fpn.lat')}
+    assert lat['fpn.lat0'] == 'A' and lat['fpn.lat1'] == 'B' and lat['fpn.lat2'] == 'B'
+    assert names.index('fpn.lat2') < names.index('fpn.lat1') < names.index('fpn.lat0')     # launched as their stages finish
+    problems, pos, _ = check_schedule(plan)
+    assert not problems, problems[:5]

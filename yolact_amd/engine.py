@@ -565,7 +565,10 @@ class Plan:
     # level above, i.e. the END of the backbone.  Fused in the lateral's epilogue (YMI_RES_BILINEAR) both sit on the critical path
     # behind C5; split, the lateral GEMMs of C3 / C4 run on stream B beside the later backbone stages — whose 35 x 35 / 18 x 18 launches
     # leave a fifth to a third of the CUs idle — and only ymi_bilinear_add_nhwc_f32 (a 20 us stream) stays behind C5.  Bit-identical
-    # (same interpolation, same association).  YOLACT_AMD_EARLY_LAT=0 keeps the fused epilogue.
+    # (same interpolation, same association).  MEASURED (session r5d, same box, alternating, profiles/r05_ab_runs.txt): 2011 - 2015
+    # images/s with it against 2017 - 2028 without — the laterals slow the backbone launches they share the chip with by as much as
+    # they save behind C5 (the finding of DESIGN 3.5 again: summed kernel time rises when streams overlap).  Hence OPT-IN:
+    # YOLACT_AMD_EARLY_LAT=1; the default keeps the fused epilogue.
     def _stage_done(self, li, t):
         sel = self.net.backbone_selected
         if not self._early_lat_on or li not in sel or sel.index(li) >= len(sel) - 1:
@@ -611,7 +614,7 @@ class Plan:
         ar = self.arena
 
         self.early_lat, self._pending_lat = {}, []
-        self._early_lat_on = self.two_streams and os.environ.get('YOLACT_AMD_EARLY_LAT', '1') == '1'
+        self._early_lat_on = self.two_streams and os.environ.get('YOLACT_AMD_EARLY_LAT', '0') == '1'
         bb = net.backbone
         # ResNet stem (fp16x2 plans): layout change + 7x7/2 conv + BN + ReLU + 3x3/2 max-pool in ONE launch straight from the NCHW
         # input (csrc/stem.hip: 0.107 vs 0.168 ms for the three launches at batch 8, 0.020 vs 0.035 at batch 1, bit-identical (see the test for the exact statement)
