@@ -425,8 +425,29 @@ def box_calibration(dev, seconds=0.25):
     evs[1].record()
     evs[1].synchronize()
     gbps = 20 * by.value / (evs[0].elapsed_time(evs[1]) * 1e-3) / 1e9
+    # the HOST half: what one C-ABI call and one asynchronous kernel launch cost from this Python process on this box (the step is
+    # ~190 such calls; slow hosts have measured 20 % lower batch-1 numbers with identical kernels)
+    t0 = time.perf_counter()
+    for _ in range(2000):
+        lib.ymi_abi_version()
+    call_us = (time.perf_counter() - t0) / 2000 * 1e6
+    small = torch.zeros(1024, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(300):
+        lib.ymi_calib_hbm_copy(small.data_ptr(), small.data_ptr() + 2048, 512, None, s)
+    launch_us = (time.perf_counter() - t0) / 300 * 1e6
+    torch.cuda.synchronize()
     del src, dst
-    return {'mfma_f16_tflops': round(sum(half) / len(half), 1), 'mfma_f16_tflops_first_launches': round(rates[0], 1),
+    host = {'ctypes_call_us': round(call_us, 2), 'async_kernel_launch_us': round(launch_us, 2)}
+    try:
+        with open('/proc/cpuinfo') as f:
+            names = [ln.split(':', 1)[1].strip() for ln in f if ln.startswith('model name')]
+        host['cpu_model'] = names[0] if names else None
+        host['logical_cpus'] = len(names)
+    except OSError:
+        pass
+    return {'host': host, 'mfma_f16_tflops': round(sum(half) / len(half), 1), 'mfma_f16_tflops_first_launches': round(rates[0], 1),
             'mfma_f16_frac_of_2500': round(sum(half) / len(half) / BF16_MFMA_PEAK_TFLOPS, 4),
             'hbm_copy_GBps': round(gbps, 1), 'hbm_copy_frac_of_8000': round(gbps / HBM_PEAK_GBPS, 4),
             'device': torch.cuda.get_device_name(dev), 'compute_units': n_cu, 'power_state': gpu_power_state(),
@@ -700,10 +721,14 @@ def main():
                 counts = buf[:n].tolist()                           # the per-image detection counts, on the host
                 got['n'] = len(counts)
 
+        issue_s = []                                    # host time to ISSUE one step (launch loop + gather + copy request), per step
+
         def run_steps(k):
             prev = None
             for _ in range(k):
+                t_is = time.perf_counter()
                 cur = launch()
+                issue_s.append(time.perf_counter() - t_is)
                 if args.no_pipeline:
                     collect(cur)
                 else:
@@ -717,6 +742,7 @@ def main():
         if have_pg:
             dist.barrier()
         torch.cuda.synchronize()
+        del issue_s[:]
         t0 = time.perf_counter()
         run_steps(args.steps)
         if have_pg:
@@ -772,6 +798,9 @@ def main():
                 'gathered_records': got['n'],
                 'collective': ('dist.gather over the nccl (RCCL) backend, %d rank(s)' % dist.get_world_size()) if have_pg
                               else 'none (RCCL init failed: %s)' % rccl_error,
+                # host side of the timed region: how long the Python launch loop needs to ISSUE one step (median / max over the timed
+                # steps).  Far below ms_per_step = the GPU sets the pace; close to it = this box's host does (box_calibration.host)
+                'host_issue_ms_per_step': {'median': round(sorted(issue_s)[len(issue_s) // 2] * 1e3, 3), 'max': round(max(issue_s) * 1e3, 3)},
                 'per_rank_ms_per_step': per_rank_ms,            # each rank's own clock over the timed region (value uses the MAX)
                 'gather_us': gather_us,                         # the record gather alone, host-paired, 50 back-to-back calls
                 'record_bytes_per_image': 4 * int(parallel.pack_records(net.forward_device(x)).shape[1]),

@@ -461,6 +461,33 @@ typedef struct ymi_chain_desc {
 } ymi_chain_desc;
 int ymi_pointwise_chain_f32(const ymi_chain_desc *d, void *stream);
 
+/* -- native plan executor (ABI 7; csrc/plan_exec.cpp) ----------------------------------------------------------------------------
+ * The engine's execution plan is a flat list of the calls above on two HIP streams (A = the caller's stream, B = a side stream
+ * for the small P4..P7 / Detect / projection-shortcut launches) with record / wait markers between them.  ymi_plan_run walks ops
+ * [first, last) in ONE call — the reference drives its layers from Python one nn.Module at a time (yolact.py:564-676); ~230
+ * interpreter-level calls per batch-8 step is what that shape costs here, and on a slow host it bounds batch 1.
+ * Descriptors are caller-owned and may be patched between runs (input pointer, prototype output).  `events`: handles from
+ * ymi_event_create, indexed by RECORD / WAIT ops.  overlap = 0: everything on stream_a, markers skipped (serialised kernels, what
+ * per-kernel timing needs).  skip_sections: bit k set = ops whose `section` is k are skipped (bit YMI_SEC_PROTO: the protonet, when
+ * cfg.eval_mask_branch is False).  On failure returns the failing call's code and, through failed_op, its index. */
+enum { YMI_OP_NOP = 0, YMI_OP_CONV = 1, YMI_OP_WINO = 2, YMI_OP_DCN = 3, YMI_OP_CHAIN = 4, YMI_OP_STEM = 5, YMI_OP_INPUT = 6,
+       YMI_OP_BILINEAR = 7, YMI_OP_MAXPOOL = 8, YMI_OP_BILINEAR_ADD = 9, YMI_OP_RECORD = 10, YMI_OP_WAIT = 11, YMI_OP_MEMSET = 12 };
+enum { YMI_SEC_NONE = 0, YMI_SEC_BACKBONE = 1, YMI_SEC_FPN = 2, YMI_SEC_PROTO = 3, YMI_SEC_HEADS = 4 };
+typedef struct ymi_plan_op {
+  int32_t kind;        /* YMI_OP_* */
+  int32_t stream;      /* 0 = A, 1 = B */
+  int32_t section;     /* YMI_SEC_* (the reference's timer sections, yolact.py:570-607) */
+  int32_t _pad;
+  const void *desc;    /* CONV / WINO / DCN / CHAIN / STEM: the call's descriptor */
+  void *p[3];          /* pointer arguments of the descriptor-less calls (see csrc/plan_exec.cpp) */
+  int64_t i[8];        /* their integer arguments; RECORD / WAIT: i[0] = event index; MEMSET: i[0] = bytes */
+  double f[2];         /* BILINEAR: scale_h, scale_w */
+} ymi_plan_op;
+int ymi_event_create(void **ev);
+int ymi_event_destroy(void *ev);
+int ymi_plan_run(const ymi_plan_op *ops, int first, int last, void *stream_a, void *stream_b, void *const *events, int overlap,
+                 int skip_sections, int32_t *failed_op);
+
 /* -- workspace sizes (ABI 7) ------------------------------------------------------------------------------------------------
  * The library never allocates device memory (SURVEY 8(b) "ownership": the reference's extension allocates its own outputs and
  * scratch, dcn_v2_cuda.cu:89-91,165-170; here the CALLER does).  A host that is not the Python shim asks this function how many

@@ -183,3 +183,44 @@ def test_bilinear_add_kernel_matches_torch():
         assert (y - want).abs().max().item() < 2e-6 * max(1.0, want.abs().max().item())
         assert abs(float(amax.max()) - float(y.abs().max())) == 0.0
     assert L.lib().ymi_bilinear_add_nhwc_f32(x.data_ptr(), y.data_ptr(), 1, 5, 7, 6, 9, 13, None, L.stream_ptr()) == -2
+
+
+def test_native_executor_equals_the_python_loop(monkeypatch):
+    """csrc/plan_exec.cpp walks the op list in two native calls (around the Detect callback); YOLACT_AMD_NATIVE_EXEC=0 issues the same
+    list from the Python loop.  Same launches, same streams, same events: every output bit-identical; the native path is the default
+    and the one this test must find active."""
+    import time
+    from gpu_utils import build_net
+    from helpers import load_golden
+    meta, _ = load_golden('r50_dense')
+    x = case_images(meta).to(DEV)
+    net = build_net(meta)
+    plan = net.plan_for(x)
+    assert plan.native_exec
+    a = net.forward_device(x)
+    assert plan._native is not None and plan._native[1] is not None
+    raw = net.forward_raw(x)
+    monkeypatch.setenv('YOLACT_AMD_NATIVE_EXEC', '0')
+    net2 = build_net(meta)
+    plan2 = net2.plan_for(x)
+    assert not plan2.native_exec
+    b = net2.forward_device(x)
+    raw2 = net2.forward_raw(x)
+    for k in ('count', 'box', 'score', 'cls', 'coef', 'proto'):
+        nb = int(a['count'].min())
+        assert torch.equal(a[k][:, :nb] if a[k].dim() > 1 and k != 'proto' else a[k], b[k][:, :nb] if b[k].dim() > 1 and k != 'proto' else b[k]), k
+    for k in ('loc', 'conf_logits', 'mask', 'proto'):
+        assert torch.equal(raw[k], raw2[k]), k
+
+    def issue_ms(n_, reps=30):
+        torch.cuda.synchronize()
+        t = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            n_.forward_device(x)
+            t.append(time.perf_counter() - t0)
+            torch.cuda.synchronize()
+        return sorted(t)[len(t) // 2] * 1e3
+    t_nat, t_py = issue_ms(net), issue_ms(net2)
+    print('host time to issue one batch-%d step: native executor %.3f ms, Python loop %.3f ms' % (meta['B'], t_nat, t_py))
+    assert t_nat < t_py

@@ -627,3 +627,42 @@ def test_outlier_guard_needs_an_amplifying_producer_not_just_tiny_columns():
             os.environ.pop('YOLACT_AMD_SPLIT', None)
         else:
             os.environ['YOLACT_AMD_SPLIT'] = old
+
+
+def test_native_plan_executor_host_side(tmp_path):
+    """csrc/plan_exec.cpp (ABI 7) without a GPU: the ymi_plan_op layout equals the C compiler's, a list of NOP / skipped ops runs to
+    completion without touching HIP, an unknown op kind is reported with its index, and a CPU-built plan translates into the op array
+    (every call of the op list is one the executor knows)."""
+    import subprocess
+    from yolact_amd import _lib as L
+    from yolact_amd.engine import Plan
+    lib = L.lib()
+    src = tmp_path / 'po.c'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu %%zu\\n",sizeof(ymi_plan_op),'
+                   'offsetof(ymi_plan_op,desc),offsetof(ymi_plan_op,p),offsetof(ymi_plan_op,i),offsetof(ymi_plan_op,f));return 0;}'
+                   % os.path.join(ROOT, 'include', 'yolact_amd.h'))
+    exe = tmp_path / 'po'
+    subprocess.run(['gcc', str(src), '-o', str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert got == [ctypes.sizeof(L.PlanOp), L.PlanOp.desc.offset, L.PlanOp.p.offset, L.PlanOp.i.offset, L.PlanOp.f.offset]
+    arr = (L.PlanOp * 4)()
+    arr[1].kind, arr[1].section = L.OP_CONV, L.SEC_PROTO          # would dereference a NULL descriptor — but its section is skipped
+    failed = ctypes.c_int32(-1)
+    assert lib.ymi_plan_run(arr, 0, 4, None, None, None, 0, 1 << L.SEC_PROTO, ctypes.byref(failed)) == 0
+    arr[2].kind = 99
+    assert lib.ymi_plan_run(arr, 0, 4, None, None, None, 0, 1 << L.SEC_PROTO, ctypes.byref(failed)) == -1 and failed.value == 2
+    assert lib.ymi_plan_run(None, 0, 1, None, None, None, 0, 0, None) == -1
+    assert lib.ymi_plan_run(arr, 3, 2, None, None, None, 0, 0, None) == -1
+    arr[1].section = 0
+    assert lib.ymi_plan_run(arr, 1, 2, None, None, None, 0, 0, ctypes.byref(failed)) == -3 and failed.value == 1     # NULL descriptor: the call's own check
+    plan = Plan(_make_net('yolact_plus_resnet50_config'), 1, 550, 550, torch.device('cpu'))
+    nat = plan._native_plan()
+    assert nat is not None
+    ops, det_idx, evs, in_idx, n = nat
+    assert n == len(plan.ops) + 1 and ops[0].kind == L.OP_MEMSET and plan.ops[det_idx - 1][0] == 'detect'
+    kinds = [ops[k].kind for k in range(n)]
+    assert kinds.count(L.OP_DCN) == 13 and L.OP_CONV in kinds and (L.OP_STEM in kinds or L.OP_INPUT in kinds)
+    assert all(ops[k + 1].section == L.SEC_PROTO for k, op in enumerate(plan.ops) if isinstance(op[2], str) and op[2].startswith('proto.'))
+    assert plan._native_plan() is nat                              # cached until an op is replaced
+    plan.ops[5] = ('nop', None, 'x', 'A')
+    assert plan._native_plan() is not nat

@@ -128,6 +128,16 @@ class StemDesc(C.Structure):
                 ('kpad', C.c_int32), ('_pad0', C.c_int32)]
 
 
+class PlanOp(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('stream', C.c_int32), ('section', C.c_int32), ('_pad', C.c_int32), ('desc', C.c_void_p),
+                ('p', C.c_void_p * 3), ('i', C.c_int64 * 8), ('f', C.c_double * 2)]
+
+
+(OP_NOP, OP_CONV, OP_WINO, OP_DCN, OP_CHAIN, OP_STEM, OP_INPUT, OP_BILINEAR, OP_MAXPOOL, OP_BILINEAR_ADD, OP_RECORD, OP_WAIT,
+ OP_MEMSET) = range(13)
+SEC_NONE, SEC_BACKBONE, SEC_FPN, SEC_PROTO, SEC_HEADS = range(5)
+
+
 class MaskIouShape(C.Structure):
     _fields_ = [('A', C.c_int32), ('B', C.c_int32), ('n', C.c_int64)]
 
@@ -185,6 +195,9 @@ SYMBOLS = [
     ('ymi_coco_poly_fill_u8', C.c_int, [_P, _I, _I, _I, _P]),
     ('ymi_coco_rle_fill_u8', C.c_int, [_P, C.c_long, _I, _I, _P]),
     ('ymi_coco_rle_string_fill_u8', C.c_int, [C.c_char_p, C.c_long, _I, _I, _P]),
+    ('ymi_event_create', C.c_int, [C.POINTER(C.c_void_p)]),
+    ('ymi_event_destroy', C.c_int, [_P]),
+    ('ymi_plan_run', C.c_int, [C.POINTER(PlanOp), _I, _I, _P, _P, C.POINTER(C.c_void_p), _I, _I, C.POINTER(C.c_int32)]),
     ('ymi_workspace_bytes', C.c_int64, [_I, _P]),
     ('ymi_calib_mfma_f16', C.c_int, [_P, _I, _I, C.POINTER(C.c_double), _P]),
     ('ymi_calib_hbm_copy', C.c_int, [_P, _P, C.c_long, C.POINTER(C.c_double), _P]),

@@ -376,6 +376,9 @@ class Plan:
         # DCN layers: conv_offset_mask padded to 32 filters / tap-interleaved channel order (pack_offmask); 0 = the reference's 27 / order
         self.om_pad = os.environ.get('YOLACT_AMD_OM_PAD', '1') == '1'
         self.om_interleave = os.environ.get('YOLACT_AMD_OM_INTERLEAVE', '1') == '1'
+        # YOLACT_AMD_NATIVE_EXEC=0: issue the op list from the Python loop (one ctypes call per launch) instead of csrc/plan_exec.cpp
+        self.native_exec = device.type == 'cuda' and os.environ.get('YOLACT_AMD_NATIVE_EXEC', '1') == '1'
+        self._native, self._native_events, self._stem_desc = None, None, None
         self.wide_ops = set()
         self.wide_layers = []       # names of the layers the outlier-channel guard took off the fp16x2 tiles (warned about once, below)
         self._sk_ws = {}
@@ -871,6 +874,7 @@ class Plan:
             md.kh, md.kw, md.stride, md.pad, md.Kpad, md.cin_alg, md.cout_alg = 7, 7, 2, 3, pk0.Kpad, 3, 64
             self.conv_meta.append(('stem', md))
             self.ops.append(('stem', sd, 'stem+maxpool', 'A'))
+            self._stem_desc = sd
         else:
             stem = self.conv('stem', x4, pk0, act=L.ACT_RELU)
             ar.free(x4)
@@ -1005,11 +1009,17 @@ class Plan:
             self.proto_patch.seg[0].ptr = proto.data_ptr()
             if self.proto_patch_wino is not None:
                 self.proto_patch_wino.proj_y = proto.data_ptr()
-        if self.h2:                  # magnitude bounds are re-derived by every run (on the caller's stream, ahead of every op)
-            self.amax[:self._nslots * AMAX_SLOT_FLOATS].zero_()
         # only a module with the reference's timer API (utils/timer.py: start / stop / env) is driven
         if timer is not None and not all(hasattr(timer, a) for a in ('start', 'stop', 'env')):
             timer = None
+        if timer is None and self.native_exec:
+            nat = self._native_plan()
+            if nat is not None:          # the whole op list in two native calls (csrc/plan_exec.cpp) around the Detect callback
+                det = self._run_native(nat, x, sa, sb, two, detect, skip_proto)
+                self.mark_done()
+                return proto, det
+        if self.h2:                  # magnitude bounds are re-derived by every run (on the caller's stream, ahead of every op)
+            self.amax[:self._nslots * AMAX_SLOT_FLOATS].zero_()
         self._sec = None
         try:
             det = self._dispatch(x, cur, sa, sb, two, detect, timer, skip_proto)
@@ -1018,6 +1028,109 @@ class Plan:
                 timer.stop(self._sec)
         self.mark_done()
         return proto, det
+
+    # ---- native executor (csrc/plan_exec.cpp, ABI 7) ------------------------------------------------------------------------------
+    _SEC_ID = {'backbone': L.SEC_BACKBONE, 'fpn': L.SEC_FPN, 'proto': L.SEC_PROTO, 'pred_heads': L.SEC_HEADS}
+
+    def _native_plan(self):
+        """The op list as a ymi_plan_op array (rebuilt whenever an op was replaced: tuner, set_winograd), the index of the Detect
+        marker, the event handles and the index of the input-layout op.  None when the list holds a call the executor does not know
+        (the Python loop then runs it)."""
+        key = tuple(map(id, self.ops))
+        if self._native is not None and self._native[0] == key:
+            return self._native[1]
+        lib = self.lib
+        n = len(self.ops)
+        arr = (L.PlanOp * (n + 1))()
+        arr[0].kind, arr[0].stream = L.OP_MEMSET, 0
+        arr[0].p[0], arr[0].i[0] = self.amax.data_ptr(), 4 * self._nslots * AMAX_SLOT_FLOATS
+        ev_index, det_idx, in_idx, ok = {}, None, None, True
+        by_fn = {id(lib.ymi_conv2d_nhwc_f32): L.OP_CONV, id(lib.ymi_conv3x3_winograd_f32): L.OP_WINO,
+                 id(lib.ymi_dcn_v2_forward_f32): L.OP_DCN, id(lib.ymi_pointwise_chain_f32): L.OP_CHAIN}
+        for k, (fn, args, name, where) in enumerate(self.ops):
+            o = arr[k + 1]
+            o.stream = 1 if where == 'B' else 0
+            o.section = self._SEC_ID.get(self.sections[k], 0) if self.sections[k] else 0
+            if fn == 'input':
+                a = self.in_args
+                o.kind, in_idx = L.OP_INPUT, k + 1
+                o.p[1] = a[1]
+                o.p[2] = self.in_amax[2] if self.h2 else None
+                o.i[0], o.i[1], o.i[2], o.i[3] = a[2], a[3], a[4], a[5]
+            elif fn == 'stem':
+                o.kind, o.desc = L.OP_STEM, C.addressof(args)
+            elif fn == 'nop':
+                o.kind = L.OP_NOP
+            elif fn in ('record', 'wait'):
+                o.kind = L.OP_RECORD if fn == 'record' else L.OP_WAIT
+                o.i[0] = ev_index.setdefault(args, len(ev_index))
+            elif fn == 'detect':
+                o.kind, det_idx = L.OP_NOP, k + 1
+            elif id(fn) in by_fn:
+                o.kind, o.desc = by_fn[id(fn)], C.addressof(args.contents)
+            elif fn is lib.ymi_bilinear_nhwc_f32:
+                o.kind = L.OP_BILINEAR
+                o.p[0], o.p[1] = args[0], args[1]
+                for q in range(6):
+                    o.i[q] = args[2 + q]
+                o.f[0], o.f[1], o.i[6] = args[8].value, args[9].value, args[10]
+            elif fn is lib.ymi_maxpool3x3s2_nhwc_f32:
+                o.kind = L.OP_MAXPOOL
+                o.p[0], o.p[1] = args[0], args[1]
+                for q in range(6):
+                    o.i[q] = args[2 + q]
+            elif fn is lib.ymi_bilinear_add_nhwc_f32:
+                o.kind = L.OP_BILINEAR_ADD
+                o.p[0], o.p[1], o.p[2] = args[0], args[1], args[8]
+                for q in range(6):
+                    o.i[q] = args[2 + q]
+            else:
+                ok = False
+                break
+        if not ok or det_idx is None:
+            self._native = (key, None)
+            return None
+        if self._native_events is None or len(self._native_events) < len(ev_index):
+            evs = (C.c_void_p * max(len(ev_index), 1))()
+            for q in range(len(ev_index)):
+                h = C.c_void_p()
+                L.check(lib.ymi_event_create(C.byref(h)), 'ymi_event_create')
+                evs[q] = h.value
+            self._native_events = evs
+        nat = (arr, det_idx, self._native_events, in_idx, n + 1)
+        self._native = (key, nat)
+        return nat
+
+    def _run_native(self, nat, x, sa, sb, two, detect, skip_proto):
+        arr, det_idx, evs, in_idx, n = nat
+        lib = self.lib
+        if in_idx is not None:
+            arr[in_idx].p[0] = x.data_ptr()
+        if self._stem_desc is not None:
+            self._stem_desc.x = x.data_ptr()
+        skip = (1 << L.SEC_PROTO) if skip_proto else 0
+        failed = C.c_int32(-1)
+        ov = 1 if two else 0
+
+        def go(first, last):
+            rc = lib.ymi_plan_run(arr, first, last, sa, sb, evs, ov, skip, C.byref(failed))
+            if rc != 0:
+                L.check(rc, self.ops[failed.value - 1][2] if failed.value > 0 else 'plan op')
+        go(0 if self.h2 else 1, det_idx)
+        det = None
+        if detect is not None:
+            det = detect(sb if self.ops[det_idx - 1][3] == 'B' else sa)
+        go(det_idx + 1, n)
+        return det
+
+    def __del__(self):
+        try:
+            if getattr(self, '_native_events', None) is not None:
+                for h in self._native_events:
+                    if h:
+                        self.lib.ymi_event_destroy(h)
+        except Exception:
+            pass
 
     def _dispatch(self, x, cur, sa, sb, two, detect, timer, skip_proto=False):
         """The flat op loop of run(): C-ABI launches on the two streams, event records / waits, the Detect callback."""
