@@ -20,16 +20,23 @@ definition (eval.py:264-281 prep_benchmark: batch 1, postprocess, top-k `.cpu().
 Other BASELINE configs: `--config yolact_im700_config --batch 8` (configs[4], per-GPU share; size 700 is implied),
 `--config yolact_base_config --batch 16` (configs[2]), `--config yolact_plus_resnet50_config` (configs[3]).
 
-One JSON line on rank 0, with `roofline` (dominant conv kernel, live HIP-event timing on the launch stream) and,
-at N=1, `cpu_baseline` (the CPU oracle = port of the reference's path, timed on this host's cores).
+One JSON line on rank 0, with `roofline`, `box_calibration` and, at N=1, `cpu_baseline` (the CPU oracle = port of the reference's
+path, timed on this host's cores).
 
-`roofline` fields: `kernel` / `achieved` / `frac` / `avg_launch_ms` / `traffic` = the instantiation of the conv engine
-with the largest summed duration; a direct launch is priced with its algorithmic conv FLOPs, a grouped Winograd GEMM
-launch with the FLOPs it executes (`flops_basis`), so `frac` is a matrix-core utilisation.  `engine` = the same over ALL
-GEMM launches of a step.  `all_conv` = ALGORITHMIC conv FLOPs (118.28 GFLOP/image) over the summed
-durations of every conv-layer launch incl. the Winograd transforms — the figure BASELINE.json's ">= 60 % of the conv
-roofline" target refers to; with Winograd layers it can exceed what the matrix cores execute.  `per_kernel` = every
-instantiation.  DESIGN.md 3.5 / 6.
+`roofline` (round 5 layout): the TOP LEVEL is SURVEY 8(d)'s whole-path figure — `achieved` = algorithmic conv FLOPs of a step (118.28
+GFLOP per image) / the TIMED step on one GPU, `peak` = the matrix pipe at the precision used (fp16x2: 2500 / 3 = 833.3 TFLOP/s),
+`frac` = their ratio: the number BASELINE.json's ">= 60 % of the conv roofline" target refers to.  `kernel` / `dominant_kernel` = the
+instantiation with the largest summed duration on ITS matrix-pipe fraction (a direct launch priced with its algorithmic conv FLOPs, a
+grouped Winograd GEMM with the FLOPs it executes: `flops_basis`), measured live with HIP events on the launch stream;
+`dominant_kernel.hbm_view` = its algorithmic bytes per launch over the same duration (for a Winograd GEMM these are Winograd-domain
+bytes: `layer_view` puts them next to what the convolution needs); `traffic` = PMC HBM bytes per launch of that kernel (static: the
+committed summary of separate rocprofv3 --pmc passes, reported only under the tile table they were measured with).  `engine` = all
+GEMM launches of a step, `all_conv` = algorithmic FLOPs over the summed launch durations, `bound_sum` = sum over launches of
+max(FLOPs / tile peak, algorithmic bytes / 8 TB/s), `per_kernel` = every instantiation.
+`box_calibration`: three fixed micro-workloads timed right before the warm-up steps (csrc/calib.hip: fp16 MFMA loop, 1 GiB HBM copy,
+L2-resident read stream), the host's cost per C-ABI call / kernel launch, and what rocm-smi reports — so that two runs can be
+attributed to the box or to the code.  `host_issue_ms_per_step`: host time to issue one step (far below ms_per_step = GPU-bound).
+DESIGN.md 3.5 / 6.
 """
 import argparse
 import ctypes as C
@@ -347,7 +354,7 @@ def traffic_from_profiles(kernel):
     inside this process, so the figure is STATIC: the committed summary of separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
     passes over this very command (FETCH_SIZE doubled per MI355X_MICROARCH.md; `tools/gpu_session.sh <name> traffic`).
     It is only reported when that summary was measured with the tile table this run uses (`tune_sha`), else null."""
-    for fn in ('r04_traffic.json', 'r03_traffic.json', 'r02_traffic.json'):
+    for fn in ('r05_traffic.json', 'r04_traffic.json', 'r03_traffic.json', 'r02_traffic.json'):
         path = os.path.join(ROOT, 'profiles', fn)
         if os.path.exists(path):
             with open(path) as f:
@@ -425,6 +432,20 @@ def box_calibration(dev, seconds=0.25):
     evs[1].record()
     evs[1].synchronize()
     gbps = 20 * by.value / (evs[0].elapsed_time(evs[1]) * 1e-3) / 1e9
+    # L2-resident read stream (1 MB swept by 8 blocks per CU): the global -> CU path the GEMM tiles are bound by
+    l2src = torch.randn(1 << 18, device=dev)
+    l2b = C.c_double()
+
+    def l2():
+        L.check(lib.ymi_calib_l2_read(l2src.data_ptr(), l2src.numel(), 8 * n_cu, 16, out.data_ptr(), C.byref(l2b), s), 'ymi_calib_l2_read')
+    l2()
+    torch.cuda.synchronize()
+    evs[0].record()
+    for _ in range(10):
+        l2()
+    evs[1].record()
+    evs[1].synchronize()
+    l2_gbps = 10 * l2b.value / (evs[0].elapsed_time(evs[1]) * 1e-3) / 1e9
     # the HOST half: what one C-ABI call and one asynchronous kernel launch cost from this Python process on this box (the step is
     # ~190 such calls; slow hosts have measured 20 % lower batch-1 numbers with identical kernels)
     t0 = time.perf_counter()
@@ -450,6 +471,7 @@ def box_calibration(dev, seconds=0.25):
     return {'host': host, 'mfma_f16_tflops': round(sum(half) / len(half), 1), 'mfma_f16_tflops_first_launches': round(rates[0], 1),
             'mfma_f16_frac_of_2500': round(sum(half) / len(half) / BF16_MFMA_PEAK_TFLOPS, 4),
             'hbm_copy_GBps': round(gbps, 1), 'hbm_copy_frac_of_8000': round(gbps / HBM_PEAK_GBPS, 4),
+            'l2_read_GBps': round(l2_gbps, 1),
             'device': torch.cuda.get_device_name(dev), 'compute_units': n_cu, 'power_state': gpu_power_state(),
             'what': 'csrc/calib.hip, timed with HIP events on the launch stream right before the warm-up steps: %d x 4 waves of '
                     'register-resident v_mfma_f32_32x32x16_f16 (random mantissas) for %.2f s, rate of the last half of the interval; '

@@ -243,7 +243,7 @@ int ymi_bilinear_nhwc_f32(const float *x, float *y, int B, int Hi, int Wi, int C
 /* The FPN top-down sum as its own in-place pass (ABI 7; yolact.py:332-334: x = F.interpolate(x, size, bilinear) + lat_layer(convout)):
  *   y [B,Ho,Wo,C] += bilinear(x [B,Hi,Wi,C] -> Ho x Wo),  C % 4 == 0, both 16-byte aligned.
  * Same interpolation (fp32 coordinates, same expression) as the YMI_RES_BILINEAR epilogue of ymi_conv2d_nhwc_f32: a lateral
- * convolution without residual followed by this pass equals the fused launch bit for bit.  What it buys: the lateral convolutions
+ * convolution without residual followed by this pass equals the fused launch (bit for bit when the same GEMM tile runs).  What it buys: the lateral convolutions
  * of the lower levels depend only on their backbone stage, so the engine launches them early on its side stream, beside the later
  * (under-filled) backbone stages, and only this small pass stays on the critical path.  y_amax: magnitude-bound slot of the SUM
  * (ymi_conv_desc.x_amax layout; zeroed by the caller; may be NULL). */
@@ -520,6 +520,9 @@ int64_t ymi_workspace_bytes(int what, const void *desc);
  *   lanes; *bytes = read + written. */
 int ymi_calib_mfma_f16(float *out, int blocks, int iters, double *flops, void *stream);
 int ymi_calib_hbm_copy(const float *src, float *dst, long n_floats, double *bytes, void *stream);
+/* every one of `blocks` 256-thread blocks reads src [n_floats] (n % 4096 == 0; 1 MB stays resident in every XCD's L2) `iters` times with
+ * 16-byte loads; *bytes = bytes delivered to the CUs.  The path the GEMM tiles are bound by (global -> CU at L2-hit latency). */
+int ymi_calib_l2_read(const float *src, long n_floats, int blocks, int iters, float *out, double *bytes, void *stream);
 
 /* -- profiling hooks -------------------------------------------------------------------- */
 /* When enabled, every conv launch is bracketed by hipEvents on its stream; ymi_prof_read returns

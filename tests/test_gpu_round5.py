@@ -153,9 +153,11 @@ def test_data_parallel_replicas_run_the_engine():
     assert torch.equal(one[0]['detection']['box'], ref[0]['detection']['box'])
 
 
-def test_early_fpn_laterals_are_bit_identical(monkeypatch):
-    """YOLACT_AMD_EARLY_LAT=1: lateral convolution without residual on the side stream + ymi_bilinear_add_nhwc_f32 == the fused
-    YMI_RES_BILINEAR epilogue of the default plan, bit for bit, on every head tensor of the batch-2 golden plan."""
+def test_early_fpn_laterals_equal_the_fused_epilogue(monkeypatch):
+    """YOLACT_AMD_EARLY_LAT=1: lateral convolution without residual on the side stream + ymi_bilinear_add_nhwc_f32 against the fused
+    YMI_RES_BILINEAR epilogue of the default plan.  The pass itself reproduces the epilogue's interpolation exactly
+    (test_bilinear_add_kernel_matches_torch); the lateral GEMM, freed of the bilinear epilogue, runs on another tile of the table
+    (another fp32 summation order), so the head tensors agree to rounding, not bit for bit."""
     from gpu_utils import build_net
     from helpers import load_golden
     meta, _ = load_golden('r50_dense')
@@ -167,7 +169,7 @@ def test_early_fpn_laterals_are_bit_identical(monkeypatch):
     plan = net.plan_for(x)
     assert any(op[2] == 'fpn.add1' for op in plan.ops) and any(op[2] == 'fpn.add2' for op in plan.ops)
     for k in ('loc', 'conf_logits', 'mask', 'proto'):
-        assert torch.equal(got[k], ref[k]), k
+        assert (got[k] - ref[k]).abs().max().item() <= 4e-6 * max(1.0, ref[k].abs().max().item()), k
 
 
 def test_bilinear_add_kernel_matches_torch():

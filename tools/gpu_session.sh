@@ -22,7 +22,7 @@
 O=gpurun_out/$1; shift; mkdir -p $O
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
-BENCH="python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary"
+BENCH="python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary --no-calibration"
 for st in "$@"; do
   arg="${st#*:}"; [ "$arg" = "$st" ] && arg=""
   case "${st%%:*}" in pytest|pytestf|py) arg="${arg//+/ }" ;; *) arg="${arg//_/ }" ;; esac      # (+ stands for a space in pytest / pytestf / py
@@ -39,10 +39,12 @@ for st in "$@"; do
     bench) timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --layers $arg > $O/bench.json 2> $O/bench_layers.txt; head -1 $O/bench.json | cut -c1-600 ;;
     configs)
       timeout 300 python bench.py --batch 1 --steps 50 --no-cpu-baseline --no-secondary > $O/bench_b1.json 2>/dev/null; head -1 $O/bench_b1.json | cut -c1-200
-      for c in "yolact_base_config 16 r101_b16" "yolact_im700_config 8 im700_b8" "yolact_plus_resnet50_config 8 plus_b8" "yolact_darknet53_config 8 darknet_b8"; do
+      for c in "yolact_base_config 16 r101_b16" "yolact_im700_config 8 im700_b8" "yolact_darknet53_config 8 darknet_b8" "yolact_plus_base_config 8 plus_base_b8" "yolact_im400_config 8 im400_b8"; do
         set -- $c
         timeout 400 python bench.py --config $1 --batch $2 --steps 10 --no-cpu-baseline --no-secondary > $O/bench_$3.json 2>/dev/null; head -1 $O/bench_$3.json | cut -c1-200
       done
+      # configs[3] WITH its secondary lines (YOLACT++: batched FastMaskIoUNet in postprocess_batch, the reference FPS definition with two score tensors)
+      timeout 500 python bench.py --config yolact_plus_resnet50_config --batch 8 --steps 10 --no-cpu-baseline > $O/bench_plus_b8.json 2>/dev/null; head -1 $O/bench_plus_b8.json | cut -c1-200
       YOLACT_AMD_SPLIT=0 timeout 400 python bench.py --no-cpu-baseline --no-secondary > $O/bench_fp32only.json 2>/dev/null; head -1 $O/bench_fp32only.json | cut -c1-200
       YOLACT_AMD_SPLIT=1 timeout 400 python bench.py --no-cpu-baseline --no-secondary > $O/bench_bf16x3.json 2>/dev/null; head -1 $O/bench_bf16x3.json | cut -c1-200 ;;
     ab) # same-box A/B of the three arithmetics on configs[1] (box-to-box spread is larger than most single changes)
@@ -58,14 +60,24 @@ for r in (csv.DictReader(open(fs[0])) if fs else []):
     print('%-116s %8s %12s %10.0f %6.2f' % (r['Name'][:116], r['Calls'], r['TotalDurationNs'], float(r['AverageNs']), float(r['Percentage'])))
 PY
       done; head -12 $O/kernel_stats_streams1.txt | cut -c1-200 ;;
+    plusstats) # rocprofv3 kernel stats of the YOLACT++ step WITH postprocess (FastMaskIoUNet's launches: conv_direct_k / global_maxpool_k)
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $R/$O/plusstats -- bash -c "cd $R && python bench.py --config yolact_plus_resnet50_config --batch 8 --steps 10 --warmup 2 --with-postprocess --no-cpu-baseline --no-secondary --no-calibration" > $R/$O/plusstats.log 2>&1)
+      python - $O/plusstats > $O/kernel_stats_plus_with_postprocess.txt <<'PY'
+import csv, glob, sys
+fs = glob.glob(sys.argv[1] + '/**/*kernel_stats.csv', recursive=True)
+print('%-116s %8s %12s %10s %6s' % ('kernel', 'calls', 'total_ns', 'avg_ns', '%'))
+for r in (csv.DictReader(open(fs[0])) if fs else []):
+    print('%-116s %8s %12s %10.0f %6.2f' % (r['Name'][:116], r['Calls'], r['TotalDurationNs'], float(r['AverageNs']), float(r['Percentage'])))
+PY
+      grep -E "conv_direct|global_maxpool|lincomb|upsample|kernel " $O/kernel_stats_plus_with_postprocess.txt | cut -c1-200 ;;
     traffic)
-      CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary"
+      CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-calibration"
       (cd /tmp && YOLACT_AMD_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex "conv_igemm|pipe_h2_k" -f csv -d $R/$O/fetch -- bash -c "cd $R && $CMD" > $R/$O/fetch.log 2>&1)
       (cd /tmp && YOLACT_AMD_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --kernel-include-regex "conv_igemm|pipe_h2_k" -f csv -d $R/$O/write -- bash -c "cd $R && $CMD" > $R/$O/write.log 2>&1)
       python tools/traffic_summary.py $O/fetch $O/write > $O/traffic.json 2> $O/traffic.err; head -c 600 $O/traffic.json
       find $O -name "*counter_collection.csv" -size +4M -delete ;;
     pmc)
-      (cd /tmp && YOLACT_AMD_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --kernel-include-regex "conv_igemm|pipe_h2_k|wino|stem_pool" -f csv -d $R/$O/pmc1 -- bash -c "cd $R && python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary" > $R/$O/pmc1.log 2>&1)
+      (cd /tmp && YOLACT_AMD_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --kernel-include-regex "conv_igemm|pipe_h2_k|wino|stem_pool" -f csv -d $R/$O/pmc1 -- bash -c "cd $R && python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-calibration" > $R/$O/pmc1.log 2>&1)
       python tools/pmc_summary.py $O/pmc1 > $O/pmc_plan_p1.tsv 2> $O/pmc.err; head -20 $O/pmc_plan_p1.tsv | cut -c1-200
       find $O -name "*counter_collection.csv" -size +4M -delete ;;
     pmcw) # wave-level counters of the Winograd GEMM variants on proto.8 (one pass, counters only)

@@ -201,6 +201,7 @@ SYMBOLS = [
     ('ymi_workspace_bytes', C.c_int64, [_I, _P]),
     ('ymi_calib_mfma_f16', C.c_int, [_P, _I, _I, C.POINTER(C.c_double), _P]),
     ('ymi_calib_hbm_copy', C.c_int, [_P, _P, C.c_long, C.POINTER(C.c_double), _P]),
+    ('ymi_calib_l2_read', C.c_int, [_P, C.c_long, _I, _I, _P, C.POINTER(C.c_double), _P]),
     ('ymi_debug_set_trace', C.c_int, [_P, C.c_long]),
     ('ymi_prof_enable', C.c_int, [_I]),
     ('ymi_prof_count', C.c_int, []),

@@ -45,9 +45,38 @@ __global__ __launch_bounds__(256) void calib_copy_k(const f32x4 *__restrict__ sr
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
 }
 
+// L2-resident read stream: every block sweeps the same small buffer (1 MB: resident in each XCD's 4 MB L2 after the first sweep)
+// `iters` times with 16-byte loads, 4 independent accumulators per lane.  The GEMM tiles of this engine are bound by exactly this
+// path (global -> CU at L2-hit latency), which neither the MFMA loop nor the HBM copy above exercises.
+__global__ __launch_bounds__(256) void calib_l2_k(const f32x4 *__restrict__ src, int n4, int iters, float *out) {
+  f32x4 a0 = {}, a1 = {}, a2 = {}, a3 = {};
+  const int t = threadIdx.x, step = 256 * 4;
+  for (int it = 0; it < iters; ++it) {
+    // (the start offset rotates with the block so that the CUs of an XCD do not hit the same channel at the same time)
+    int i = (t + ((blockIdx.x * 37 + it) & 63) * 256) % n4;
+    for (int k = 0; k < n4 / step; ++k) {
+      a0 += src[i]; i += 256; if (i >= n4) i -= n4;
+      a1 += src[i]; i += 256; if (i >= n4) i -= n4;
+      a2 += src[i]; i += 256; if (i >= n4) i -= n4;
+      a3 += src[i]; i += 256; if (i >= n4) i -= n4;
+    }
+  }
+  const f32x4 s = (a0 + a1) + (a2 + a3);
+  if (s[0] + s[1] + s[2] + s[3] == 12345.678f) out[0] = s[0];
+}
+
 }  // namespace
 
 extern "C" {
+
+int ymi_calib_l2_read(const float *src, long n_floats, int blocks, int iters, float *out, double *bytes, void *stream) {
+  if (!src || !out) return YMI_ENULL;
+  if (n_floats < 4096 || (n_floats % 4096) || blocks < 1 || iters < 1 || (((uintptr_t)src) & 15)) return YMI_ESHAPE;
+  hipLaunchKernelGGL(calib_l2_k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)src, (int)(n_floats / 4), iters, out);
+  if (bytes) *bytes = 4.0 * (double)n_floats * iters * blocks;
+  return ymi_launch_status();
+}
+
 
 int ymi_calib_mfma_f16(float *out, int blocks, int iters, double *flops, void *stream) {
   if (!out) return YMI_ENULL;

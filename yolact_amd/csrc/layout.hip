@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void bilinear_nhwc_k(const float *__restrict__
 
 // FPN top-down sum as its own pass (yolact.py:332-334: x = F.interpolate(x, size=(h, w), mode=bilinear) + lat_layer(convout)):
 // y[b,oy,ox,:] += bilinear(x -> Ho x Wo)[b,oy,ox,:] IN PLACE, the interpolation in the epilogue form of csrc/conv_igemm.hip
-// (YMI_RES_BILINEAR: same coordinates, same expression), so lateral-conv launch + this pass == the fused launch bit for bit.  Raises
+// (YMI_RES_BILINEAR: same coordinates, same expression), so lateral-conv launch + this pass == the fused launch.  Raises
 // the magnitude-bound slot of the SUM (fp16x2 consumers scale by it).
 __global__ __launch_bounds__(256) void bilinear_add_k(const float *__restrict__ x, float *__restrict__ y, int Hi, int Wi, int C4, int Ho,
                                                        int Wo, float sh, float sw, long total, float *__restrict__ amax) {

@@ -567,8 +567,8 @@ class Plan:
     # lat_layers[i](C_j) depends only on backbone stage j (yolact.py:324-334); the top-down sum x_j = up(x_{j+1}) + lat(C_j) needs the
     # level above, i.e. the END of the backbone.  Fused in the lateral's epilogue (YMI_RES_BILINEAR) both sit on the critical path
     # behind C5; split, the lateral GEMMs of C3 / C4 run on stream B beside the later backbone stages — whose 35 x 35 / 18 x 18 launches
-    # leave a fifth to a third of the CUs idle — and only ymi_bilinear_add_nhwc_f32 (a 20 us stream) stays behind C5.  Bit-identical
-    # (same interpolation, same association).  MEASURED (session r5d, same box, alternating, profiles/r05_ab_runs.txt): 2011 - 2015
+    # leave a fifth to a third of the CUs idle — and only ymi_bilinear_add_nhwc_f32 (a 20 us stream) stays behind C5.  Same
+    # interpolation, same association (results differ only through the tile the residual-free lateral GEMM runs on).  MEASURED (session r5d, same box, alternating, profiles/r05_ab_runs.txt): 2011 - 2015
     # images/s with it against 2017 - 2028 without — the laterals slow the backbone launches they share the chip with by as much as
     # they save behind C5 (the finding of DESIGN 3.5 again: summed kernel time rises when streams overlap).  Hence OPT-IN:
     # YOLACT_AMD_EARLY_LAT=1; the default keeps the fused epilogue.
