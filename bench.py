@@ -69,7 +69,7 @@ def kernel_peak(name):
     bounded by the fp32 MFMA peak, the `...x3` tiles (fp32-class products as 6 bf16 MFMAs) by bf16 peak / 6, the `...h2`
     tiles (3 fp16 MFMAs) by fp16 peak / 3."""
     tile = name.split('<', 1)[1].split(',', 1)[0] if '<' in name else ''
-    return X3_PEAK_TFLOPS if tile.endswith('x3') else H2_PEAK_TFLOPS if (tile.endswith('h2') or tile.startswith('dcnp') or tile.startswith('ws')) \
+    return X3_PEAK_TFLOPS if tile.endswith('x3') else H2_PEAK_TFLOPS if (tile.endswith('h2') or tile.startswith('dcnp') or tile.startswith('ws') or tile.startswith('patch')) \
         else FP32_MFMA_PEAK_TFLOPS
 
 
@@ -133,6 +133,7 @@ def roofline(net, x, reps=3):
     # record kinds: 0/1/2 = one direct conv launch (loader id), 7 = a direct 1x1 launch on the pointwise loader (kernel
     # template LOADER 3); 3 / 4 = a whole Winograd F(2x2) / F(4x4) layer (input transform + 16- / 36-group GEMM + output
     # transform, ALGORITHMIC conv FLOPs); 5 / 6 = the Winograd GEMM launch alone (the FLOPs it executes).
+    # 14 = csrc/patch.hip (3x3 64 -> 64 from an LDS-resident input patch).
     # 11 = the weight-stationary streaming kernel (csrc/wstat.hip); 12 = a 1x1 layer fused into the previous layer's launch (its FLOPs, no
     # duration of its own); 13 = ymi_pointwise_chain_f32 (csrc/chain.hip: conv3 + shortcut + ReLU -> the next block's conv1).
     # 9 = the pipelined DCNv2 gather-GEMM (csrc/dcn.hip: pipe_h2_k<..., PLAIN = false>), 10 = the same kernel as an ordinary 3x3 / 1x1
@@ -181,7 +182,7 @@ def roofline(net, x, reps=3):
                 dd_ = descs[(li + 1) % nl]
                 nbytes += 4.0 * dd_.B * dd_.Ho * dd_.Wo * 64
         if kind.value not in (3, 4):
-            pk_ = (X3_PEAK_TFLOPS if tname.endswith('x3') else H2_PEAK_TFLOPS if (tname.endswith('h2') or tname.startswith('dcnp') or tname.startswith('ws'))
+            pk_ = (X3_PEAK_TFLOPS if tname.endswith('x3') else H2_PEAK_TFLOPS if (tname.endswith('h2') or tname.startswith('dcnp') or tname.startswith('ws') or tname.startswith('patch'))
                    else FP32_MFMA_PEAK_TFLOPS)
             t_m, t_h = fl.value / (pk_ * 1e12) * 1e3, nbytes / (HBM_PEAK_GBPS * 1e9) * 1e3
             bound_ms['mfma' if t_m >= t_h else 'hbm'] += max(t_m, t_h) / reps
@@ -194,6 +195,7 @@ def roofline(net, x, reps=3):
                 else 'pipe_h2_k<%s,DCNv2 gather>' % tname if kind.value == 9 \
                 else 'pipe_h2_k<%s,convolution>' % tname if kind.value == 10 \
                 else 'ws_h2_k<%s,convolution>' % tname if kind.value == 11 \
+                else 'patch3x3_c64_k<%s,convolution>' % tname if kind.value == 14 \
                 else 'chain_h2_k<conv3 + shortcut + ReLU -> next conv1, one launch>' if kind.value == 13 \
                 else 'conv_igemm_f32<%s,loader%d>' % (tname, 3 if kind.value == 7 else kind.value)
             la = layers.setdefault(names[li % nl], [0.0, fl.value, lkey])
@@ -206,6 +208,7 @@ def roofline(net, x, reps=3):
                 ('pipe_h2_k<%s,DCNv2 gather>' % tname) if kind.value == 9 else \
                 ('pipe_h2_k<%s,convolution>' % tname) if kind.value == 10 else \
                 ('ws_h2_k<%s,convolution>' % tname) if kind.value == 11 else \
+                ('patch3x3_c64_k<%s,convolution>' % tname) if kind.value == 14 else \
                 'chain_h2_k<pointwise chain>' if kind.value == 13 else \
                 'conv_igemm_f32<%s,loader%d>' % (tname, 3 if kind.value == 7 else kind.value)
             a = by_kernel.setdefault(key, [0.0, 0.0, 0, 0.0, 0.0, 0.0])

@@ -152,7 +152,11 @@ enum { YMI_DCNP_64x128 = 1, YMI_DCNP_64x128_W8 = 2, YMI_DCNP_64x64 = 3, YMI_DCNP
         * operand registers, no barrier in the loop.  BM x BN, _W4 / _W8 = waves per block (32 or 64 rows per wave).  The K range
         * of a block must fit 64 KB of LDS: ymi_conv_desc.split_k >= Kpad * BN / 16384 (YMI_EARG otherwise) */
        YMI_DCNP_WS_128x32_W4 = 20, YMI_DCNP_WS_256x32_W8 = 21, YMI_DCNP_WS_256x32_W4 = 22, YMI_DCNP_WS_512x32_W8 = 23,
-       YMI_DCNP_WS_128x64_W4 = 24, YMI_DCNP_WS_256x64_W8 = 25, YMI_DCNP_WS_256x64_W4 = 26, YMI_DCNP_WS_512x64_W8 = 27 };
+       YMI_DCNP_WS_128x64_W4 = 24, YMI_DCNP_WS_256x64_W8 = 25, YMI_DCNP_WS_256x64_W4 = 26, YMI_DCNP_WS_512x64_W8 = 27,
+       /* round 5, csrc/patch.hip: 3x3 / stride 1 / pad 1, 64 -> 64 channels (conv2 of the first ResNet stage, backbone.py:44-46), one
+        * dense output, no residual: a persistent block per CU owns 8 x 16 pixel output tiles, the 10 x 18 x 64 input patch lives in
+        * LDS as fp16 planes (loaded ONCE instead of once per filter tap) and the filters live in registers */
+       YMI_DCNP_PATCH_C64 = 28 };
 
 int ymi_abi_version(void);
 const char *ymi_strerror(int code);

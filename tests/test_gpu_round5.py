@@ -226,3 +226,81 @@ def test_native_executor_equals_the_python_loop(monkeypatch):
     t_nat, t_py = issue_ms(net), issue_ms(net2)
     print('host time to issue one batch-%d step: native executor %.3f ms, Python loop %.3f ms' % (meta['B'], t_nat, t_py))
     assert t_nat < t_py
+
+
+@pytest.mark.parametrize('case', [(2, 19, 23, 'bn_relu'), (1, 138, 138, 'bn_relu'), (3, 8, 16, 'bias'), (1, 5, 7, 'leaky'), (2, 40, 33, 'bn_relu')])
+def test_patch_kernel_matches_torch(case):
+    """csrc/patch.hip (YMI_DCNP_PATCH_C64): 3x3 / stride 1 / pad 1, 64 -> 64, the input patch of an 8 x 16 tile in LDS and the filters in
+    registers — against torch's fp32 convolution (ragged edge tiles, a map smaller than a tile, exactly one tile, more tiles than
+    blocks), with the magnitude bound it reports, and bit-reproducible."""
+    import torch.nn as nn
+    from gpu_utils import run_conv
+    from yolact_amd import _lib as L
+    B, H, W, mode = case
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    x = torch.randn(B, 64, H, W, generator=g) * 3.0
+    w = torch.randn(64, 64, 3, 3, generator=g) * 0.05
+    bias, bn, act = None, None, L.ACT_RELU
+    if mode == 'bn_relu':
+        bn = nn.BatchNorm2d(64).eval()
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5, generator=g); bn.bias.normal_(0, 0.1, generator=g)
+            bn.running_mean.normal_(0, 0.1, generator=g); bn.running_var.uniform_(0.5, 1.5, generator=g)
+    elif mode == 'bias':
+        bias, act = torch.randn(64, generator=g), L.ACT_NONE
+    else:
+        bias, act = torch.randn(64, generator=g), L.ACT_LEAKY01
+    tile = L.DCNP_PATCH_C64 | L.TILE_H2 | L.TILE_DCNP
+    got = run_conv(x, w, bias, bn, 1, 1, act, tile=tile)
+    amax = run_conv.last_amax[1]
+    with torch.no_grad():
+        ref = torch.nn.functional.conv2d(x.double(), w.double(), bias.double() if bias is not None else None, padding=1)
+        if bn is not None:
+            ref = bn.double()(ref)
+            bn.float()
+        ref = torch.relu(ref) if act == L.ACT_RELU else torch.nn.functional.leaky_relu(ref, 0.1) if act == L.ACT_LEAKY01 else ref
+    err = (got.double() - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+    assert err < 2e-6, err
+    assert abs(amax - got.abs().max().item()) <= 1e-6 * max(1.0, amax)
+    again = run_conv(x, w, bias, bn, 1, 1, act, tile=tile)
+    assert torch.equal(again, got)
+    # the tile is refused for anything but its shape (an explicit request a kernel cannot honour is an error, never another kernel)
+    with pytest.raises(RuntimeError):
+        run_conv(torch.randn(1, 64, 9, 9), torch.randn(64, 64, 3, 3), None, None, 2, 1, L.ACT_NONE, tile=tile)
+    with pytest.raises(RuntimeError):
+        run_conv(torch.randn(1, 128, 9, 9), torch.randn(64, 128, 3, 3), None, None, 1, 1, L.ACT_NONE, tile=tile)
+
+
+def test_patch_kernel_speed_on_the_layer_it_was_built_for():
+    """layer0.x.conv2 at batch 8 (138 x 138 x 64 -> 64): the patch kernel against the pipelined implicit-GEMM tile the shipped table
+    held for this shape (printed; the tuner decides what the plan runs)."""
+    import ctypes as C
+    from gpu_utils import DEV as D_
+    from yolact_amd import _lib as L
+    from yolact_amd.engine import Packed
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(8, 138, 138, 64, generator=g)).to(D_)
+    pk = Packed(torch.randn(64, 64, 3, 3, generator=g) * 0.05, None, None, 1, 1, None, D_)
+    y = torch.empty(8, 138, 138, 64, device=D_)
+    amax = torch.zeros(2 * 1024, device=D_)
+    L.check(L.lib().ymi_amax_f32(x.data_ptr(), x.numel(), amax.data_ptr(), L.stream_ptr()))
+    hp, sc2, winv = pk.h2()
+    out = {}
+    for name, tile in (('patch8x16c64', L.DCNP_PATCH_C64 | L.TILE_H2 | L.TILE_DCNP), ('dcnp128x64w8', L.DCNP_128x64_W8 | L.TILE_H2 | L.TILE_DCNP)):
+        d = L.ConvDesc()
+        d.x, d.w, d.B, d.H, d.W, d.Cin, d.ldx, d.Ho, d.Wo, d.Cout = x.data_ptr(), pk.w.data_ptr(), 8, 138, 138, 64, 64, 138, 138, 64
+        d.kh, d.kw, d.stride, d.pad, d.Kpad, d.nseg, d.tile = 3, 3, 1, 1, pk.Kpad, 1, tile
+        d.seg[0] = L.ConvSeg(0, 64, L.ACT_RELU, 64, 138 * 138 * 64, y.data_ptr())
+        d.w_h2, d.scale_h2, d.winv_h2, d.x_amax, d.y_amax = hp.data_ptr(), sc2.data_ptr(), winv.data_ptr(), amax.data_ptr(), amax.data_ptr() + 4096
+        s = L.stream_ptr()
+        for _ in range(3):
+            L.check(L.lib().ymi_conv2d_nhwc_f32(C.byref(d), s))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            L.check(L.lib().ymi_conv2d_nhwc_f32(C.byref(d), s))
+        e1.record(); e1.synchronize()
+        out[name] = (e0.elapsed_time(e1) / 20, y.clone())
+        print('%-14s %.4f ms  %.1f TFLOP/s' % (name, out[name][0], 2 * 8 * 138 * 138 * 64 * 576 / out[name][0] / 1e9))
+    a, b = out['patch8x16c64'][1], out['dcnp128x64w8'][1]
+    assert (a - b).abs().max().item() < 2e-6 * max(1.0, b.abs().max().item())

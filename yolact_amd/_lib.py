@@ -47,7 +47,9 @@ DCNP_PLAIN_ONLY = (14, 15, 16, 17, 18, 19)     # 64x64 wave tiles, 32-column til
 WS_TILES = {20: 'ws128x32w4', 21: 'ws256x32w8', 22: 'ws256x32w4', 23: 'ws512x32w8',
             24: 'ws128x64w4', 25: 'ws256x64w8', 26: 'ws256x64w4', 27: 'ws512x64w8'}
 DCNP_WS_128x32_W4, DCNP_WS_512x64_W8 = 20, 27
-for _t, _n in list(DCNP_TILES.items()) + list(WS_TILES.items()):
+DCNP_PATCH_C64 = 28                 # csrc/patch.hip: 3x3 / s1 / p1, 64 -> 64, input patch in LDS, filters in registers
+PATCH_TILES = {28: 'patch8x16c64'}
+for _t, _n in list(DCNP_TILES.items()) + list(WS_TILES.items()) + list(PATCH_TILES.items()):
     TILE_NAMES[_t | TILE_H2 | TILE_DCNP] = _n
 WINO_PLANES = 1024                  # tune-table flag on a Winograd GEMM tile id: V written as fp16x2 planes (ymi_wino_desc.v_planes)
 KSPLIT_TILES = (6, 7, 8, 13, 14, 15, 6 | 32, 7 | 32, 8 | 32, 6 | 64, 7 | 64, 8 | 64, 13 | 64, 14 | 64, 15 | 64)   # different (still deterministic) fp32 summation order than the unsplit tiles

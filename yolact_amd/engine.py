@@ -1442,6 +1442,9 @@ class Plan:
                     cands = cands + self.dcnp_candidates(d, dcn=True)
                 if not is_dcn and h2_ and self.pipe and self._pipe_ok(d):   # the same pipelined kernel as an ordinary convolution
                     cands = cands + self.dcnp_candidates(d) + self.ws_candidates(d)     # (+ the streaming kernel for narrow outputs)
+                    if ((d.kh, d.kw, d.stride, d.pad, d.Cin, d.Cout) == (3, 3, 1, 1, 64, 64) and d.res_mode == L.RES_NONE
+                            and os.environ.get('YOLACT_AMD_PATCH', '1') == '1'):
+                        cands = cands + [L.DCNP_PATCH_C64 | L.TILE_H2 | L.TILE_DCNP]    # csrc/patch.hip: the input patch in LDS, filters in registers
                 if not is_dcn and self._splitk_ok(d) and self.splitk:
                     # split-K candidates: big tiles whose grid alone cannot fill the chip, K cut 2 / 4 ways
                     x3 = spflag
