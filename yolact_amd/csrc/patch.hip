@@ -12,9 +12,18 @@
 // csrc/chain.hip) and the four 16-pixel rows 4 i .. 4 i + 3 of the tile.  v_mfma_f32_16x16x32_f16 issued as W X^T: a lane ends with
 // four consecutive output channels of one pixel (float4 epilogue, no transposition).  The next tile's patch is requested before the
 // current tile's MFMAs and written to the other LDS buffer behind them: one barrier per tile.
+// MEASURED (tools/patch_probe.py, profiles/r05_patch_probe.txt): 0.0526 ms at batch 8 against 0.0572 for the implicit-GEMM tile of the
+// shipped table (0.090 vs 0.111 at batch 16) — a gain, not the 2x the traffic arithmetic above promises: with the filters in 144
+// registers a wave cannot ALSO hold the next patch in flight, convert it and run its MFMAs without everything serialising inside the
+// one wave a SIMD has room for (request -> 432 MFMAs -> epilogue -> convert + publish -> barrier: ~8.5 us per tile, 3.5 of them
+// MFMA).  Three schedules were measured: 8 waves x 4 rows at two per SIMD (no room to prefetch fragments: ds_read -> wait -> MFMA in
+// the ISA, 0.0522), 4 waves x 8 rows with register double-buffered fragments (this file, 0.0526), the same with stores deferred by
+// one tile (0.0555).  What is left is splitting the block into producer and consumer waves, which needs the consumer inside 256
+// registers next to its 144 of filters.  The tuner takes the kernel where it wins.
 // Arithmetic: the fp16x2 scheme of the engine (tensor scale from x_amax, h*l + l*h + h*h on the fp16 pipe, fp32 accumulate), K order
 // tap-major like engine.Packed — the filter planes of Packed.h2() are used unchanged.
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 #include "../../include/yolact_amd.h"
 
@@ -27,14 +36,15 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int C = 64, NW = 8, NT = 64 * NW;
+constexpr int C = 64, NW = 4, NT = 64 * NW;
 constexpr int TH = 8, TW = 16, PH = TH + 2, PW = TW + 2, PPX = PH * PW;      // output tile, input patch (180 pixels)
-constexpr int RS = 2 * C + 16;              // bytes per patch pixel in a plane: 128 + 16 (the 16 lanes of a read phase hit 16 bank groups)
-constexpr int PLANE = PPX * RS, BUF = 2 * PLANE;                             // 25 920 B per plane, two planes per buffer
-constexpr int NLOAD = (PPX * (C / 4) + NT - 1) / NT;                          // float4 loads per thread per patch: 6 (2880 / 512) ...
-constexpr int NHALF = NLOAD / 2;                                              // ... requested and published in two halves of 3 (registers)
-static_assert(NLOAD == 2 * NHALF, "patch loads split in two halves");
-constexpr int OFF_EP = 2 * BUF;             // per-(wave, lane group) epilogue constants behind the two patch buffers: 8 x 4 x 32 B
+// bytes per patch pixel in a plane: 128 + 32.  A ds_read_b128 is served in four groups of 16 lanes that MIX the lane's pixel (lr) and
+// its k group (g): {0-3, 12-15, 20-27}, ...; with a pitch of 160 bytes the 16-byte slot index (10 lr + g) mod 16 is a permutation of
+// 0 .. 15 inside every group (conflict-free); with the 144 bytes of csrc/chain.hip's K = 64 plane seven of the eight g = 1 lanes of
+// a group land on the banks of a g = 0 lane (2-way: first version of this kernel)
+constexpr int RS = 2 * C + 32;
+constexpr int PLANE = PPX * RS, BUF = 2 * PLANE;                             // 28 800 B per plane, two planes per buffer
+constexpr int NLOAD = (PPX * (C / 4) + NT - 1) / NT;                          // float4 loads per thread per patch: 12 (2880 / 256)
 constexpr int NCH = 9 * (C / 32);           // K chunks of 32: (tap, channel half) = 18
 
 struct PatchParams {
@@ -45,12 +55,18 @@ struct PatchParams {
   unsigned w_plane, x_bytes, y_bytes;
 };
 
-__global__ __launch_bounds__(NT) void patch3x3_c64_k(const PatchParams p) {
+struct Frag { f16x8 h, l; };
+
+// Four waves, ONE per SIMD (up to 512 registers each): wave q owns output channels 16 q .. 16 q + 15 — 144 VGPRs of filter fragments —
+// and ALL eight rows of the tile: eight independent accumulators, so consecutive MFMAs never depend on each other, and room for a
+// second set of activation fragments: the LDS reads of K chunk s + 1 are issued before the 24 MFMAs of chunk s (explicit double
+// buffering in registers).  The first version ran eight waves at two per SIMD inside 256 registers: no room to prefetch, every
+// chunk was ds_read -> s_waitcnt -> MFMA (seen in the ISA), 0.052 ms for the 0.058 of the implicit-GEMM tile.
+__global__ __launch_bounds__(NT, 1) void patch3x3_c64_k(const PatchParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  __shared__ __attribute__((aligned(16))) char lds[2 * BUF + NW * 4 * 32];
-  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
+  const int t = threadIdx.x, lane = t & 63, q = __builtin_amdgcn_readfirstlane(t >> 6);
   const int lr = lane & 15, g = lane >> 4;
-  const int q = wave & 3, ih = wave >> 2;              // this wave's 16 output channels (16 q ..) and its four tile rows (4 ih ..)
   constexpr unsigned OOB = 0x80000000u;
   float sA, invA;
   ymi_h2_scale(ymi_amax_read(p.x_amax), sA, invA);
@@ -64,16 +80,11 @@ __global__ __launch_bounds__(NT) void patch3x3_c64_k(const PatchParams p) {
     wh[c] = *reinterpret_cast<const f16x8 *>(src);
     wl[c] = *reinterpret_cast<const f16x8 *>(src + p.w_plane);
   }
-  // epilogue constants of this lane's four channels (16 q + 4 g ..): parked in LDS, re-read per tile (8 registers the filters need)
-  if (lr == 0) {
-    f32x4 sc, bi = {0.f, 0.f, 0.f, 0.f};
+  f32x4 sc, bi = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      sc[e] = p.scale_h2[16 * q + 4 * g + e] * invA;   // folded BN scale / filter-row scale, times the exact 1 / sA
-      if (p.bias) bi[e] = p.bias[16 * q + 4 * g + e];
-    }
-    *reinterpret_cast<f32x4 *>(lds + OFF_EP + (wave * 4 + g) * 32) = sc;
-    *reinterpret_cast<f32x4 *>(lds + OFF_EP + (wave * 4 + g) * 32 + 16) = bi;
+  for (int e = 0; e < 4; ++e) {
+    sc[e] = p.scale_h2[16 * q + 4 * g + e] * invA;     // folded BN scale / filter-row scale, times the exact 1 / sA
+    if (p.bias) bi[e] = p.bias[16 * q + 4 * g + e];
   }
   const float slope = p.act == YMI_ACT_RELU ? 0.f : (p.act == YMI_ACT_LEAKY01 ? 0.1f : 1.f);
 
@@ -83,15 +94,14 @@ __global__ __launch_bounds__(NT) void patch3x3_c64_k(const PatchParams p) {
 
   // patch loads: thread t takes float4 number t + NT * i of the patch (pixel (t + NT i) / 16, channels 4 ((t + NT i) % 16) ..);
   // pixels outside the image (the convolution's zero padding) and slots past the patch are out-of-bounds buffer offsets: zeros
-  auto request = [&](int tile, auto half_c, f32x4 (&v)[NHALF]) {
-    constexpr int HALF = decltype(half_c)::value;
+  auto request = [&](int tile, f32x4 (&v)[NLOAD]) {
     const bool live = tile < p.ntiles;
     const int b = tile / per_img, r = tile - b * per_img;
     const int ty = r / p.tiles_x, tx = r - ty * p.tiles_x;
     const int y0 = ty * TH - 1, x0 = tx * TW - 1;
 #pragma unroll
-    for (int i = 0; i < NHALF; ++i) {
-      const int idx = t + NT * (i + HALF * NHALF), px = idx >> 4, cg = idx & 15;
+    for (int i = 0; i < NLOAD; ++i) {
+      const int idx = t + NT * i, px = idx >> 4, cg = idx & 15;
       const int py = px / PW, pxx = px - py * PW;
       const int yy = y0 + py, xx = x0 + pxx;
       const bool in = live && px < PPX && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
@@ -99,11 +109,10 @@ __global__ __launch_bounds__(NT) void patch3x3_c64_k(const PatchParams p) {
       v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0));
     }
   };
-  auto publish = [&](const f32x4 (&v)[NHALF], auto half_c, char *buf) {
-    constexpr int HALF = decltype(half_c)::value;
+  auto publish = [&](const f32x4 (&v)[NLOAD], char *buf) {
 #pragma unroll
-    for (int i = 0; i < NHALF; ++i) {
-      const int idx = t + NT * (i + HALF * NHALF), px = idx >> 4, cg = idx & 15;
+    for (int i = 0; i < NLOAD; ++i) {
+      const int idx = t + NT * i, px = idx >> 4, cg = idx & 15;
       if (px < PPX) {
         const f32x4 s = v[i] * sA;
         f16x4 h4, l4;
@@ -123,61 +132,64 @@ __global__ __launch_bounds__(NT) void patch3x3_c64_k(const PatchParams p) {
 
   float am = 0.f;
   const int grid = (int)gridDim.x;
-  using H0 = std::integral_constant<int, 0>;
-  using H1 = std::integral_constant<int, 1>;
-  f32x4 ld[NHALF];
+  f32x4 ld[NLOAD];
   int tile = blockIdx.x;
-  request(tile, H0{}, ld);
-  publish(ld, H0{}, lds);
-  request(tile, H1{}, ld);
-  publish(ld, H1{}, lds);
+  request(tile, ld);
+  publish(ld, lds);
   PATCH_BARRIER();
   for (int k = 0; tile < p.ntiles; tile += grid, ++k) {
     const char *const cur = lds + (k & 1) * BUF;
     char *const nxt = lds + ((k + 1) & 1) * BUF;          // last read one iteration ago: free for the whole of this one
-    request(tile + grid, H0{}, ld);                      // first half of the next patch: in flight during taps 0 .. 3
-    // ---- 18 K chunks x 4 tile rows: B operand = patch pixel (4 ih + rb + ky, lr + kx), channels 32 c + 8 g .. + 7 -----------------
-    f32x4 acc[4];
+    request(tile + grid, ld);                            // the next patch: in flight during this tile's MFMAs
+    // ---- 18 K chunks x 8 tile rows: B operand = patch pixel (rb + ky, lr + kx), channels 32 c + 8 g .. + 7 ---------------------------
+    f32x4 acc[TH];
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto taps = [&](auto t0_c, auto t1_c) {
+    for (int rb = 0; rb < TH; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const char *const lane_base = cur + lr * RS + g * 16;
+    auto load_chunk = [&](int ch, Frag (&f)[TH]) {        // chunk = 2 tap + c
+      const int tap = ch >> 1, c = ch & 1, ky = tap / 3, kx = tap - 3 * ky;
 #pragma unroll
-      for (int tap = decltype(t0_c)::value; tap < decltype(t1_c)::value; ++tap) {
-        const int ky = tap / 3, kx = tap - 3 * ky;
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-          for (int rp = 0; rp < 2; ++rp) {              // two tile rows at a time (fragment registers), three products each
-            f16x8 xh[2], xl[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-              const char *src = cur + ((4 * ih + 2 * rp + u + ky) * PW + lr + kx) * RS + c * 64 + g * 16;
-              xh[u] = *reinterpret_cast<const f16x8 *>(src);
-              xl[u] = *reinterpret_cast<const f16x8 *>(src + PLANE);
-            }
-#pragma unroll
-            for (int pr = 0; pr < 3; ++pr)              // product-major: consecutive MFMAs belong to different accumulators
-#pragma unroll
-              for (int u = 0; u < 2; ++u)
-                acc[2 * rp + u] = ymi_mfma16(pr == 0 ? wl[2 * tap + c] : wh[2 * tap + c], pr == 1 ? xl[u] : xh[u], acc[2 * rp + u]);
-          }
+      for (int rb = 0; rb < TH; ++rb) {
+        const char *src = lane_base + ((rb + ky) * PW + kx) * RS + c * 64;
+        f[rb].h = *reinterpret_cast<const f16x8 *>(src);
+        f[rb].l = *reinterpret_cast<const f16x8 *>(src + PLANE);
       }
     };
-    taps(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
-    publish(ld, H0{}, nxt);
-    request(tile + grid, H1{}, ld);                      // second half: in flight during taps 4 .. 8
-    taps(std::integral_constant<int, 4>{}, std::integral_constant<int, 9>{});
-    // ---- epilogue: lane = pixel (row 4 ih + rb, column lr) x channels 16 q + 4 g .. + 3 -----------------------------------------------
+    // MFMAs through the plain builtin, accumulating IN PLACE (vDst == SrcC is the one overlap the hardware handles).  The hazard of
+    // csrc/common.h — hipcc placing an MFMA's destination over a source operand that dies at the instruction — is closed differently
+    // from ymi_mfma16 (whose per-instruction register constraints made the compiler shuttle every accumulator through a[0:3] here:
+    // 4 000 v_accvgpr moves, seen in the ISA): the filter fragments live for the whole kernel, and the activation fragments of a
+    // chunk are kept alive until its last MFMA has been issued (the empty asm below), so no destination can land on them.
+    // tools/check_mfma_overlap.py verifies the built object.
+    auto mma_chunk = [&](int ch, const Frag (&f)[TH]) {
+#pragma unroll
+      for (int pr = 0; pr < 3; ++pr)                      // product-major: eight independent accumulators between dependent MFMAs
+#pragma unroll
+        for (int rb = 0; rb < TH; ++rb)
+          acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pr == 0 ? wl[ch] : wh[ch], pr == 1 ? f[rb].l : f[rb].h, acc[rb], 0, 0, 0);
+#pragma unroll
+      for (int rb = 0; rb < TH; ++rb) asm volatile("" ::"v"(f[rb].h), "v"(f[rb].l));
+    };
+    Frag fa[TH], fb[TH];
+    load_chunk(0, fa);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch += 2) {
+      load_chunk(ch + 1, fb);
+      mma_chunk(ch, fa);
+      if (ch + 2 < NCH) load_chunk(ch + 2, fa);
+      mma_chunk(ch + 1, fb);
+    }
+    // ---- epilogue: lane = pixel (row rb, column lr) x channels 16 q + 4 g .. + 3 ------------------------------------------------------
+    // (tried: forming the values here and storing them during the NEXT tile's MFMAs, so that the next tile's fragment loads do not
+    // wait for these stores to complete — the s_waitcnt vmcnt at the top of the loop in the ISA; measured 0.0555 against 0.0526 ms)
     {
       const int b = tile / per_img, r = tile - b * per_img;
       const int ty = r / p.tiles_x, tx = r - ty * p.tiles_x;
       const int ox = tx * TW + lr;
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) {
-        const int oy = ty * TH + 4 * ih + rb;
+      for (int rb = 0; rb < TH; ++rb) {
+        const int oy = ty * TH + rb;
         const bool ok = oy < p.H && ox < p.W;
-        const f32x4 sc = *reinterpret_cast<const f32x4 *>(lds + OFF_EP + (wave * 4 + g) * 32);
-        const f32x4 bi = *reinterpret_cast<const f32x4 *>(lds + OFF_EP + (wave * 4 + g) * 32 + 16);
         f32x4 v = acc[rb] * sc + bi;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], slope * v[e]);
@@ -186,7 +198,7 @@ __global__ __launch_bounds__(NT) void patch3x3_c64_k(const PatchParams p) {
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, off, 0, 0);
       }
     }
-    publish(ld, H1{}, nxt);
+    publish(ld, nxt);                                    // the next tile's patch: its buffer was last read one iteration ago
     PATCH_BARRIER();
   }
 #undef PATCH_BARRIER
