@@ -1410,8 +1410,11 @@ class Plan:
             skey = str(key) + ('|x3' if split_ else '|h2' if h2_ else '')
             key = key + (('wide',) if wide else ())
             if key not in cache and skey in disk:
-                if self._apply_choice(fn, dptr, where, disk[skey], s) == 0:   # a stale / foreign entry must not make every forward raise
-                    cache[key] = int(disk[skey])
+                v_ = int(disk[skey])
+                patch_off = ((v_ & 255) == (L.DCNP_PATCH_C64 | L.TILE_H2 | L.TILE_DCNP) and os.environ.get('YOLACT_AMD_PATCH', '1') != '1')
+                # (YOLACT_AMD_PATCH=0: the A/B switch of csrc/patch.hip — a table entry that names it counts as a miss)
+                if not patch_off and self._apply_choice(fn, dptr, where, disk[skey], s) == 0:   # a stale / foreign entry must not make every forward raise
+                    cache[key] = v_
             if key not in cache:
                 self.tune_misses += 1
                 if not measure:
