@@ -270,6 +270,68 @@ __global__ __launch_bounds__(256) void conv_direct_k(const float *__restrict__ x
   }
 }
 
+// The first layers of FastMaskIoUNet at BATCH scale (round 5: postprocess_batch runs the net once over all B x cap masks — 800 masks of
+// 138 x 138 at batch 8): Cin x Cout = 1 x 8, 8 x 16, 16 x 32, 3x3 / stride 2 / unpadded.  conv_direct_k above spends a thread per
+// (pixel, 4 output channels) with scalar activation loads and run-time loops: 150 us per layer.  Here a thread owns ONE output
+// pixel and ALL its output channels (<= 32 accumulators in registers), the filters sit in LDS as [tap][cin][cout] and are read as
+// wave-uniform broadcasts, the pixel's input channels arrive as float4s: the layers become the bandwidth streams they are.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void conv_direct_small_k(const float *__restrict__ x, const float *__restrict__ w,
+                                                            const float *__restrict__ bias, float *__restrict__ y, int H, int W, int Ho,
+                                                            int Wo, int kh, int kw, int stride, int pad, int relu, unsigned total) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];
+  const int nw = kh * kw * CIN * COUT;
+  for (int i = threadIdx.x; i < nw; i += 256) wl[i] = w[i];
+  __syncthreads();
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const unsigned r = i / (unsigned)Wo, bu = r / (unsigned)Ho;
+    const int ox = (int)(i - r * (unsigned)Wo), oy = (int)(r - bu * (unsigned)Ho);
+    f32x4 acc[COUT / 4];
+#pragma unroll
+    for (int n = 0; n < COUT / 4; ++n)
+      acc[n] = bias ? *reinterpret_cast<const f32x4 *>(bias + 4 * n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ky = 0; ky < kh; ++ky) {
+      const int iy = oy * stride - pad + ky;
+      if ((unsigned)iy >= (unsigned)H) continue;
+      for (int kx = 0; kx < kw; ++kx) {
+        const int ix = ox * stride - pad + kx;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        const float *xp = x + ((size_t)(bu * (unsigned)H + (unsigned)iy) * (unsigned)W + (unsigned)ix) * CIN;
+        float xv[CIN];
+        if constexpr (CIN % 4 == 0) {
+#pragma unroll
+          for (int c = 0; c < CIN / 4; ++c) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(xp + 4 * c);
+            xv[4 * c] = v[0]; xv[4 * c + 1] = v[1]; xv[4 * c + 2] = v[2]; xv[4 * c + 3] = v[3];
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < CIN; ++c) xv[c] = xp[c];
+        }
+        const float *wt = wl + (ky * kw + kx) * CIN * COUT;
+#pragma unroll
+        for (int c = 0; c < CIN; ++c)
+#pragma unroll
+          for (int n = 0; n < COUT / 4; ++n) {
+            const f32x4 wv = *reinterpret_cast<const f32x4 *>(wt + c * COUT + 4 * n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[n][e] = __builtin_fmaf(xv[c], wv[e], acc[n][e]);
+          }
+      }
+    }
+    float *yp = y + (size_t)i * COUT;
+#pragma unroll
+    for (int n = 0; n < COUT / 4; ++n) {
+      f32x4 v = acc[n];
+      if (relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];
+      }
+      *reinterpret_cast<f32x4 *>(yp + 4 * n) = v;
+    }
+  }
+}
+
 // y[b,c] = max over the HW positions of x[b,:,c]   (F.max_pool2d with kernel = full map)
 __global__ void global_max_k(const float *__restrict__ x, float *__restrict__ y, int HW, int C, long total) {
   const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
@@ -290,6 +352,24 @@ int ymi_conv2d_direct_nhwc_f32(const float *x, const float *w, const float *bias
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0) return YMI_EARG;
   if (Ho != (H + 2 * pad - kh) / stride + 1 || Wo != (W + 2 * pad - kw) / stride + 1) return YMI_ESHAPE;
   const int Co4 = (Cout + 3) / 4;
+  {   // the pixel-per-thread kernel for the narrow first layers of FastMaskIoUNet (filters in LDS; everything 16-byte aligned)
+    const long px = (long)B * Ho * Wo;
+    const size_t lds = (size_t)kh * kw * Cin * Cout * sizeof(float);
+    const bool aligned = !((((uintptr_t)x) | ((uintptr_t)w) | ((uintptr_t)y) | ((uintptr_t)bias)) & 15);
+    if (aligned && px < (1L << 31) && lds <= 48 * 1024 && (long)B * H * W * Cin < (1L << 32)) {
+      const int g = grid_for(px);
+#define YMI_SMALL(CI, CO)                                                                                                        \
+  if (Cin == CI && Cout == CO) {                                                                                                 \
+    hipLaunchKernelGGL((conv_direct_small_k<CI, CO>), dim3(g), dim3(256), lds, (hipStream_t)stream, x, w, bias, y, H, W, Ho, Wo, kh, \
+                       kw, stride, pad, relu, (unsigned)px);                                                                     \
+    return ymi_launch_status();                                                                                                  \
+  }
+      YMI_SMALL(1, 8)
+      YMI_SMALL(8, 16)
+      YMI_SMALL(16, 32)
+#undef YMI_SMALL
+    }
+  }
   const long total = (long)B * Ho * Wo * Co4;
   hipLaunchKernelGGL(conv_direct_k, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, H, W, Cin,
                      Ho, Wo, Cout, Co4, kh, kw, stride, pad, relu, total);

@@ -10,6 +10,7 @@ libyolact_amd.so and replays it on the current HIP stream.  CPU tensors are reje
 """
 from __future__ import annotations
 
+import ctypes as C_
 import os
 import sys
 import threading
@@ -231,6 +232,7 @@ class Yolact(nn.Module):
         key = ('maskiou', dev)
         packed = self._plans.get(key)
         if packed is None:
+            from .engine import Packed
             packed = []
             for m in self.maskiou_net.maskiou_net:
                 if isinstance(m, nn.Conv2d):
@@ -238,18 +240,32 @@ class Yolact(nn.Module):
                     co4 = (Cout + 3) // 4 * 4
                     w = torch.zeros(kh * kw * Cin, co4, device=dev)
                     w[:, :Cout] = m.weight.detach().float().permute(2, 3, 1, 0).reshape(kh * kw * Cin, Cout)
+                    # the wide layers (Cin % 32 == 0: 32 -> 64, 64 -> 128, the 1x1 128 -> 80) also get the conv engine's packing:
+                    # at batch scale (postprocess_batch: B x cap masks at once) they run as exact-fp32 MFMA GEMMs
+                    # (ymi_conv2d_nhwc_f32, heuristic tile) instead of the thread-per-pixel kernel — round 5: the six direct
+                    # launches averaged 150 us each for 800 masks (profiles/r05_kernel_stats_plus_with_postprocess.txt)
+                    pk = Packed(m.weight, m.bias, None, m.stride[0], m.padding[0], None, dev) if (Cin % 32 == 0 and Cout % 4 == 0) else None
                     packed.append((w.contiguous(), m.bias.detach().float().contiguous(), Cin, Cout, kh, kw,
-                                   m.stride[0], m.padding[0]))
+                                   m.stride[0], m.padding[0], pk))
             self._plans[key] = packed
         N, H, W = masks_lo.shape
         x = masks_lo.contiguous()          # [N,H,W,1] NHWC with one channel
         with torch.cuda.device(dev):
             s = L.stream_ptr()
-            for (w, b, Cin, Cout, kh, kw, stride, pad) in packed:
+            for (w, b, Cin, Cout, kh, kw, stride, pad, pk) in packed:
                 Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
                 y = torch.empty(N, Ho, Wo, Cout, device=dev)
-                L.check(lib.ymi_conv2d_direct_nhwc_f32(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), N, H, W,
-                                                       Cin, Ho, Wo, Cout, kh, kw, stride, pad, 1, s), 'maskiou conv')
+                if pk is not None:       # (ONE fixed unsplit tile whatever N is: the K summation order — hence every bit — is the same
+                                         #  for one image's masks and for a whole batch's: postprocess_batch == postprocess row by row)
+                    d = L.ConvDesc()
+                    d.x, d.w, d.bias = x.data_ptr(), pk.w.data_ptr(), pk.bias.data_ptr()
+                    d.B, d.H, d.W, d.Cin, d.ldx, d.Ho, d.Wo, d.Cout = N, H, W, Cin, Cin, Ho, Wo, Cout
+                    d.kh, d.kw, d.stride, d.pad, d.Kpad, d.nseg, d.tile = kh, kw, stride, pad, pk.Kpad, 1, L.TILE_64x64
+                    d.seg[0] = L.ConvSeg(0, Cout, L.ACT_RELU, Cout, Ho * Wo * Cout, y.data_ptr())
+                    L.check(lib.ymi_conv2d_nhwc_f32(C_.byref(d), s), 'maskiou conv (engine)')
+                else:
+                    L.check(lib.ymi_conv2d_direct_nhwc_f32(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), N, H, W,
+                                                           Cin, Ho, Wo, Cout, kh, kw, stride, pad, 1, s), 'maskiou conv')
                 x, H, W = y, Ho, Wo
             out = torch.empty(N, x.shape[3], device=dev)
             L.check(lib.ymi_global_maxpool_nhwc_f32(x.data_ptr(), out.data_ptr(), N, H * W, x.shape[3], s), 'maskiou max')
