@@ -526,6 +526,9 @@ def cpu_baseline(sd, size, batch=8, budget_s=14.0):
     return {'value': round(med[best], 3), 'unit': 'images/s', 'cores': best, 'threads': best, 'host_logical_cpus': ncpu,
             'cpus_in_affinity_mask': naff, 'kind': 'port',
             'thread_sweep_images_per_s': {str(k): v for k, v in sweep.items()},
+            'scaling_note': ('torch-CPU (oneDNN) does not scale past %d threads on this workload on this host: the sweep %s stops where more '
+                             'threads hurt; `cores` is the thread count of the best MEDIAN, not the host\'s %d logical CPUs'
+                             % (best, {k: v for k, v in sweep.items()}, ncpu)),
             'timed_runs_images_per_s': {str(k): v for k, v in runs.items()},
             'sample': 'median of 3 batches of %d (= the timed workload, %dx%d) forward+Detect through oracle/yolact_oracle.py at '
                       'each of the two best thread counts of a sweep over the same batch (%d + %d batches, %.0f s of host time '

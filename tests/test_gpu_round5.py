@@ -304,3 +304,29 @@ def test_patch_kernel_speed_on_the_layer_it_was_built_for():
         print('%-14s %.4f ms  %.1f TFLOP/s' % (name, out[name][0], 2 * 8 * 138 * 138 * 64 * 576 / out[name][0] / 1e9))
     a, b = out['patch8x16c64'][1], out['dcnp128x64w8'][1]
     assert (a - b).abs().max().item() < 2e-6 * max(1.0, b.abs().max().item())
+
+
+@pytest.mark.parametrize('case', [(5, 1, 8, 138, 138, 2, 0), (3, 8, 16, 68, 68, 2, 0), (4, 16, 32, 33, 33, 2, 0), (2, 8, 16, 9, 11, 1, 1),
+                                  (2, 32, 64, 16, 16, 2, 0), (1, 4, 12, 7, 9, 1, 1)])
+def test_small_direct_convolution_matches_torch(case):
+    """ymi_conv2d_direct_nhwc_f32: the pixel-per-thread kernel with LDS-resident filters that FastMaskIoUNet's narrow layers take at
+    batch scale (1 -> 8, 8 -> 16, 16 -> 32; yolact.py:363-375, data/config.py:785-791: 3x3 / stride 2 / unpadded, also checked padded /
+    stride 1), and the general kernel every other shape still takes — against torch's fp32 convolution."""
+    import ctypes as C
+    from yolact_amd import _lib as L
+    N, Cin, Cout, H, W, stride, pad = case
+    g = torch.Generator().manual_seed(Cin * 100 + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    wt = torch.randn(Cout, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    Ho, Wo = (H + 2 * pad - 3) // stride + 1, (W + 2 * pad - 3) // stride + 1
+    co4 = (Cout + 3) // 4 * 4
+    wp = torch.zeros(9 * Cin, co4)
+    wp[:, :Cout] = wt.permute(2, 3, 1, 0).reshape(9 * Cin, Cout)
+    xd, wd, bd = x.permute(0, 2, 3, 1).contiguous().to(DEV), wp.to(DEV), b.to(DEV)
+    y = torch.full((N, Ho, Wo, Cout), float('nan'), device=DEV)
+    L.check(L.lib().ymi_conv2d_direct_nhwc_f32(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), N, H, W, Cin, Ho, Wo, Cout, 3, 3,
+                                               stride, pad, 1, L.stream_ptr()))
+    ref = torch.relu(torch.nn.functional.conv2d(x.double(), wt.double(), b.double(), stride, pad)).permute(0, 2, 3, 1)
+    err = (y.cpu().double() - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+    assert err < 2e-6 and not torch.isnan(y).any(), err
