@@ -12,14 +12,16 @@
 // csrc/chain.hip) and the four 16-pixel rows 4 i .. 4 i + 3 of the tile.  v_mfma_f32_16x16x32_f16 issued as W X^T: a lane ends with
 // four consecutive output channels of one pixel (float4 epilogue, no transposition).  The next tile's patch is requested before the
 // current tile's MFMAs and written to the other LDS buffer behind them: one barrier per tile.
-// MEASURED (tools/patch_probe.py, profiles/r05_patch_probe.txt): 0.0526 ms at batch 8 against 0.0572 for the implicit-GEMM tile of the
-// shipped table (0.090 vs 0.111 at batch 16) — a gain, not the 2x the traffic arithmetic above promises: with the filters in 144
-// registers a wave cannot ALSO hold the next patch in flight, convert it and run its MFMAs without everything serialising inside the
-// one wave a SIMD has room for (request -> 432 MFMAs -> epilogue -> convert + publish -> barrier: ~8.5 us per tile, 3.5 of them
-// MFMA).  Three schedules were measured: 8 waves x 4 rows at two per SIMD (no room to prefetch fragments: ds_read -> wait -> MFMA in
-// the ISA, 0.0522), 4 waves x 8 rows with register double-buffered fragments (this file, 0.0526), the same with stores deferred by
-// one tile (0.0555).  What is left is splitting the block into producer and consumer waves, which needs the consumer inside 256
-// registers next to its 144 of filters.  The tuner takes the kernel where it wins.
+// MEASURED (tools/patch_probe.py, profiles/r05_patch_probe.txt), batch 8 / batch 16, against 0.0575 / 0.111 ms for the implicit-GEMM
+// tile of the round-4 table:
+//   8 waves x 4 rows, two per SIMD, no room to prefetch fragments (ds_read -> wait -> MFMA in the ISA)      0.0522
+//   4 waves x 8 rows, ONE per SIMD, fragments double-buffered in registers (patch3x3_c64_k below)           0.0526 / 0.090
+//     — clean ISA, yet request -> 432 MFMAs -> epilogue -> convert + publish -> barrier serialise inside the one wave a SIMD holds
+//   the same with stores deferred by one tile                                                              0.0555
+//   PRODUCER / CONSUMER waves (patch3x3_c64_pc_k, the default): four waves keep the filters and multiply, four load / convert /
+//   publish the next patch beside them, everything inside 256 registers                                    0.0421 / 0.0695 (323 TFLOP/s)
+// = 6.3 us per tile of which 3.5 are MFMA issue; the rest is tile quantisation (1296 tiles on 256 CUs = 5.06 rounds run as 6) and the
+// 8.5 % of masked rows / columns of 138 = 8 x 17.25.  The tuner takes the kernel where it wins.
 // Arithmetic: the fp16x2 scheme of the engine (tensor scale from x_amax, h*l + l*h + h*h on the fp16 pipe, fp32 accumulate), K order
 // tap-major like engine.Packed — the filter planes of Packed.h2() are used unchanged.
 #include "common.h"
@@ -206,6 +208,172 @@ __global__ __launch_bounds__(NT, 1) void patch3x3_c64_k(const PatchParams p) {
 #endif
 }
 
+// ---- producer / consumer form (8 waves, two per SIMD, inside 256 registers each) ----------------------------------------------------
+// Waves 0 .. 3 are CONSUMERS: wave q keeps the filters of output channels 16 q .. + 15 in 144 registers and runs the tile's MFMAs in
+// two passes of four rows (4 accumulators, fragments double-buffered: 144 + 16 + 64 registers).  Waves 4 .. 7 are PRODUCERS: they
+// request the next tile's patch, split it into the fp16 planes and write it to the other LDS buffer WHILE the consumers multiply —
+// the load / convert / publish phases that serialise inside the one wave per SIMD of patch3x3_c64_k run beside the MFMAs here.  One
+// barrier per tile for all eight waves.
+constexpr int PC_NT = 512, PC_NLOAD = (PPX * (C / 4) + 255) / 256;             // 12 float4 per producer thread per patch
+
+__global__ __launch_bounds__(PC_NT) void patch3x3_c64_pc_k(const PatchParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int lr = lane & 15, g = lane >> 4;
+  constexpr unsigned OOB = 0x80000000u;
+  float sA, invA;
+  ymi_h2_scale(ymi_amax_read(p.x_amax), sA, invA);
+  const ymi_amax_pre apre = ymi_amax_prefetch(p.y_amax);
+  const int per_img = p.tiles_x * p.tiles_y;
+  const int grid = (int)gridDim.x;
+#define PATCH_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+  if (wave >= 4) {
+    // =============================== producers: 256 threads, patch of tile k + 1 -> LDS buffer (k + 1) & 1 ===========================
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)p.x_bytes, 0x00020000);
+    const int tp = t - 256;
+    auto request = [&](int tile, f32x4 (&v)[PC_NLOAD]) {
+      const bool live = tile < p.ntiles;
+      const int b = tile / per_img, r = tile - b * per_img;
+      const int ty = r / p.tiles_x, tx = r - ty * p.tiles_x;
+      const int y0 = ty * TH - 1, x0 = tx * TW - 1;
+#pragma unroll
+      for (int i = 0; i < PC_NLOAD; ++i) {
+        const int idx = tp + 256 * i, px = idx >> 4, cg = idx & 15;
+        const int py = px / PW, pxx = px - py * PW;
+        const int yy = y0 + py, xx = x0 + pxx;
+        const bool in = live && px < PPX && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+        const unsigned off = in ? (unsigned)(((b * p.H + yy) * p.W + xx) * p.ldx + 4 * cg) * 4u : OOB;
+        v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0));
+      }
+    };
+    auto publish = [&](const f32x4 (&v)[PC_NLOAD], char *buf) {
+#pragma unroll
+      for (int i = 0; i < PC_NLOAD; ++i) {
+        const int idx = tp + 256 * i, px = idx >> 4, cg = idx & 15;
+        if (px < PPX) {
+          const f32x4 sv = v[i] * sA;
+          f16x4 h4, l4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const _Float16 h = (_Float16)sv[e];
+            h4[e] = h;
+            l4[e] = (_Float16)(sv[e] - (float)h);
+          }
+          char *dst = buf + px * RS + cg * 8;
+          *reinterpret_cast<f16x4 *>(dst) = h4;
+          *reinterpret_cast<f16x4 *>(dst + PLANE) = l4;
+        }
+      }
+    };
+    // the patch of tile k + 2 is in flight while that of tile k + 1 is converted and written: two register sets, swapped per trip
+    int tile = blockIdx.x;
+    f32x4 va[PC_NLOAD], vb[PC_NLOAD];
+    request(tile, va);
+    request(tile + grid, vb);
+    publish(va, lds);
+    PATCH_BARRIER();
+    for (int k = 0; tile < p.ntiles; tile += 2 * grid, k += 2) {
+      request(tile + 2 * grid, va);
+      publish(vb, lds + ((k + 1) & 1) * BUF);            // tile + grid
+      PATCH_BARRIER();
+      if (tile + grid < p.ntiles) {
+        request(tile + 3 * grid, vb);
+        publish(va, lds + (k & 1) * BUF);                // tile + 2 grid
+        PATCH_BARRIER();
+      }
+    }
+    return;
+  }
+  // ================================= consumers: wave q = output channels 16 q .. 16 q + 15 ==============================================
+  const int q = wave;
+  f16x8 wh[NCH], wl[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const char *src = reinterpret_cast<const char *>(p.w_h2) + (size_t)(16 * q + lr) * (2 * 9 * C) + c * 64 + g * 16;
+    wh[c] = *reinterpret_cast<const f16x8 *>(src);
+    wl[c] = *reinterpret_cast<const f16x8 *>(src + p.w_plane);
+  }
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.y, 0, (int)p.y_bytes, 0x00020000);
+  const float slope = p.act == YMI_ACT_RELU ? 0.f : (p.act == YMI_ACT_LEAKY01 ? 0.1f : 1.f);
+  f32x4 sc, bi = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    sc[e] = p.scale_h2[16 * q + 4 * g + e] * invA;       // folded BN scale / filter-row scale, times the exact 1 / sA
+    if (p.bias) bi[e] = p.bias[16 * q + 4 * g + e];
+  }
+  float am = 0.f;
+  int tile = blockIdx.x;
+  PATCH_BARRIER();
+  for (int k = 0; tile < p.ntiles; tile += grid, ++k) {
+    const char *const cur = lds + (k & 1) * BUF;
+    const char *const lane_base = cur + lr * RS + g * 16;
+    const int b = tile / per_img, r = tile - b * per_img;
+    const int ty = r / p.tiles_x, tx = r - ty * p.tiles_x;
+    const int ox = tx * TW + lr;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {                // rows 4 half .. 4 half + 3 of the tile
+      f32x4 acc[4];
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // Per chunk the products run (w_h, x_l) | (w_l, x_h) | (w_h, x_h) — both small terms first, as everywhere.
+      auto src_of = [&](int ch, int rb) {
+        const int tap = ch >> 1, c = ch & 1, ky = tap / 3, kx = tap - 3 * ky;
+        return lane_base + ((4 * half + rb + ky) * PW + kx) * RS + c * 64;
+      };
+      // x_l single-buffered (free after the first product, re-read behind it: eight MFMAs of cover); x_h double-buffered (its last
+      // use is the chunk's last product and its first the next chunk's second: one buffer left 4 MFMAs of cover — measured)
+      f16x8 xl[4], xh0[4], xh1[4];
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        xl[rb] = *reinterpret_cast<const f16x8 *>(src_of(0, rb) + PLANE);
+        xh0[rb] = *reinterpret_cast<const f16x8 *>(src_of(0, rb));
+      }
+      auto chunk = [&](int ch, f16x8 (&xh)[4], f16x8 (&xhn)[4]) {
+        if (ch + 1 < NCH) {
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb) xhn[rb] = *reinterpret_cast<const f16x8 *>(src_of(ch + 1, rb));
+        }
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ch], xl[rb], acc[rb], 0, 0, 0);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) asm volatile("" ::"v"(xl[rb]));       // (plain builtin + keep-alive: see patch3x3_c64_k)
+        if (ch + 1 < NCH) {
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb) xl[rb] = *reinterpret_cast<const f16x8 *>(src_of(ch + 1, rb) + PLANE);
+        }
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[ch], xh[rb], acc[rb], 0, 0, 0);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ch], xh[rb], acc[rb], 0, 0, 0);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) asm volatile("" ::"v"(xh[rb]));
+      };
+#pragma unroll
+      for (int ch = 0; ch < NCH; ch += 2) {
+        chunk(ch, xh0, xh1);
+        chunk(ch + 1, xh1, xh0);
+      }
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        const int oy = ty * TH + 4 * half + rb;
+        const bool ok = oy < p.H && ox < p.W;
+        f32x4 v = acc[rb] * sc + bi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], slope * v[e]);
+        am = fmaxf(am, ok ? ymi_absmax4(v) : 0.f);
+        const unsigned off = ok ? (unsigned)(((b * p.H + oy) * p.W + ox) * p.ldy + 16 * q + 4 * g) * 4u : OOB;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, off, 0, 0);
+      }
+    }
+    PATCH_BARRIER();
+  }
+#undef PATCH_BARRIER
+  if (p.y_amax) ymi_amax_finish(apre, am);
+#endif
+}
+
 }  // namespace
 
 // internal (called by ymi_conv2d_nhwc_f32 for tile YMI_TILE_H2 | YMI_TILE_DCNP | YMI_DCNP_PATCH_C64): 3x3 / stride 1 / pad 1, 64 -> 64,
@@ -232,7 +400,11 @@ int ymi_internal_patch_conv(const ymi_conv_desc *d, hipStream_t s) {
   hipGetDevice(&dev);
   hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   const int pr = ymi_internal_prof_begin(2.0 * (double)px * C * 9.0 * C, YMI_TILE_H2 | YMI_TILE_DCNP | YMI_DCNP_PATCH_C64, 14, s);
-  hipLaunchKernelGGL(patch3x3_c64_k, dim3((unsigned)(p.ntiles < cus ? p.ntiles : cus)), dim3(NT), 0, s, p);
+  static const int variant = [] { const char *e = getenv("YMI_PATCH_VARIANT"); return e ? atoi(e) : 1; }();   // 1 (default) = producer / consumer, 0 = one wave per SIMD
+  if (variant == 1)
+    hipLaunchKernelGGL(patch3x3_c64_pc_k, dim3((unsigned)(p.ntiles < cus ? p.ntiles : cus)), dim3(PC_NT), 0, s, p);
+  else
+    hipLaunchKernelGGL(patch3x3_c64_k, dim3((unsigned)(p.ntiles < cus ? p.ntiles : cus)), dim3(NT), 0, s, p);
   const int rc = ymi_launch_status();
   ymi_internal_prof_end(pr, s);
   return rc;
