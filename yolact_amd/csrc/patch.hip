@@ -146,7 +146,10 @@ __global__ __launch_bounds__(NT, 1) void patch3x3_c64_k(const PatchParams p) {
     // ---- 18 K chunks x 8 tile rows: B operand = patch pixel (rb + ky, lr + kx), channels 32 c + 8 g .. + 7 ---------------------------
     f32x4 acc[TH];
 #pragma unroll
-    for (int rb = 0; rb < TH; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int rb = 0; rb < TH; ++rb) {
+      acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      asm volatile("" : "+v"(acc[rb]));                   // (own register group per accumulator: see patch3x3_c64_pc_k)
+    }
     const char *const lane_base = cur + lr * RS + g * 16;
     auto load_chunk = [&](int ch, Frag (&f)[TH]) {        // chunk = 2 tap + c
       const int tap = ch >> 1, c = ch & 1, ky = tap / 3, kx = tap - 3 * ky;
@@ -168,7 +171,8 @@ __global__ __launch_bounds__(NT, 1) void patch3x3_c64_k(const PatchParams p) {
       for (int pr = 0; pr < 3; ++pr)                      // product-major: eight independent accumulators between dependent MFMAs
 #pragma unroll
         for (int rb = 0; rb < TH; ++rb)
-          acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pr == 0 ? wl[ch] : wh[ch], pr == 1 ? f[rb].l : f[rb].h, acc[rb], 0, 0, 0);
+          acc[rb] = (ch == NCH - 1 && pr == 2) ? ymi_mfma16(wh[ch], f[rb].h, acc[rb])      // (the chain's last link: see patch3x3_c64_pc_k)
+                                               : __builtin_amdgcn_mfma_f32_16x16x32_f16(pr == 0 ? wl[ch] : wh[ch], pr == 1 ? f[rb].l : f[rb].h, acc[rb], 0, 0, 0);
 #pragma unroll
       for (int rb = 0; rb < TH; ++rb) asm volatile("" ::"v"(f[rb].h), "v"(f[rb].l));
     };
@@ -316,7 +320,13 @@ __global__ __launch_bounds__(PC_NT) void patch3x3_c64_pc_k(const PatchParams p) 
     for (int half = 0; half < 2; ++half) {                // rows 4 half .. 4 half + 3 of the tile
       f32x4 acc[4];
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int rb = 0; rb < 4; ++rb) {
+        acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // every accumulator its OWN live register group from the start: a zero shared between them is a SrcC that dies at the
+        // first MFMA, and hipcc then placed that MFMA's destination half over it (v[166:169] <- ..., v[168:171]: caught by
+        // tools/check_mfma_overlap.py in the first build of this kernel)
+        asm volatile("" : "+v"(acc[rb]));
+      }
       // Per chunk the products run (w_h, x_l) | (w_l, x_h) | (w_h, x_h) — both small terms first, as everywhere.
       auto src_of = [&](int ch, int rb) {
         const int tap = ch >> 1, c = ch & 1, ky = tap / 3, kx = tap - 3 * ky;
@@ -345,8 +355,12 @@ __global__ __launch_bounds__(PC_NT) void patch3x3_c64_pc_k(const PatchParams p) 
         }
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[ch], xh[rb], acc[rb], 0, 0, 0);
+        // the LAST product of the chain through ymi_mfma16 (destination disjoint from every source): that is where the compiler
+        // retargets the accumulators for the epilogue, and it placed one HALF over its own SrcC (v[174:177] <- ..., v[176:179]:
+        // caught by the lint in this kernel's first full build).  Everywhere else the chain stays in place.
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ch], xh[rb], acc[rb], 0, 0, 0);
+        for (int rb = 0; rb < 4; ++rb)
+          acc[rb] = ch == NCH - 1 ? ymi_mfma16(wh[ch], xh[rb], acc[rb]) : __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ch], xh[rb], acc[rb], 0, 0, 0);
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) asm volatile("" ::"v"(xh[rb]));
       };
