@@ -435,6 +435,57 @@ def box_calibration(dev, seconds=0.25):
     evs[1].record()
     evs[1].synchronize()
     gbps = 20 * by.value / (evs[0].elapsed_time(evs[1]) * 1e-3) / 1e9
+    # the same copy over footprints that FIT the 256 MB memory-side cache (source + destination = 16 / 64 / 192 MB, repeated): what a
+    # tensor written by one launch and read by the next one sees.  The 1 GiB copy and the MFMA loop did not separate the ~1.8k from
+    # the ~2.05k images/s boxes of this pool (sessions r5a ... r5x) while every HBM-side kernel of the step was 20 - 60 % slower
+    # on the former: this is the axis those two numbers do not cover.
+    cache_copy = {}
+    for mb in (8, 32, 96):
+        nn = mb * (1 << 20) // 4
+        rep = max(4, 2048 // (2 * mb))
+
+        def ccopy():
+            L.check(lib.ymi_calib_hbm_copy(src.data_ptr(), dst.data_ptr(), nn, C.byref(by), s), 'ymi_calib_hbm_copy')
+        for _ in range(2):
+            ccopy()
+        torch.cuda.synchronize()
+        evs[0].record()
+        for _ in range(rep):
+            ccopy()
+        evs[1].record()
+        evs[1].synchronize()
+        cache_copy['%dMB' % (2 * mb)] = round(rep * by.value / (evs[0].elapsed_time(evs[1]) * 1e-3) / 1e9, 1)
+    # GPU-side cost of one DEPENDENT launch: 400 one-block launches back to back on the stream, start-to-end by HIP events (the
+    # step is ~133 dependent launches; = max(host issue rate, the command processor's launch-to-launch time))
+    evs[0].record()
+    for _ in range(400):
+        lib.ymi_calib_mfma_f16(out.data_ptr(), 1, 1, None, s)
+    evs[1].record()
+    evs[1].synchronize()
+    dep_us = evs[0].elapsed_time(evs[1]) * 1e3 / 400
+    # load-to-use LATENCY (ymi_calib_latency: one lane follows a random single-cycle permutation, one entry per 128-byte line) over
+    # 1 MB (L2 after the warm pass), 64 MB and 2 GiB (memory + address translation: 16 M lines on distinct pages)
+    latency = {}
+    i32 = torch.int32
+    res = torch.zeros(4, dtype=i32, device=dev)
+    for label, mb, hops in (('1MB', 1, 20000), ('64MB', 64, 20000), ('2048MB', 2048, 10000)):
+        lines = mb * (1 << 20) // 128
+        perm = torch.randperm(lines, device=dev)
+        chain = torch.zeros(lines * 32, dtype=i32, device=dev)
+        chain[perm * 32] = (torch.roll(perm, -1) * 32).to(i32)
+        starts = [int(v) * 32 for v in perm[torch.arange(3, device=dev) * hops % lines]]
+        del perm
+        best = None
+        for r in range(3):          # every pass starts where the previous one stopped on the cycle: a footprint larger than L2 is
+            torch.cuda.synchronize()    # never re-visited, the 1 MB one is warm from the second pass on
+            evs[0].record()
+            L.check(lib.ymi_calib_latency(chain.data_ptr(), chain.numel(), starts[r], hops, res.data_ptr(), s), 'ymi_calib_latency')
+            evs[1].record()
+            evs[1].synchronize()
+            ns = evs[0].elapsed_time(evs[1]) * 1e6 / hops
+            best = ns if best is None else min(best, ns)
+        latency[label] = round(best, 1)
+        del chain
     # L2-resident read stream (1 MB swept by 8 blocks per CU): the global -> CU path the GEMM tiles are bound by
     l2src = torch.randn(1 << 18, device=dev)
     l2b = C.c_double()
@@ -469,16 +520,33 @@ def box_calibration(dev, seconds=0.25):
             names = [ln.split(':', 1)[1].strip() for ln in f if ln.startswith('model name')]
         host['cpu_model'] = names[0] if names else None
         host['logical_cpus'] = len(names)
+        host['kernel'] = os.uname().release
+        with open('/proc/loadavg') as f:
+            host['loadavg_1m'] = float(f.read().split()[0])
     except OSError:
         pass
+    # which physical GPU this was (kfd's unique_id): the pool's boxes differ, and two runs on the same id are directly comparable
+    gpu_ids = []
+    import glob
+    for pth in sorted(glob.glob('/sys/class/kfd/kfd/topology/nodes/*/properties')):
+        try:
+            with open(pth) as f:
+                props = dict(ln.split(None, 1) for ln in f.read().splitlines() if len(ln.split(None, 1)) == 2)
+            if int(props.get('simd_count', '0')) > 0:
+                gpu_ids.append(props.get('unique_id', '').strip())
+        except (OSError, ValueError):
+            continue
+    host['gpu_unique_ids'] = gpu_ids
     return {'host': host, 'mfma_f16_tflops': round(sum(half) / len(half), 1), 'mfma_f16_tflops_first_launches': round(rates[0], 1),
             'mfma_f16_frac_of_2500': round(sum(half) / len(half) / BF16_MFMA_PEAK_TFLOPS, 4),
             'hbm_copy_GBps': round(gbps, 1), 'hbm_copy_frac_of_8000': round(gbps / HBM_PEAK_GBPS, 4),
-            'l2_read_GBps': round(l2_gbps, 1),
+            'l2_read_GBps': round(l2_gbps, 1), 'cache_copy_GBps_by_footprint': cache_copy, 'dependent_launch_us': round(dep_us, 2),
+            'load_latency_ns_by_footprint': latency,
             'device': torch.cuda.get_device_name(dev), 'compute_units': n_cu, 'power_state': gpu_power_state(),
             'what': 'csrc/calib.hip, timed with HIP events on the launch stream right before the warm-up steps: %d x 4 waves of '
                     'register-resident v_mfma_f32_32x32x16_f16 (random mantissas) for %.2f s, rate of the last half of the interval; '
-                    'float4 copy of 1 GiB (read + write bytes) x 20' % (blocks, seconds)}
+                    'float4 copy of 1 GiB (read + write bytes) x 20; the same copy over 16 / 64 / 192 MB footprints (inside the 256 MB '
+                    'memory-side cache); 400 dependent one-block launches; a one-lane dependent-load chain over 1 MB / 64 MB / 2 GiB (best of 3)' % (blocks, seconds)}
 
 
 def cpu_baseline(sd, size, batch=8, budget_s=14.0):
@@ -664,6 +732,8 @@ def main():
     ap.add_argument('--no-secondary', action='store_true')
     ap.add_argument('--no-calibration', action='store_true', help='skip the box calibration block (csrc/calib.hip)')
     ap.add_argument('--no-pipeline', action='store_true', help='block on the host read of every step before launching the next')
+    ap.add_argument('--prealloc-gb', type=int, default=0, help='experiment: reserve ONE allocation of this size in torch\'s caching '
+                    'allocator before anything else is allocated, so that weights / activations / workspaces are carved from one mapping')
     ap.add_argument('--layers', action='store_true', help='also print the per-layer conv table to stderr')
     args = ap.parse_args()
     if args.gpus < 1:
@@ -712,6 +782,9 @@ def main():
     from yolact_amd.utils.synth import synth_images
     size = args.size or int(yolact_amd.CONFIGS[args.config].max_size)
     with torch.no_grad():
+        if args.prealloc_gb > 0:
+            _pre = torch.empty(args.prealloc_gb << 30, dtype=torch.uint8, device=dev)
+            del _pre                                   # stays cached: later allocations are split from this block
         net, sd = build_model(dev, size, args.config)
         x = synth_images(args.batch, size, size, seed=1234 + rank).to(dev)   # resident in HBM
         have_pg = dist.is_initialized()

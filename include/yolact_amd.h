@@ -527,6 +527,9 @@ int ymi_calib_hbm_copy(const float *src, float *dst, long n_floats, double *byte
 /* every one of `blocks` 256-thread blocks reads src [n_floats] (n % 4096 == 0; 1 MB stays resident in every XCD's L2) `iters` times with
  * 16-byte loads; *bytes = bytes delivered to the CUs.  The path the GEMM tiles are bound by (global -> CU at L2-hit latency). */
 int ymi_calib_l2_read(const float *src, long n_floats, int blocks, int iters, float *out, double *bytes, void *stream);
+/* one lane follows i = chain[i] from `start` for `hops` dependent loads and stores where it ended in out[0]; the caller lays the
+ * permutation (one entry per 128-byte line over the footprint to probe) and divides its event time by hops: load-to-use latency. */
+int ymi_calib_latency(const int32_t *chain, long n, int start, int hops, int32_t *out, void *stream);
 
 /* -- profiling hooks -------------------------------------------------------------------- */
 /* When enabled, every conv launch is bracketed by hipEvents on its stream; ymi_prof_read returns

@@ -19,6 +19,7 @@
 #   chainpmc     wave-state and LDS counters of the pointwise-chain kernel
 #   plusab       A/B of the DCN offset / mask convolution layouts on configs[3];   tuneplus = re-tune configs[3] + bench with the layer table
 #   py:<file>    python <file> (a probe under tools/), output to <file basename>.log
+#   boxinfo      tools/box_info.sh: driver / firmware / partition / clock facts of THIS box (to tell the pool's boxes apart)
 O=gpurun_out/$1; shift; mkdir -p $O
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
@@ -28,6 +29,11 @@ for st in "$@"; do
   case "${st%%:*}" in pytest|pytestf|py) arg="${arg//+/ }" ;; *) arg="${arg//_/ }" ;; esac      # (+ stands for a space in pytest / pytestf / py
                                                                                                   #  arguments, whose names contain _; _ elsewhere)
   case "${st%%:*}" in
+    allocab) # does ONE device mapping for everything (weights, activations, workspaces) change the step?  (address translation: the pool's slow
+             # boxes lose 30 - 60 % on short / scatter-heavy kernels while every streaming probe runs at the fast boxes' rate)
+      for v in 0 16 0 16; do timeout 300 python bench.py --steps 30 --no-cpu-baseline --no-secondary --no-calibration --prealloc-gb $v 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('prealloc_gb=$v', d['value'], d['ms_per_step'])"; done | tee $O/allocab.txt
+      PYTORCH_HIP_ALLOC_CONF=expandable_segments:True timeout 300 python bench.py --steps 30 --no-cpu-baseline --no-secondary --no-calibration 2>$O/expandable.err | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('expandable_segments', d['value'], d['ms_per_step'])" | tee -a $O/allocab.txt ;;
+    boxinfo) bash tools/box_info.sh > $O/boxinfo.txt 2>&1; grep -E "^param|partition|Partition" $O/boxinfo.txt | head -12 ;;
     build) make -C yolact_amd/csrc -j16 > $O/build.log 2>&1; tail -2 $O/build.log ;;
     tune) timeout 1500 python tools/make_tune_table.py --fresh > $O/tune.log 2>&1      # default arithmetic (fp16x2), every plan
       for m in 1 0; do YOLACT_AMD_SPLIT=$m timeout 600 python tools/make_tune_table.py --only configs1_r50_b8 r50_b1 r50_b2 >> $O/tune.log 2>&1; done   # bf16x3 / exact-fp32 keys of configs[1]

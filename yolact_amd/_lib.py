@@ -204,6 +204,7 @@ SYMBOLS = [
     ('ymi_calib_mfma_f16', C.c_int, [_P, _I, _I, C.POINTER(C.c_double), _P]),
     ('ymi_calib_hbm_copy', C.c_int, [_P, _P, C.c_long, C.POINTER(C.c_double), _P]),
     ('ymi_calib_l2_read', C.c_int, [_P, C.c_long, _I, _I, _P, C.POINTER(C.c_double), _P]),
+    ('ymi_calib_latency', C.c_int, [_P, C.c_long, _I, _I, _P, _P]),
     ('ymi_debug_set_trace', C.c_int, [_P, C.c_long]),
     ('ymi_prof_enable', C.c_int, [_I]),
     ('ymi_prof_count', C.c_int, []),

@@ -65,9 +65,31 @@ __global__ __launch_bounds__(256) void calib_l2_k(const f32x4 *__restrict__ src,
   if (s[0] + s[1] + s[2] + s[3] == 12345.678f) out[0] = s[0];
 }
 
+// Dependent-load chain: ONE lane follows chain[i] -> i for `hops` steps (the caller lays a random single-cycle permutation over the
+// footprint it wants to probe, one entry per 128-byte line).  Time / hops = the load-to-use latency of that footprint: L2 for 1 MB,
+// memory + address translation for gigabytes.  The axis the bandwidth probes above do not see: the pool's slow boxes run every
+// streaming probe at the fast boxes' rate while every short or scatter-heavy kernel of the step is 30 - 60 % slower.
+__global__ __launch_bounds__(64) void calib_chase_k(const int *__restrict__ chain, int start, int hops, int *out) {
+  if (threadIdx.x != 0) return;
+  int i = start;
+  for (int h = 0; h < hops; ++h) {
+    // (a VECTOR-memory load on purpose: the compiler would follow a uniform index through the scalar cache)
+    const int *p = chain + i;
+    asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(i) : "v"(p) : "memory");
+  }
+  out[0] = i;
+}
+
 }  // namespace
 
 extern "C" {
+
+int ymi_calib_latency(const int32_t *chain, long n, int start, int hops, int32_t *out, void *stream) {
+  if (!chain || !out) return YMI_ENULL;
+  if (n < 1 || n > 0x7fffffffL || start < 0 || start >= n || hops < 1) return YMI_EARG;
+  hipLaunchKernelGGL(calib_chase_k, dim3(1), dim3(64), 0, (hipStream_t)stream, (const int *)chain, start, hops, (int *)out);
+  return ymi_launch_status();
+}
 
 int ymi_calib_l2_read(const float *src, long n_floats, int blocks, int iters, float *out, double *bytes, void *stream) {
   if (!src || !out) return YMI_ENULL;
