@@ -337,8 +337,9 @@ def whole_path_roofline(rk, step_ms, batch):
                      % (gflop, batch, gflop / batch, step_ms, 100 * max(eng['h2_share_of_time'], eng['x3_share_of_time'], 0.0)
                         if peak != FP32_MFMA_PEAK_TFLOPS else 100.0),
             'frac_of_fp32_mfma_peak': round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-            'frac_of_raw_fp16_pipe': round(ach * (3 if peak == H2_PEAK_TFLOPS else 6 if peak == X3_PEAK_TFLOPS else 1)
-                                           / (BF16_MFMA_PEAK_TFLOPS if peak != FP32_MFMA_PEAK_TFLOPS else FP32_MFMA_PEAK_TFLOPS), 4),
+            # algorithmic fp32-class products per second against the RAW 16-bit matrix pipe (2500 TFLOP/s: what a network that could
+            # run every product as ONE fp16 MFMA would be priced against) - i.e. frac / 3 for an fp16x2 plan
+            'frac_of_raw_fp16_pipe': round(ach / BF16_MFMA_PEAK_TFLOPS, 4),
             'dominant_kernel': dom}
     for k in ('bound_sum_ms', 'bound_sum', 'measured', 'all_conv', 'engine', 'per_kernel', 'layer_view'):
         if k in rk:
