@@ -124,22 +124,33 @@ __global__ __launch_bounds__(256) void wino_out_k(const float *__restrict__ Mm, 
     if (scale) sc = *reinterpret_cast<const f32x4 *>(scale + n4 * 4);
     if (bias) bi = *reinterpret_cast<const f32x4 *>(bias + n4 * 4);
     const float slope = act == YMI_ACT_RELU ? 0.f : (act == YMI_ACT_LEAKY01 ? 0.1f : 1.f);
+    // Every value (scale, bias, activation) BEFORE the first store (round 5, from the ISA): a load result first used inside a
+    // conditional store block made the compiler wait with vmcnt(0) in EVERY such block, i.e. for the previous block's store — one
+    // memory round trip per pixel.  Measured on the plan's launches: 8.4 -> 7.6 us here, 27.8 -> 25.0 us (69 x 69 x 256, batch 8) and
+    // 10.4 -> 9.4 us (35 x 35) for wino43_out_k.  The same restructuring of the INPUT transforms (36 unconditional loads up front
+    // instead of six branchy columns) and of the segmented output kernels measured 2 - 10 % SLOWER and was not kept: those launches
+    // already run at 3.3 - 5 TB/s of tensor bytes, the dependent round trips were not what bounded them.
+    f32x4 vv[2][2];
 #pragma unroll
     for (int iy = 0; iy < 2; ++iy) {
       const f32x4 o0 = (s[iy][0] + s[iy][1]) + s[iy][2], o1 = (s[iy][1] - s[iy][2]) - s[iy][3];
-      const int oy = 2 * ty + iy;
-      if (oy >= Ho) continue;
 #pragma unroll
       for (int ix = 0; ix < 2; ++ix) {
-        const int ox = 2 * tx + ix;
-        if (ox >= Wo) continue;
         f32x4 v = (ix == 0 ? o0 : o1) * sc + bi;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], slope * v[e]);
-        am = fmaxf(am, ymi_absmax4(v));
-        *reinterpret_cast<f32x4 *>(y + ((b * Ho + oy) * (long)Wo + ox) * (N4 * 4L) + n4 * 4) = v;
+        vv[iy][ix] = v;
+        const bool ok = 2 * ty + iy < Ho && 2 * tx + ix < Wo;
+        am = fmaxf(am, ok ? ymi_absmax4(v) : 0.f);
       }
     }
+#pragma unroll
+    for (int iy = 0; iy < 2; ++iy)
+#pragma unroll
+      for (int ix = 0; ix < 2; ++ix) {
+        const int oy = 2 * ty + iy, ox = 2 * tx + ix;
+        if (oy < Ho && ox < Wo) *reinterpret_cast<f32x4 *>(y + ((b * Ho + oy) * (long)Wo + ox) * (N4 * 4L) + n4 * 4) = vv[iy][ix];
+      }
   }
   if (y_amax) ymi_amax_finish(apre, am);
 }
@@ -448,20 +459,23 @@ __global__ __launch_bounds__(256) void wino43_out_k(const float *__restrict__ Mm
     if (bias) bi = *reinterpret_cast<const f32x4 *>(bias + n4 * 4);
     const float slope = act == YMI_ACT_RELU ? 0.f : (act == YMI_ACT_LEAKY01 ? 0.1f : 1.f);
 #pragma unroll
-    for (int iy = 0; iy < 4; ++iy) {
-      const int oy = 4 * ty + iy;
-      if (oy >= Ho) continue;
+    for (int iy = 0; iy < 4; ++iy)           // values first, stores last (see wino_out_k)
 #pragma unroll
       for (int ix = 0; ix < 4; ++ix) {
-        const int ox = 4 * tx + ix;
-        if (ox >= Wo) continue;
         f32x4 v = o[iy][ix] * sc + bi;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], slope * v[e]);
-        am = fmaxf(am, ymi_absmax4(v));
-        *reinterpret_cast<f32x4 *>(y + ((b * Ho + oy) * (long)Wo + ox) * (N4 * 4L) + n4 * 4) = v;
+        o[iy][ix] = v;
+        const bool ok = 4 * ty + iy < Ho && 4 * tx + ix < Wo;
+        am = fmaxf(am, ok ? ymi_absmax4(v) : 0.f);
       }
-    }
+#pragma unroll
+    for (int iy = 0; iy < 4; ++iy)
+#pragma unroll
+      for (int ix = 0; ix < 4; ++ix) {
+        const int oy = 4 * ty + iy, ox = 4 * tx + ix;
+        if (oy < Ho && ox < Wo) *reinterpret_cast<f32x4 *>(y + ((b * Ho + oy) * (long)Wo + ox) * (N4 * 4L) + n4 * 4) = o[iy][ix];
+      }
   }
   if (y_amax) ymi_amax_finish(apre, am);
 }
