@@ -66,7 +66,7 @@ def test_latency_chain_ends_where_the_permutation_says():
             assert int(out[0]) == int(perm[(r + 1) * hops % lines]) * 32
         ns[mb] = e0.elapsed_time(e1) * 1e6 / hops
     print('load-to-use latency: 1 MB %.0f ns, 1 GiB %.0f ns' % (ns[1], ns[1024]))
-    assert 100.0 < ns[1] < 1500.0 and ns[1024] > 1.3 * ns[1], ns
+    assert 40.0 < ns[1] < 1500.0 and ns[1024] > 1.3 * ns[1], ns       # measured: 99 - 105 ns (L2), 385 - 390 ns (1 - 2 GiB)
     assert lib.ymi_calib_latency(None, 10, 0, 1, out.data_ptr(), s) == -3
     assert lib.ymi_calib_latency(chain_d.data_ptr(), 10, 10, 1, out.data_ptr(), s) == -1
     assert lib.ymi_calib_latency(chain_d.data_ptr(), 10, 0, 0, out.data_ptr(), s) == -1
