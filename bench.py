@@ -733,6 +733,8 @@ def main():
     ap.add_argument('--no-secondary', action='store_true')
     ap.add_argument('--no-calibration', action='store_true', help='skip the box calibration block (csrc/calib.hip)')
     ap.add_argument('--no-pipeline', action='store_true', help='block on the host read of every step before launching the next')
+    ap.add_argument('--exchange-after-join', action='store_true', help='A/B: enqueue the record gather + count read behind the whole '
+                    'forward (round 4 behaviour) instead of right behind Detect on its stream')
     ap.add_argument('--prealloc-gb', type=int, default=0, help='experiment: reserve ONE allocation of this size in torch\'s caching '
                     'allocator before anything else is allocated, so that weights / activations / workspaces are carved from one mapping')
     ap.add_argument('--layers', action='store_true', help='also print the per-layer conv table to stderr')
@@ -800,18 +802,27 @@ def main():
         turn = {'i': 0}
         gatherer = parallel.RecordGatherer(0)        # persistent receive buffers: no allocation, no torch.cat per step
 
-        def launch():
-            out = net.forward_device(x)
+        def exchange(out):
+            # (called by forward_device right behind Detect, on the stream Detect runs on — the way Yolact.forward_sharded /
+            #  parallel.sharded_forward enqueue it: the records do not depend on the prototypes)
             # pack_records = the record tensor the Detect selection kernel wrote itself (no torch op)
             rec = gatherer(parallel.pack_records(out), args.batch, force_collective=have_pg)
-            handle = None
-            if rec is not None:
-                buf = host_counts[turn['i'] & 1]
-                turn['i'] += 1
-                buf[:rec.shape[0]].copy_(rec[:, 0], non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record()
-                handle = (buf, ev, int(rec.shape[0]))
+            if rec is None:
+                return None
+            buf = host_counts[turn['i'] & 1]
+            turn['i'] += 1
+            buf[:rec.shape[0]].copy_(rec[:, 0], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            return (buf, ev, int(rec.shape[0]))
+
+        def launch():
+            if args.exchange_after_join:
+                out = net.forward_device(x)
+                handle = exchange(out)
+            else:
+                out = net.forward_device(x, after_detect=exchange)
+                handle = out.pop('after_detect')
             if args.with_postprocess:
                 postprocess_batch(out, size, size)
             return handle

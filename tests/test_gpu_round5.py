@@ -330,3 +330,42 @@ def test_small_direct_convolution_matches_torch(case):
     ref = torch.relu(torch.nn.functional.conv2d(x.double(), wt.double(), b.double(), stride, pad)).permute(0, 2, 3, 1)
     err = (y.cpu().double() - ref).abs().max().item() / max(1.0, ref.abs().max().item())
     assert err < 2e-6 and not torch.isnan(y).any(), err
+
+
+def test_after_detect_hook_runs_on_detects_stream_and_changes_nothing():
+    """Yolact.forward_device(x, after_detect=f): f sees Detect's outputs with Detect's stream current (the side stream of the two-stream
+    plan), before the prototypes exist; what it enqueues there (the data-parallel record gather) is covered by the plan's final join.
+    The outputs are the ones a plain forward_device returns."""
+    from gpu_utils import build_net
+    from helpers import case_images, load_golden
+    from yolact_amd import parallel
+    meta, _ = load_golden('r50_dense')
+    x = case_images(meta).to(DEV)
+    net = build_net(meta)
+    ref = net.forward_device(x)
+    ref_rec = parallel.pack_records(ref).clone()
+    plan = net.plan_for(x)
+    seen = {}
+
+    def hook(out):
+        seen['stream'] = torch.cuda.current_stream().cuda_stream
+        seen['keys'] = sorted(out.keys())
+        return parallel.pack_records(out).clone()          # a consumer of the records, enqueued on Detect's stream
+
+    got = net.forward_device(x, after_detect=hook)
+    rec = got.pop('after_detect')
+    torch.cuda.synchronize()
+    assert 'proto' not in seen['keys'] and 'rec' in seen['keys']
+    if plan.stream_b is not None and plan.two_streams:
+        assert seen['stream'] == plan.stream_b.cuda_stream != torch.cuda.current_stream().cuda_stream
+    assert torch.equal(rec, ref_rec)
+    for k in ('count', 'box', 'score', 'cls', 'coef', 'proto'):
+        assert torch.equal(got[k], ref[k]), k
+    # and through the sharded entry point (world 1: the gather is a passthrough enqueued from inside the forward)
+    sh = net.forward_sharded(x)
+    base = net.detect.finish(ref, ref['proto'], net)
+    for a, r in zip(sh, base):
+        assert (a['detection'] is None) == (r['detection'] is None)
+        if r['detection'] is not None:
+            for k in ('box', 'score', 'class'):
+                assert torch.equal(a['detection'][k], r['detection'][k]), k

@@ -315,10 +315,16 @@ def _gloo8_worker(rank, world, port, q):
         class detect:
             top_k, use_cross_class_nms = 200, False
 
-        def forward_device(self, xs):
+        def forward_device(self, xs, after_detect=None):
+            # like Yolact.forward_device: the caller's consumer of the records (sharded_forward's gather) is invoked from INSIDE the
+            # forward, behind Detect and before the prototypes exist; ranks with an empty shard enter the same collective from outside
             lo = int(xs[0, 0, 0, 0])
             calls.append((lo, xs.shape[0]))
-            return {k: v[lo:lo + xs.shape[0]] for k, v in full.items()}
+            out = {k: v[lo:lo + xs.shape[0]] for k, v in full.items() if k != 'proto'}
+            assert after_detect is not None, 'sharded_forward must hand its gather to a forward that accepts after_detect'
+            out['after_detect'] = after_detect(out)
+            out['proto'] = full['proto'][lo:lo + xs.shape[0]]
+            return out
     import yolact_amd
     yolact_amd.set_cfg('yolact_resnet50_config')
     yolact_amd.cfg.max_num_detections = cap

@@ -29,6 +29,8 @@ for st in "$@"; do
   case "${st%%:*}" in pytest|pytestf|py) arg="${arg//+/ }" ;; *) arg="${arg//_/ }" ;; esac      # (+ stands for a space in pytest / pytestf / py
                                                                                                   #  arguments, whose names contain _; _ elsewhere)
   case "${st%%:*}" in
+    exab) # record gather + count read enqueued right behind Detect on its stream (default) against behind the whole forward (round 4)
+      for v in "" "--exchange-after-join" "" "--exchange-after-join"; do timeout 300 python bench.py --steps 30 --no-cpu-baseline --no-secondary --no-calibration $v 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('exchange ${v:-after-detect}', d['value'], d['ms_per_step'])"; done | tee $O/exab.txt ;;
     allocab) # does ONE device mapping for everything (weights, activations, workspaces) change the step?  (address translation: the pool's slow
              # boxes lose 30 - 60 % on short / scatter-heavy kernels while every streaming probe runs at the fast boxes' rate)
       for v in 0 16 0 16; do timeout 300 python bench.py --steps 30 --no-cpu-baseline --no-secondary --no-calibration --prealloc-gb $v 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('prealloc_gb=$v', d['value'], d['ms_per_step'])"; done | tee $O/allocab.txt

@@ -127,14 +127,24 @@ def sharded_forward(forward_device, x_global: torch.Tensor, D: int, gatherer: Op
     B = int(x_global.shape[0])
     lo, hi = shard_range(B, rank, world)
     rows = (B + world - 1) // world
-    out = forward_device(x_global[lo:hi].contiguous()) if hi > lo else None
-    if out is not None:
-        rec = pack_records(out)
-    else:                                         # more ranks than images: contribute count-0 records only
-        L_ = 1 + int(_cap_of(forward_device)) * (6 + D)
-        rec = torch.zeros(0, L_, dtype=torch.float32, device=x_global.device)
     g = gatherer or RecordGatherer(dst)
-    allrec = g(rec, rows, n_items=B, force_collective=world > 1)
+    out, allrec, hooked = None, None, False
+    if hi > lo:
+        if _accepts_after_detect(forward_device):
+            # the gather is enqueued from INSIDE the forward, right behind Detect on the stream Detect runs on (Yolact.forward_device):
+            # the records do not depend on the prototypes, so the collective overlaps the protonet instead of queueing behind it
+            out = forward_device(x_global[lo:hi].contiguous(),
+                                 after_detect=lambda o: g(pack_records(o), rows, n_items=B, force_collective=world > 1))
+            allrec, hooked = out.pop('after_detect'), True
+        else:
+            out = forward_device(x_global[lo:hi].contiguous())
+    if not hooked:
+        if out is not None:
+            rec = pack_records(out)
+        else:                                         # more ranks than images: contribute count-0 records only
+            L_ = 1 + int(_cap_of(forward_device)) * (6 + D)
+            rec = torch.zeros(0, L_, dtype=torch.float32, device=x_global.device)
+        allrec = g(rec, rows, n_items=B, force_collective=world > 1)
     if masks_fn is None:
         return allrec, out
     bits = masks_fn(out)                                       # [b, cap, W64] int64
@@ -182,6 +192,14 @@ def unpack_mask_bits(bits: torch.Tensor, h: int, w: int) -> torch.Tensor:
     shifts = torch.arange(64, device=bits.device, dtype=torch.int64)
     flat = ((bits.unsqueeze(-1) >> shifts) & 1).reshape(n, -1)[:, :h * w]
     return flat.to(torch.float32).view(n, h, w)
+
+
+def _accepts_after_detect(forward_device) -> bool:
+    import inspect
+    try:
+        return 'after_detect' in inspect.signature(forward_device).parameters
+    except (TypeError, ValueError):
+        return False
 
 
 def _cap_of(forward_device):

@@ -271,15 +271,32 @@ class Yolact(nn.Module):
             L.check(lib.ymi_global_maxpool_nhwc_f32(x.data_ptr(), out.data_ptr(), N, H * W, x.shape[3], s), 'maskiou max')
         return out
 
-    def _forward_device_one(self, x, slot=0):
+    def _forward_device_one(self, x, slot=0, after_detect=None):
         plan = self.plan_for(x, slot)
         if os.environ.get('YOLACT_AMD_GRAPH', '0') == '1':
-            return self._forward_device_graph(plan, x, slot)
+            out = self._forward_device_graph(plan, x, slot)
+            if after_detect is not None:       # (a replayed graph has no point "after Detect": the hook runs behind the whole replay)
+                out['after_detect'] = after_detect(out)
+            return out
         nomask = not bool(getattr(self.cfg, 'eval_mask_branch', True))
+
+        def detect_cb(s):
+            out = self.detect.run_device(plan.loc, plan.conf, self._coef_for(plan, nomask), plan.priors, True, stream=s, slot=slot,
+                                         conf_ld=plan.conf_ld)
+            if after_detect is not None:
+                # the caller's consumer of the detection records (the record gather of the data-parallel path, a host read of the
+                # counts) is enqueued HERE, on the stream Detect just ran on — in two-stream mode the side stream, where it overlaps the
+                # protonet's tail on the main stream instead of queueing behind it (the final join of the plan covers it)
+                ptr = s.value if hasattr(s, 'value') else s
+                side = plan.stream_b if (plan.stream_b is not None and ptr == plan.stream_b.cuda_stream) else None
+                if side is not None:
+                    with torch.cuda.stream(side):
+                        out['after_detect'] = after_detect(out)
+                else:
+                    out['after_detect'] = after_detect(out)
+            return out
         with self._run_lock_for(x.device):    # a plan's arena / head buffers are shared state: one forward at a time per model
-            proto, out = plan.run(x, detect=lambda s: self.detect.run_device(
-                plan.loc, plan.conf, self._coef_for(plan, nomask), plan.priors, True, stream=s, slot=slot, conf_ld=plan.conf_ld),
-                skip_proto=nomask)
+            proto, out = plan.run(x, detect=detect_cb, skip_proto=nomask)
         out['proto'] = proto
         out['net'] = self                    # postprocess_batch's FastMaskIoUNet (YOLACT++) lives on the model, like dets['net']
         return out
@@ -319,14 +336,19 @@ class Yolact(nn.Module):
             plan.mark_done()                                     # the clones read the graph's static outputs
             return res
 
-    def forward_device(self, x):
+    def forward_device(self, x, after_detect=None):
         """Forward + Detect with NO host synchronisation: fixed-capacity device tensors
         (count [B], box [B,cap,4], score, cls, coef, prior) + 'proto'. Used by the data-parallel path
-        (yolact_amd.parallel) and by throughput runs that keep results on the GPU."""
+        (yolact_amd.parallel) and by throughput runs that keep results on the GPU.
+
+        after_detect (optional): `after_detect(out)` is called with Detect's outputs (everything but 'proto') as soon as Detect's
+        kernels are enqueued, with the stream they run on as torch's current stream; what it returns is out['after_detect'].  The
+        data-parallel path hands its record gather in here: the records do not depend on the prototypes, and the protonet is the
+        tail of the step."""
         L.require_cuda(x, 'input batch')
         x = x.detach().to(torch.float32).contiguous()
         with torch.cuda.device(x.device):
-            return self._forward_device_one(x)
+            return self._forward_device_one(x, after_detect=after_detect)
 
     def forward_sharded(self, x_global, dst=0, masks=None, mask_size=None):
         """Data-parallel inference of one global batch across the ranks of torch.distributed (one process per GPU, RCCL): this
