@@ -108,7 +108,7 @@ def build_model(device, size, config=CONFIG):
     return net.to(device), sd
 
 
-def roofline(net, x, reps=3):
+def roofline(net, x, reps=5):
     """Per-launch HIP-event timing of every conv launch (events recorded on the launch stream by the library)."""
     from yolact_amd import _lib as L
     lib = L.lib()
@@ -148,8 +148,22 @@ def roofline(net, x, reps=3):
     bound_ms = {'mfma': 0.0, 'hbm': 0.0}          # step-level sum of max(F / peak of the tile used, bytes / HBM peak) per launch
     wino_pending = None
     lv = {'n': 0, 'ms': 0.0, 'fl': 0.0, 'conv_bytes': 0.0, 'wd_bytes': 0.0, 'gemm_bytes': 0.0}
+    # every record of every pass first: a record's duration is the MEDIAN over the passes at its position (the events bracket a
+    # host-issued launch: a host thread descheduled between the start event and the launch shows up as a 26 ms "kernel" — seen once on
+    # a loaded host, session r5fz — and a mean over three passes keeps a third of it)
+    recs = []
     for i in range(n):
         L.check(lib.ymi_prof_read(i, C.byref(ms), C.byref(fl), C.byref(tile), C.byref(kind)))
+        recs.append([ms.value, fl.value, tile.value, kind.value])
+    nper = n // reps if reps and n % reps == 0 else 0
+    if nper and all(recs[r * nper + i][3] == recs[i][3] for r in range(reps) for i in range(nper)):
+        import statistics
+        for i in range(nper):
+            med = statistics.median(recs[r * nper + i][0] for r in range(reps))
+            for r in range(reps):
+                recs[r * nper + i][0] = med
+    for i in range(n):
+        ms.value, fl.value, tile.value, kind.value = recs[i]
         tname = L.TILE_NAMES.get(tile.value, '?')
         if kind.value == 12:      # a 1x1 layer computed INSIDE the previous layer's F(4x4) output transform (ymi_wino_desc.proj_*): its
             li += 1               # algorithmic FLOPs count for the step, its time is part of that layer's record
