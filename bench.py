@@ -108,6 +108,22 @@ def build_model(device, size, config=CONFIG):
     return net.to(device), sd
 
 
+def median_over_passes(recs, reps):
+    """recs: the [ms, flops, tile, kind] records of `reps` identical passes over the op list, pass after pass.  Replaces every record's
+    duration by the median over the passes at its position — in place, and only when the passes really are the same sequence (same
+    count, same kinds); returns whether it did."""
+    import statistics
+    n = len(recs)
+    nper = n // reps if reps > 0 and n and n % reps == 0 else 0
+    if not nper or not all(recs[r * nper + i][3] == recs[i][3] for r in range(reps) for i in range(nper)):
+        return False
+    for i in range(nper):
+        med = statistics.median(recs[r * nper + i][0] for r in range(reps))
+        for r in range(reps):
+            recs[r * nper + i][0] = med
+    return True
+
+
 def roofline(net, x, reps=5):
     """Per-launch HIP-event timing of every conv launch (events recorded on the launch stream by the library)."""
     from yolact_amd import _lib as L
@@ -155,13 +171,7 @@ def roofline(net, x, reps=5):
     for i in range(n):
         L.check(lib.ymi_prof_read(i, C.byref(ms), C.byref(fl), C.byref(tile), C.byref(kind)))
         recs.append([ms.value, fl.value, tile.value, kind.value])
-    nper = n // reps if reps and n % reps == 0 else 0
-    if nper and all(recs[r * nper + i][3] == recs[i][3] for r in range(reps) for i in range(nper)):
-        import statistics
-        for i in range(nper):
-            med = statistics.median(recs[r * nper + i][0] for r in range(reps))
-            for r in range(reps):
-                recs[r * nper + i][0] = med
+    median_over_passes(recs, reps)
     for i in range(n):
         ms.value, fl.value, tile.value, kind.value = recs[i]
         tname = L.TILE_NAMES.get(tile.value, '?')
