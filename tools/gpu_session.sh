@@ -20,6 +20,8 @@
 #   plusab       A/B of the DCN offset / mask convolution layouts on configs[3];   tuneplus = re-tune configs[3] + bench with the layer table
 #   py:<file>    python <file> (a probe under tools/), output to <file basename>.log
 #   boxinfo      tools/box_info.sh: driver / firmware / partition / clock facts of THIS box (to tell the pool's boxes apart)
+#   exab         same-box A/B: record gather enqueued behind Detect on its stream (default) against behind the whole forward
+#   allocab      same-box A/B: one 16 GiB device mapping for every buffer / expandable segments against the default allocator
 O=gpurun_out/$1; shift; mkdir -p $O
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
