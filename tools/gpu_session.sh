@@ -129,6 +129,12 @@ PY
       (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE --kernel-include-regex chain_h2_k -f csv -d $R/$O/chainpmc2 -- bash -c "cd $R && $PCMD" > $R/$O/chainpmc2.log 2>&1)
       for k in 1 2; do python tools/pmc_summary.py $O/chainpmc$k > $O/pmc_chain_p$k.tsv 2> $O/chainpmc$k.err; cat $O/pmc_chain_p$k.tsv | cut -c1-420; done
       find $O -name "*counter_collection.csv" -size +4M -delete ;;
+    pipetrace) # diagnostics build of csrc/dcn.hip, then the per-block phase stamps of pipe_h2_k on the plan's layers (tools/pipe_trace.py); the product dcn.o is linked back afterwards
+      (cd yolact_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-value -I../../include -DYMI_DIAGNOSTICS=1 -c dcn.hip -o /tmp/dcn_diag.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls *.o | grep -v '^dcn.o$') /tmp/dcn_diag.o -o ../libyolact_amd.so) > $O/pipetrace_build.log 2>&1; tail -2 $O/pipetrace_build.log
+      timeout 600 python tools/pipe_trace.py --mode 1 ${arg:+--layers $arg} > $O/pipe_phase_trace.txt 2>&1
+      timeout 600 python tools/pipe_trace.py --mode 2 ${arg:+--layers $arg} > $O/pipe_phase_trace_mode2.txt 2>&1
+      (cd yolact_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC *.o -o ../libyolact_amd.so) >> $O/pipetrace_build.log 2>&1
+      grep -vE "^\[W|amdgpu.ids" $O/pipe_phase_trace.txt | head -60 ;;
     pipeabl) # diagnostics build of csrc/dcn.hip, then the ablation of the pipelined kernel as an ordinary convolution on representative layers
       (cd yolact_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-value -I../../include -DYMI_DIAGNOSTICS=1 -c dcn.hip -o /tmp/dcn_diag.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls *.o | grep -v '^dcn.o$') /tmp/dcn_diag.o -o ../libyolact_amd.so) > $O/pipeabl_build.log 2>&1; tail -2 $O/pipeabl_build.log
       timeout 600 python tools/pipe_probe.py --layers ${arg:-proto.8,proto.2,layer1.1.conv2,layer1.1.conv1,layer2.1.conv1,layer3.0.conv1,layer2.1.conv3} --ablate 1,2,3,4,8,12,16,15,31 > $O/pipe_ablation.txt 2>&1; grep -E "abl=|pipelined" $O/pipe_ablation.txt | cut -c1-330 ;;

@@ -58,6 +58,10 @@ struct DcnParams {
   int om_layout;
   int abl;      // diagnostics build only (env YMI_DCN_ABLATE): bit0 corner loads -> OOB (no memory access), bit1 filter DMAs -> OOB,
                 // bit2 no combine / LDS store, bit3 no MFMAs, bit4 no barrier, bit5 no vmcnt wait — wrong results by design; bit6 no residency cap
+  unsigned long long *trace;    // diagnostics build only (env YMI_PIPE_TRACE = device address of a u64 buffer, 16 slots per block): phase
+                                // time stamps of wave 0 (tools/pipe_trace.py).  Stamps are kept in registers and written behind the
+                                // kernel's last store (a store inside the pipeline would change its counted vmcnt waits)
+  int trace_mode;               // 1: stamps at the kernel's own synchronisation points only; 2: + a stamp that WAITS for the tensor scale
 };
 
 template <int WM, int WN, int TM, int TN, int RING>
@@ -110,6 +114,15 @@ void pipe_h2_k(const DcnParams p) {
   const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int kq = t & 7, r0 = t >> 3;
+#ifdef YMI_DIAGNOSTICS
+  unsigned long long tr_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tr_rt0 = 0;
+  const bool tracing = p.trace != nullptr;
+#define YMI_STAMP(i) do { if (tracing) tr_[i] = __builtin_amdgcn_s_memtime(); } while (0)
+  if (tracing) tr_rt0 = __builtin_amdgcn_s_memrealtime();
+  YMI_STAMP(0);
+#else
+#define YMI_STAMP(i) do { } while (0)
+#endif
 
   const int logical = ymi_xcd_remap(blockIdx.x, gridDim.x);
   const int tile_n = logical % p.tiles_n, tile_m = logical / p.tiles_n;
@@ -122,6 +135,13 @@ void pipe_h2_k(const DcnParams p) {
   float sA, invA;
   ymi_h2_scale(ymi_amax_read(p.x_amax), sA, invA);
   const ymi_amax_pre apre = ymi_amax_prefetch(p.y_amax);
+#ifdef YMI_DIAGNOSTICS
+  if (tracing && p.trace_mode == 2) {      // wait for the magnitude bound (the stamp takes the scale as an operand)
+    unsigned long long tt;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt) : "s"(__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sA))) : "memory");
+    tr_[1] = tt;
+  }
+#endif
 
   // ---- epilogue mapping (conv_igemm.hip's fast path) ------------------------------------------------------------------------
   constexpr int C4 = BN / 4, RSTEP = NT / C4, RPT = BM / RSTEP;
@@ -387,6 +407,7 @@ void pipe_h2_k(const DcnParams p) {
   };
 
   // ---- prologue: chunks 0 .. RING requested, chunk 0 combined ---------------------------------------------------------------
+  YMI_STAMP(2);                 // index arithmetic done
   raw_fetch(g_tap);
   tap_step();
 #pragma unroll
@@ -410,8 +431,10 @@ void pipe_h2_k(const DcnParams p) {
 #pragma unroll
   for (int i = 0; i < RB; ++i) issue_b_piece(RING, RING, i);
   chunk_advance();
+  YMI_STAMP(3);                 // prologue requests issued, chunk 0 combined (its loads have arrived)
   YMI_WAIT_VM(N_STEADY);        // the filter DMA of chunk 0 has RING * (NG + NB) younger operations behind it
   YMI_BARRIER();
+  YMI_STAMP(4);                 // first barrier passed: the main loop starts
 
   // ---- main loop: RING steps per trip (the ring slot is a compile-time index) -----------------------------------------------
   // (RING == 2: both steps unconditionally inside the trip: with `if (st + 1 < nk)` around the second one the CFG has a path from
@@ -427,8 +450,10 @@ void pipe_h2_k(const DcnParams p) {
   } else {
     for (int st = 0; st < nk; ++st) step(st, std::integral_constant<int, 0>{});
   }
+  YMI_STAMP(5);                 // main loop done
   YMI_WAIT_VM(0);               // the run-ahead filter DMAs target LDS the epilogue is about to reuse
   YMI_BARRIER();
+  YMI_STAMP(6);
 #undef YMI_WAIT_VM
 #undef YMI_BARRIER
 
@@ -472,6 +497,7 @@ void pipe_h2_k(const DcnParams p) {
   }
   sc = sc * invA;               // exact (a power of two); (v * invA) * sc == v * (invA * sc)
   __syncthreads();
+  YMI_STAMP(7);                 // accumulators transposed through LDS (and scale / bias / residual loads back)
   const float slope = p.act == YMI_ACT_RELU ? 0.f : (p.act == YMI_ACT_LEAKY01 ? 0.1f : 1.f);
   float am = 0.f;
   f32x4 o[RPT];
@@ -495,6 +521,25 @@ void pipe_h2_k(const DcnParams p) {
       }
   }
   if (p.y_amax) ymi_amax_finish(apre, am);
+#ifdef YMI_DIAGNOSTICS
+  if (tracing) {
+    YMI_STAMP(8);               // stores and the bound's atomic issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    YMI_STAMP(9);               // ... and acknowledged
+    if (t == 0) {
+      unsigned long long *o = p.trace + 16 * (size_t)(blockIdx.x + gridDim.x * blockIdx.y);
+#pragma unroll
+      for (int i = 0; i < 10; ++i) o[i] = tr_[i];
+      o[10] = tr_rt0;
+      o[11] = __builtin_amdgcn_s_memrealtime();
+      o[12] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);                                   // HW_REG_HW_ID
+      o[13] = (unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u);                            // XCC_ID
+      o[14] = (unsigned long long)my_nk;
+      o[15] = 1;
+    }
+  }
+#endif
+#undef YMI_STAMP
 #endif
 }
 
@@ -580,9 +625,11 @@ int run_pipe(const ymi_conv_desc *d, const float *offmask, int ldo, int mask_is_
   p.x_bytes = (unsigned)((size_t)d->B * d->H * d->W * d->ldx * sizeof(float));
   p.om_bytes = plain ? 0u : (unsigned)((size_t)M * ldo * sizeof(float));
   p.w_plane = (unsigned)((((long)d->Cout + 127) / 128 * 128) * d->Kpad * 2L);
-  p.abl = 0;
+  p.abl = 0; p.trace = nullptr; p.trace_mode = 0;
 #ifdef YMI_DIAGNOSTICS   // `make DIAG=1`: stall attribution for tools/dcn_probe.py — wrong results by design
   { const char *e = getenv("YMI_DCN_ABLATE"); p.abl = e ? atoi(e) : 0; }
+  { const char *e = getenv("YMI_PIPE_TRACE"); p.trace = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }
+  { const char *e = getenv("YMI_PIPE_TRACE_MODE"); p.trace_mode = e ? atoi(e) : 1; }
 #endif
   if (S > 1) {           // partial launches undo the operand scales only (true partial sums), the second pass does the rest
     p.scale_h2 = d->winv_h2; p.bias = nullptr; p.act = YMI_ACT_NONE; p.y_amax = nullptr; p.res = nullptr;

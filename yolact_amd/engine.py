@@ -65,6 +65,23 @@ def load_tune_table(device):
     return dict(_table_cache[arch])
 
 
+def build_meta():
+    """yolact_amd/build_meta.json, written by __graft_entry__.build(): {'lint': 'ok' | 'skipped'} (missing file: {})."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'build_meta.json')) as f:
+            doc = json.load(f)
+        return doc if isinstance(doc, dict) else {}
+    except (OSError, ValueError):
+        return {}
+
+
+def patch_tile_allowed():
+    """csrc/patch.hip issues gfx950's new MFMAs through the plain builtins (no constrained wrapper): what keeps its results right is the
+    post-build ISA lint (tools/check_mfma_overlap.py).  A build whose lint could NOT run (build_meta 'lint': 'skipped', only possible
+    with YOLACT_AMD_ALLOW_NO_LINT=1) must not select that tile (round-5 advisor); YOLACT_AMD_PATCH=0 is the A/B switch."""
+    return os.environ.get('YOLACT_AMD_PATCH', '1') == '1' and build_meta().get('lint', 'ok') != 'skipped'
+
+
 def split3_planes(w: torch.Tensor) -> torch.Tensor:
     """fp32 [..., R, K] -> bf16 bit patterns int16 [..., 3, R, K]: plane 0 = the top 8 significant bits of every value (its
     upper 16 bits, i.e. truncation to bf16), plane 1 = the top 8 bits of the exact remainder, plane 2 = what is left (at most
@@ -155,6 +172,17 @@ class Packed:
         checkpoints — same column signature, ordinary activations, no precision problem — and demoting those layers would silently
         cost them the fp16x2 tiles, Winograd and every fusion.  Without producer information (in_gain None) the weights-only test is
         kept, conservatively."""
+        memo = getattr(self, '_tiny_memo', None)
+        if memo is None:
+            memo = self._tiny_memo = {}
+        mkey = (binades, None if in_gain is None else (id(in_gain), int(in_gain.numel())))
+        if mkey in memo and (in_gain is None or memo[mkey][1] is in_gain):      # (the gain tensor is kept: its id cannot be reused)
+            return memo[mkey][0]
+        r = self._tiny_columns(binades, in_gain)
+        memo[mkey] = (r, in_gain)
+        return r
+
+    def _tiny_columns(self, binades, in_gain):
         w = self._wp_host[:self.Cout, :self.kh * self.kw * self.Cin].abs().float().cpu()
         col = w.view(self.Cout, self.kh * self.kw, self.Cin).amax(dim=(0, 1))
         nzm = col > 0
@@ -175,13 +203,17 @@ class Packed:
         return bool((tiny & (g >= pos.median() * float(2 ** max(binades - 4, 1)))).any())
 
     def out_gain(self):
-        """[Cout] per-output-channel gain of this layer: max|w[n, :]| x |folded BN scale[n]| (1 without BN) — how strongly the launch
-        amplifies each channel it writes.  Consumers compare it across channels (tiny_columns): an outlier channel of a BN-folded
-        checkpoint shows up as a gain far above the median."""
+        """[Cout] per-output-channel gain of this layer: max|w[n, :]| x |folded BN scale[n]| (1 without BN) + |folded shift[n]| — how
+        large the launch can make each channel it writes relative to the others.  Consumers compare it across channels
+        (tiny_columns): an outlier channel of a BN-folded checkpoint shows up as a gain far above the median, whether it comes from a
+        huge gamma / sigma or from a huge beta / mean shift (round-5 advisor: the shift used to be ignored; adding it is the
+        conservative fold — ordinary checkpoints have |shift| = O(1), which moves no channel 2^6 above the median)."""
         if getattr(self, '_out_gain', None) is None:
             g = self._wp_host[:self.Cout].abs().amax(dim=1).float().cpu()
             if self.scale is not None:
                 g = g * self.scale.detach().abs().float().cpu()
+            if self.bias is not None:
+                g = g + self.bias.detach().abs().float().cpu()[:self.Cout]
             self._out_gain = g
         return self._out_gain
 
@@ -326,13 +358,41 @@ def out_size(n, k, s, p):
     return (n + 2 * p - k) // s + 1
 
 
+class _OpList(list):
+    """The plan's op list: a list that counts its mutations.  The native executor's ymi_plan_op array bakes descriptor addresses and
+    op kinds; it is rebuilt whenever `version` moved (round-5 advisor: the earlier key, the ids of the op tuples, could repeat once the
+    tuner / the fusions had replaced a tuple and CPython reused the freed one's id)."""
+    version = 0
+
+    def _bump(self):
+        self.version += 1
+
+    def __setitem__(self, k, v):
+        self._bump(); list.__setitem__(self, k, v)
+
+    def __delitem__(self, k):
+        self._bump(); list.__delitem__(self, k)
+
+    def append(self, v):
+        self._bump(); list.append(self, v)
+
+    def insert(self, k, v):
+        self._bump(); list.insert(self, k, v)
+
+    def pop(self, *a):
+        self._bump(); return list.pop(self, *a)
+
+    def extend(self, it):
+        self._bump(); list.extend(self, it)
+
+
 class Plan:
     def __init__(self, net, B, H, W, device, dry_two_streams=False):
         """`dry_two_streams`: emit the two-stream op list (fork / join markers, per-stream arenas) without creating HIP
         streams or events — for static checks of the schedule on a machine without a GPU (tests/test_plan_schedule.py);
         such a plan cannot be run."""
         self.net, self.B, self.H, self.W, self.device = net, B, H, W, device
-        self.ops = []          # (callable, args...) executed in order
+        self.ops = _OpList()   # (callable, args...) executed in order; counts its mutations (native executor cache)
         self.conv_meta = []    # (name, desc) for profiling / roofline accounting
         self.arena = Arena(device)
         self.keepalive = []
@@ -1036,7 +1096,7 @@ class Plan:
         """The op list as a ymi_plan_op array (rebuilt whenever an op was replaced: tuner, set_winograd), the index of the Detect
         marker, the event handles and the index of the input-layout op.  None when the list holds a call the executor does not know
         (the Python loop then runs it)."""
-        key = tuple(map(id, self.ops))
+        key = (self.ops.version, len(self.ops)) if isinstance(self.ops, _OpList) else tuple(map(id, self.ops))
         if self._native is not None and self._native[0] == key:
             return self._native[1]
         lib = self.lib
@@ -1091,6 +1151,9 @@ class Plan:
             self._native = (key, None)
             return None
         if self._native_events is None or len(self._native_events) < len(ev_index):
+            for h in (self._native_events or ()):       # regrown: the old handles are destroyed, not leaked
+                if h:
+                    lib.ymi_event_destroy(C.c_void_p(h))
             evs = (C.c_void_p * max(len(ev_index), 1))()
             for q in range(len(ev_index)):
                 h = C.c_void_p()
@@ -1411,7 +1474,7 @@ class Plan:
             key = key + (('wide',) if wide else ())
             if key not in cache and skey in disk:
                 v_ = int(disk[skey])
-                patch_off = ((v_ & 255) == (L.DCNP_PATCH_C64 | L.TILE_H2 | L.TILE_DCNP) and os.environ.get('YOLACT_AMD_PATCH', '1') != '1')
+                patch_off = ((v_ & 255) == (L.DCNP_PATCH_C64 | L.TILE_H2 | L.TILE_DCNP) and not patch_tile_allowed())
                 # (YOLACT_AMD_PATCH=0: the A/B switch of csrc/patch.hip — a table entry that names it counts as a miss)
                 if not patch_off and self._apply_choice(fn, dptr, where, disk[skey], s) == 0:   # a stale / foreign entry must not make every forward raise
                     cache[key] = v_
@@ -1446,7 +1509,7 @@ class Plan:
                 if not is_dcn and h2_ and self.pipe and self._pipe_ok(d):   # the same pipelined kernel as an ordinary convolution
                     cands = cands + self.dcnp_candidates(d) + self.ws_candidates(d)     # (+ the streaming kernel for narrow outputs)
                     if ((d.kh, d.kw, d.stride, d.pad, d.Cin, d.Cout) == (3, 3, 1, 1, 64, 64) and d.res_mode == L.RES_NONE
-                            and os.environ.get('YOLACT_AMD_PATCH', '1') == '1'):
+                            and patch_tile_allowed()):
                         cands = cands + [L.DCNP_PATCH_C64 | L.TILE_H2 | L.TILE_DCNP]    # csrc/patch.hip: the input patch in LDS, filters in registers
                 if not is_dcn and self._splitk_ok(d) and self.splitk:
                     # split-K candidates: big tiles whose grid alone cannot fill the chip, K cut 2 / 4 ways

@@ -220,6 +220,9 @@ class Yolact(nn.Module):
             return plan.coef
         if getattr(plan, 'zero_coef', None) is None:
             plan.zero_coef = torch.zeros_like(plan.coef)
+            # the fill runs on torch's current stream, Detect on the plan's side stream with no event between them (round-5
+            # advisor): a one-time host wait at the first --detect forward of a plan orders them for good
+            torch.cuda.current_stream(plan.coef.device).synchronize()
         return plan.zero_coef
 
     def maskiou_forward(self, masks_lo):
@@ -273,12 +276,12 @@ class Yolact(nn.Module):
 
     def _forward_device_one(self, x, slot=0, after_detect=None):
         plan = self.plan_for(x, slot)
+        nomask = not bool(getattr(self.cfg, 'eval_mask_branch', True))
         if os.environ.get('YOLACT_AMD_GRAPH', '0') == '1':
-            out = self._forward_device_graph(plan, x, slot)
+            out = self._forward_device_graph(plan, x, slot, nomask)
             if after_detect is not None:       # (a replayed graph has no point "after Detect": the hook runs behind the whole replay)
                 out['after_detect'] = after_detect(out)
             return out
-        nomask = not bool(getattr(self.cfg, 'eval_mask_branch', True))
 
         def detect_cb(s):
             out = self.detect.run_device(plan.loc, plan.conf, self._coef_for(plan, nomask), plan.priors, True, stream=s, slot=slot,
@@ -301,13 +304,13 @@ class Yolact(nn.Module):
         out['net'] = self                    # postprocess_batch's FastMaskIoUNet (YOLACT++) lives on the model, like dets['net']
         return out
 
-    def _forward_device_graph(self, plan, x, slot):
+    def _forward_device_graph(self, plan, x, slot, nomask=False):
         """YOLACT_AMD_GRAPH=1: the whole op list of the plan (both streams, ~190 launches incl. Detect) is captured once
         into a hipGraph and replayed per batch — one submission instead of ~190 launches, which is what bounds small
         batches (batch 1: the GPU idles between 10-20 us kernels while Python issues the next one).  The graph owns a
         static input and static outputs; every call copies x in and clones the results out, so returned tensors keep
         the eager path's lifetime rules."""
-        key = ('graph', tuple(x.shape), x.device, slot)
+        key = ('graph', tuple(x.shape), x.device, slot, bool(nomask))   # cfg.eval_mask_branch changes the captured launches
         # capture and replay touch the plan's shared arena / head buffers exactly like an eager run: same host lock, and
         # the device-side ordering against the previous run (possibly on another stream) through the plan's done-event
         with self._run_lock_for(x.device):
@@ -318,7 +321,8 @@ class Yolact(nn.Module):
             if rec is None:
                 def body(inp):
                     proto, out = plan.run(inp, detect=lambda s: self.detect.run_device(
-                        plan.loc, plan.conf, plan.coef, plan.priors, True, stream=s, slot=slot, conf_ld=plan.conf_ld))
+                        plan.loc, plan.conf, self._coef_for(plan, nomask), plan.priors, True, stream=s, slot=slot, conf_ld=plan.conf_ld),
+                        skip_proto=nomask)
                     out['proto'] = proto
                     out['net'] = self
                     return out
