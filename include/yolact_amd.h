@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define YMI_ABI_VERSION 7
+#define YMI_ABI_VERSION 8
 
 /* negative return codes (ymi_strerror) */
 #define YMI_EFORMAT (-4)       /* corrupt or truncated input stream (ymi_jpeg_*) */
@@ -156,7 +156,13 @@ enum { YMI_DCNP_64x128 = 1, YMI_DCNP_64x128_W8 = 2, YMI_DCNP_64x64 = 3, YMI_DCNP
        /* round 5, csrc/patch.hip: 3x3 / stride 1 / pad 1, 64 -> 64 channels (conv2 of the first ResNet stage, backbone.py:44-46), one
         * dense output, no residual: a persistent block per CU owns 8 x 16 pixel output tiles, the 10 x 18 x 64 input patch lives in
         * LDS as fp16 planes (loaded ONCE instead of once per filter tap) and the filters live in registers */
-       YMI_DCNP_PATCH_C64 = 28 };
+       YMI_DCNP_PATCH_C64 = 28,
+       /* round 6, csrc/pcconv.hip: the same convolutions as the pipelined tiles (3x3 / pad 1 or 1x1 / pad 0, Cin % 32 == 0, one dense
+        * output, optional residual, optional split_k) as a PRODUCER / CONSUMER block: four consumer waves (one per SIMD: fragment
+        * reads + MFMAs only) and four producer waves (row requests, the fp32 -> fp16-plane split, the filter LDS-DMAs), so that a
+        * request stalled on the vector-memory pipe no longer holds MFMAs back.  BM x BN = the block tile; results are bit-identical
+        * to the pipelined tiles' (same products, same order per accumulator) */
+       YMI_DCNP_PC_128x128 = 29, YMI_DCNP_PC_256x128 = 30, YMI_DCNP_PC_128x256 = 31 };
 
 int ymi_abi_version(void);
 const char *ymi_strerror(int code);
@@ -439,7 +445,7 @@ typedef struct ymi_stem_desc {
 } ymi_stem_desc;
 int ymi_stem_pool_f32(const ymi_stem_desc *d, void *stream);
 
-/* -- two chained 1x1 convolutions of the first ResNet stage in one streaming launch (csrc/chain.hip) -------------------------
+/* -- two chained 1x1 convolutions of a ResNet stage in one launch (csrc/chain.hip: 64 planes; csrc/chain2.hip, ABI 8: 128 / 256) --
  *     y = act_a(scale_a * (W_a x) + bias_a + res)      conv3 + bn3 + shortcut + ReLU of Bottleneck b   (backbone.py:49-55)
  *     z = act_b(scale_b * (W_b y) + bias_b)            conv1 + bn1 + ReLU of Bottleneck b + 1          (backbone.py:41-43)
  * x [M,ldx] (k_a = 64 channels), res [M,res_ld] or NULL, y [M,ldy] (n_a = 256), z [M,ldz] (n_b = 64) or NULL (then only y is
@@ -459,9 +465,16 @@ typedef struct ymi_chain_desc {
   float *y_amax, *z_amax;                                    /* may be NULL */
   int64_t M;
   int32_t ldx, res_ld, ldy, ldz;
-  int32_t k_a, n_a, n_b;                                     /* 64, 256, 64: the only instantiated shape */
+  int32_t k_a, n_a, n_b;                                     /* (P, 4P, P) with P = 64 (csrc/chain.hip), 128 or 256 (csrc/chain2.hip) */
   int32_t cout_pad_a, cout_pad_b;                            /* rows per filter plane (engine.Packed.CoutPad) */
   int32_t act_a, act_b, _pad0;                               /* YMI_ACT_NONE / RELU / LEAKY01 */
+  /* ABI 8, P = 128 / 256 only (ignored at P = 64): the y slices of a block feed ONE accumulation of z and therefore share one
+   * power-of-two scale, derived when the kernel starts from a rigorous bound of y:
+   *     |y| <= amax(x) * gain_a + bias_max_a + amax(res)
+   * gain_a = max_n(|folded BN scale_n| * sum_k |w_a[n, k]|) (> 0), bias_max_a = max_n |bias_a[n]| (>= 0), both from the fp32
+   * filters (engine.Packed.l1_gain()); res_amax = the magnitude-bound slot of the residual tensor (required when res != NULL). */
+  const float *res_amax;
+  float gain_a, bias_max_a;
 } ymi_chain_desc;
 int ymi_pointwise_chain_f32(const ymi_chain_desc *d, void *stream);
 

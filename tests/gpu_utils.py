@@ -140,34 +140,37 @@ def run_wino(x, weight, bias=None, bn=None, act=L.ACT_NONE, tile=L.TILE_AUTO, m=
 
 
 def run_chain(x, wa, ba, res, wb=None, bb=None, act_a=L.ACT_RELU, act_b=L.ACT_RELU):
-    """ymi_pointwise_chain_f32 on CPU tensors: x [M,64], wa [256,64], res [M,256] or None, wb [64,256] or None.
-    Returns (y [M,256], z [M,64] or None) on the CPU; run_chain.last_amax = the bounds reported for (y, z)."""
-    M = x.shape[0]
-    pa = Packed(wa.view(256, 64, 1, 1), ba, None, 1, 0, None, DEV)
+    """ymi_pointwise_chain_f32 on CPU tensors: x [M,P], wa [4P,P], res [M,4P] or None, wb [P,4P] or None (P = 64: csrc/chain.hip;
+    P = 128 / 256: csrc/chain2.hip).  Returns (y [M,4P], z [M,P] or None) on the CPU; run_chain.last_amax = the bounds reported for (y, z)."""
+    M, P = x.shape
+    pa = Packed(wa.view(4 * P, P, 1, 1), ba, None, 1, 0, None, DEV)
     pla, sca, _ = pa.h2()
     xd = x.contiguous().to(DEV)
-    y = torch.full((M, 256), float('nan'), device=DEV)
-    amax = torch.zeros(3 * 1024, device=DEV)
+    y = torch.full((M, 4 * P), float('nan'), device=DEV)
+    amax = torch.zeros(4 * 1024, device=DEV)
     L.check(L.lib().ymi_amax_f32(xd.data_ptr(), xd.numel(), amax.data_ptr(), L.stream_ptr()), 'amax')
     d = L.ChainDesc()
-    d.x, d.y, d.M, d.ldx, d.ldy = xd.data_ptr(), y.data_ptr(), M, 64, 256
+    d.x, d.y, d.M, d.ldx, d.ldy = xd.data_ptr(), y.data_ptr(), M, P, 4 * P
     d.w_a_h2, d.scale_a_h2, d.cout_pad_a = pla.data_ptr(), sca.data_ptr(), pa.CoutPad
     d.bias_a = pa.bias.data_ptr() if pa.bias is not None else None
-    d.k_a, d.n_a, d.n_b, d.act_a, d.act_b = 64, 256, 64, act_a, act_b
+    d.k_a, d.n_a, d.n_b, d.act_a, d.act_b = P, 4 * P, P, act_a, act_b
     d.x_amax, d.y_amax, d.z_amax = amax.data_ptr(), amax.data_ptr() + 4096, amax.data_ptr() + 8192
+    d.gain_a, d.bias_max_a = pa.l1_gain()
     rd = None
     if res is not None:
         rd = res.contiguous().to(DEV)
-        d.res, d.res_ld = rd.data_ptr(), 256
+        d.res, d.res_ld = rd.data_ptr(), 4 * P
+        d.res_amax = amax.data_ptr() + 12288
+        L.check(L.lib().ymi_amax_f32(rd.data_ptr(), rd.numel(), d.res_amax, L.stream_ptr()), 'amax')
     z = keep = None
     if wb is not None:
-        pb = Packed(wb.view(64, 256, 1, 1), bb, None, 1, 0, None, DEV)
+        pb = Packed(wb.view(P, 4 * P, 1, 1), bb, None, 1, 0, None, DEV)
         plb, scb, _ = pb.h2()
         keep = (pb, plb, scb)
-        z = torch.full((M, 64), float('nan'), device=DEV)
-        d.z, d.ldz, d.w_b_h2, d.scale_b_h2, d.cout_pad_b = z.data_ptr(), 64, plb.data_ptr(), scb.data_ptr(), pb.CoutPad
+        z = torch.full((M, P), float('nan'), device=DEV)
+        d.z, d.ldz, d.w_b_h2, d.scale_b_h2, d.cout_pad_b = z.data_ptr(), P, plb.data_ptr(), scb.data_ptr(), pb.CoutPad
         d.bias_b = pb.bias.data_ptr() if pb.bias is not None else None
     L.check(L.lib().ymi_pointwise_chain_f32(C.byref(d), L.stream_ptr()), 'chain')
     torch.cuda.synchronize()
-    run_chain.last_amax = amax.view(3, 1024).amax(1).cpu().tolist()[1:]
+    run_chain.last_amax = amax.view(4, 1024).amax(1).cpu().tolist()[1:3]
     return y.cpu(), (z.cpu() if z is not None else None)

@@ -234,6 +234,7 @@ def test_dcn_matches_oracle(stride, tile):
 
 PIPE_ALL = [t | L.TILE_H2 | L.TILE_DCNP for t in sorted(L.DCNP_TILES)]                 # every block tile of csrc/dcn.hip
 DCNP_ALL = [t for t in PIPE_ALL if (t & 31) not in L.DCNP_PLAIN_ONLY]                     # ... that the DCN gather can use
+PC_ALL = [t | L.TILE_H2 | L.TILE_DCNP for t in sorted(L.PC_TILES)]                     # producer / consumer blocks of csrc/pcconv.hip (round 6)
 
 
 @pytest.mark.parametrize('tile', DCNP_ALL)
@@ -287,7 +288,7 @@ def test_dcn_pipelined_split_k(tile, split):
     assert torch.equal(y, y2)                                               # fixed summation order: bit-reproducible
 
 
-@pytest.mark.parametrize('tile', PIPE_ALL)
+@pytest.mark.parametrize('tile', PIPE_ALL + PC_ALL)
 @pytest.mark.parametrize('case', [(2, 64, 19, 17, 72, 3, 1, False, L.ACT_RELU), (1, 128, 23, 21, 260, 3, 2, False, L.ACT_NONE),
                                   (2, 256, 14, 15, 64, 1, 1, True, L.ACT_RELU), (3, 64, 9, 10, 128, 1, 2, False, L.ACT_LEAKY01),
                                   (1, 32, 31, 29, 36, 3, 1, False, L.ACT_RELU), (2, 96, 12, 13, 512, 1, 1, True, L.ACT_LEAKY01),
@@ -299,7 +300,7 @@ def test_pipelined_kernel_as_ordinary_convolution(case, tile):
     and column tiles, odd chunk counts — against torch fp32."""
     from gpu_utils import run_conv, rel_err
     B, Cin, H, W, Cout, k, stride, has_res, act = case
-    if (tile & 31) >= L.DCNP_128x32_W4 and Cout > 32:
+    if L.DCNP_128x32_W4 <= (tile & 31) <= L.DCNP_64x32_W2 and Cout > 32:
         pytest.skip('32-column tiles take Cout <= 32 only (rejected with YMI_EARG: test_dcn_pipelined_rejects_what_it_cannot_run)')
     g = _g(300 + Cin + Cout + k)
     x = torch.randn(B, Cin, H, W, generator=g)
@@ -321,7 +322,7 @@ def test_pipelined_kernel_as_ordinary_convolution(case, tile):
     assert abs(run_conv.last_amax[1] - ref.abs().max().item()) <= 2e-5 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize('tile', [L.DCNP_64x128_W8, L.DCNP_128x128_W8_R1, L.DCNP_96x256_W12, L.DCNP_128x256_W16, L.DCNP_32x128, 14, 15, 16])
+@pytest.mark.parametrize('tile', [L.DCNP_64x128_W8, L.DCNP_128x128_W8_R1, L.DCNP_96x256_W12, L.DCNP_128x256_W16, L.DCNP_32x128, 14, 15, 16, 29, 30, 31])
 @pytest.mark.parametrize('split', [2, 3, 4, 8])
 def test_pipelined_ordinary_convolution_split_k(tile, split):
     """K ranges on the PLAIN path (1x1, K = 512 -> 16 chunks; 3x3 with a residual): partial sums + the deterministic second pass."""
@@ -342,6 +343,30 @@ def test_pipelined_ordinary_convolution_split_k(tile, split):
     if per >= 2 and per * (split - 1) < 18:
         y3 = run_conv(x3, w3, None, None, 2, 1, tile=t, split_k=split)
         assert rel_err(y3, F.conv2d(x3, w3, None, 2, 1)) < 2e-5
+
+
+@pytest.mark.parametrize('tile', PC_ALL)
+@pytest.mark.parametrize('case', [(8, 1024, 35, 35, 256, 1, 1, False), (2, 128, 69, 69, 128, 3, 1, False), (8, 256, 35, 35, 1024, 1, 1, True),
+                                  (2, 512, 35, 35, 256, 3, 2, False), (1, 64, 7, 5, 68, 3, 1, True), (1, 96, 3, 3, 36, 1, 1, False)])
+def test_producer_consumer_kernel_is_bit_identical_to_the_pipelined_tile(case, tile):
+    """csrc/pcconv.hip against the pipelined kernel of csrc/dcn.hip on the same descriptor: same products, same order per accumulator,
+    same epilogue — the outputs and the recorded magnitude bound are equal bit for bit (backbone-sized and ragged shapes, residual,
+    stride 2, odd chunk counts); torch fp32 as the outside reference."""
+    from gpu_utils import run_conv, rel_err
+    B, Cin, H, W, Cout, k, stride, has_res = case
+    g = _g(900 + Cin + Cout + k)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    pad = 1 if k == 3 else 0
+    ref = F.conv2d(x, w, b, stride, pad)
+    res = torch.randn(ref.shape, generator=g) if has_res else None
+    kw = dict(act=L.ACT_RELU, res=res, res_mode=L.RES_ADD if has_res else L.RES_NONE)
+    y = run_conv(x, w, b, None, stride, pad, tile=tile, **kw)
+    am = run_conv.last_amax[1]
+    y0 = run_conv(x, w, b, None, stride, pad, tile=L.DCNP_128x128_W8_R1 | L.TILE_H2 | L.TILE_DCNP, **kw)
+    assert torch.equal(y, y0) and am == run_conv.last_amax[1]
+    assert rel_err(y, torch.relu(ref + res) if has_res else torch.relu(ref)) < 2e-5
 
 
 @pytest.mark.parametrize('tile', [L.DCNP_128x32_W4, L.DCNP_256x32_W8, L.DCNP_64x32_W2])
@@ -435,6 +460,42 @@ def test_pointwise_chain_matches_fp64(M, mode):
         assert torch.equal(y, y2) and torch.equal(z, z2)
     else:
         assert z is None
+
+
+@pytest.mark.parametrize('P', [128, 256])
+@pytest.mark.parametrize('M,mode', [(64, 'chain'), (37, 'chain'), (9800, 'chain'), (1225, 'chain_nores_leaky'), (200, 'chain_big_res'),
+                                    (130, 'chain_outlier_row')])
+def test_pointwise_chain2_matches_fp64(M, mode, P):
+    """csrc/chain2.hip through ymi_pointwise_chain_f32 (P = 128 / 256 planes: y = act(W_a x + b_a + res) [P -> 4P] written once, each
+    128-channel slice fed from LDS into z = act(W_b y + b_b) [4P -> P]) against fp64: one block, a ragged block, the 35 x 35 x 8 map,
+    no residual + LeakyReLU, a residual 2^6 larger than the conv term and a row 2^8 larger than the rest (both stretch the y slices
+    below their shared bound-derived scale); the magnitude bounds of y and z; bit-reproducible."""
+    from gpu_utils import run_chain
+    g = _g(950 + M + P)
+    x = torch.randn(M, P, generator=g).abs() * 3
+    if mode == 'chain_outlier_row':
+        x[7] *= 256.0
+    wa = torch.randn(4 * P, P, generator=g) / P ** 0.5
+    ba = torch.randn(4 * P, generator=g) * 0.3
+    res = None if mode == 'chain_nores_leaky' else torch.randn(M, 4 * P, generator=g) * (128.0 if mode == 'chain_big_res' else 2.0)
+    wb = torch.randn(P, 4 * P, generator=g) / (4 * P) ** 0.5
+    bb = torch.randn(P, generator=g) * 0.1
+    act = L.ACT_LEAKY01 if mode == 'chain_nores_leaky' else L.ACT_RELU
+
+    def a_(t):
+        return torch.relu(t) if act == L.ACT_RELU else F.leaky_relu(t, 0.1)
+    yr = x.double() @ wa.double().t() + ba.double()
+    yr = a_(yr + res.double() if res is not None else yr)
+    zr = a_(yr @ wb.double().t() + bb.double())
+    y, z = run_chain(x, wa, ba, res, wb, bb, act, act)
+    assert ((y.double() - yr).abs().max() / yr.abs().max()).item() < 1e-6
+    assert abs(run_chain.last_amax[0] - yr.abs().max().item()) <= 2e-6 * yr.abs().max().item()
+    # per ROW for z: an outlier row must not hide the error of the ordinary ones behind its own scale
+    rel = (z.double() - zr).abs().amax(dim=1) / zr.abs().amax(dim=1).clamp_min(1e-30)
+    assert rel.max().item() < 2e-6, rel.max().item()
+    assert abs(run_chain.last_amax[1] - zr.abs().max().item()) <= 3e-6 * zr.abs().max().item()
+    y2, z2 = run_chain(x, wa, ba, res, wb, bb, act, act)
+    assert torch.equal(y, y2) and torch.equal(z, z2)
 
 
 WS_ALL = [t | L.TILE_H2 | L.TILE_DCNP for t in sorted(L.WS_TILES)]                     # every block shape of csrc/wstat.hip

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libyolact_amd.so')
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 ACT_NONE, ACT_RELU, ACT_LEAKY01, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 RES_NONE, RES_ADD, RES_BILINEAR = 0, 1, 2
@@ -49,7 +49,10 @@ WS_TILES = {20: 'ws128x32w4', 21: 'ws256x32w8', 22: 'ws256x32w4', 23: 'ws512x32w
 DCNP_WS_128x32_W4, DCNP_WS_512x64_W8 = 20, 27
 DCNP_PATCH_C64 = 28                 # csrc/patch.hip: 3x3 / s1 / p1, 64 -> 64, input patch in LDS, filters in registers
 PATCH_TILES = {28: 'patch8x16c64'}
-for _t, _n in list(DCNP_TILES.items()) + list(WS_TILES.items()) + list(PATCH_TILES.items()):
+# csrc/pcconv.hip (round 6): producer / consumer blocks (4 consumer + 4 producer waves); ordinary convolutions
+PC_TILES = {29: 'pc128x128', 30: 'pc256x128', 31: 'pc128x256'}
+DCNP_PC_128x128, DCNP_PC_256x128, DCNP_PC_128x256 = 29, 30, 31
+for _t, _n in list(DCNP_TILES.items()) + list(WS_TILES.items()) + list(PATCH_TILES.items()) + list(PC_TILES.items()):
     TILE_NAMES[_t | TILE_H2 | TILE_DCNP] = _n
 WINO_PLANES = 1024                  # tune-table flag on a Winograd GEMM tile id: V written as fp16x2 planes (ymi_wino_desc.v_planes)
 KSPLIT_TILES = (6, 7, 8, 13, 14, 15, 6 | 32, 7 | 32, 8 | 32, 6 | 64, 7 | 64, 8 | 64, 13 | 64, 14 | 64, 15 | 64)   # different (still deterministic) fp32 summation order than the unsplit tiles
@@ -121,7 +124,8 @@ class ChainDesc(C.Structure):
                 ('x_amax', C.c_void_p), ('y_amax', C.c_void_p), ('z_amax', C.c_void_p),
                 ('M', C.c_int64), ('ldx', C.c_int32), ('res_ld', C.c_int32), ('ldy', C.c_int32), ('ldz', C.c_int32),
                 ('k_a', C.c_int32), ('n_a', C.c_int32), ('n_b', C.c_int32), ('cout_pad_a', C.c_int32), ('cout_pad_b', C.c_int32),
-                ('act_a', C.c_int32), ('act_b', C.c_int32), ('_pad0', C.c_int32)]
+                ('act_a', C.c_int32), ('act_b', C.c_int32), ('_pad0', C.c_int32),
+                ('res_amax', C.c_void_p), ('gain_a', C.c_float), ('bias_max_a', C.c_float)]
 
 
 class StemDesc(C.Structure):

@@ -284,17 +284,22 @@ __global__ __launch_bounds__(64 * NW) void chain_h2_k(const ChainParams p) {
 // y = act_a(scale_a * (W_a x) + bias_a + res),  z = act_b(scale_b * (W_b y) + bias_b): two chained 1x1 convolutions, 64 -> 256 -> 64
 // (include/yolact_amd.h, ymi_chain_desc).  Profiling: record kind 13 = the launch with conv A's algorithmic FLOPs, then — when z
 // is computed — a kind-12 record (no duration of its own) carrying conv B's.
+int ymi_internal_chain2(const ymi_chain_desc *d, hipStream_t s);    // csrc/chain2.hip: 128 / 256 planes, filters streamed through LDS
+
 extern "C" int ymi_pointwise_chain_f32(const ymi_chain_desc *d, void *stream) {
   if (!d) return YMI_ENULL;
   if (!d->x || !d->w_a_h2 || !d->scale_a_h2 || !d->y || !d->x_amax) return YMI_ENULL;
   if (d->z && (!d->w_b_h2 || !d->scale_b_h2)) return YMI_ENULL;
-  if (d->M <= 0 || d->k_a != K1 || d->n_a != N1 || (d->z && d->n_b != N2)) return YMI_EARG;
+  const bool wide = d->k_a == 128 || d->k_a == 256;
+  if (d->M <= 0 || (!wide && (d->k_a != K1 || d->n_a != N1 || (d->z && d->n_b != N2)))) return YMI_EARG;
+  if (wide && (d->n_a != 4 * d->k_a || (d->z && d->n_b != d->k_a))) return YMI_EARG;
   if (d->act_a < 0 || d->act_a > YMI_ACT_LEAKY01 || d->act_b < 0 || d->act_b > YMI_ACT_LEAKY01) return YMI_EARG;
-  if (d->ldx < K1 || d->ldy < N1 || (d->z && d->ldz < N2) || (d->res && d->res_ld < N1)) return YMI_ESHAPE;
+  if (d->ldx < d->k_a || d->ldy < d->n_a || (d->z && d->ldz < d->n_b) || (d->res && d->res_ld < d->n_a)) return YMI_ESHAPE;
   if ((d->ldx | d->ldy | d->ldz | d->res_ld) & 3) return YMI_ESHAPE;
   if ((((uintptr_t)d->x) | ((uintptr_t)d->y) | ((uintptr_t)d->z) | ((uintptr_t)d->res) | ((uintptr_t)d->w_a_h2) | ((uintptr_t)d->w_b_h2)) & 15)
     return YMI_ESHAPE;
   if (d->M * (int64_t)(d->ldy > d->res_ld ? d->ldy : d->res_ld) >= (1LL << 29) || d->M * (int64_t)d->ldx >= (1LL << 29)) return YMI_ESHAPE;   // 32-bit buffer offsets
+  if (wide) return ymi_internal_chain2(d, (hipStream_t)stream);
   if (d->cout_pad_a < N1 || (d->z && d->cout_pad_b < N2)) return YMI_ESHAPE;
   ChainParams p;
   p.x = d->x; p.res = d->res; p.x_amax = d->x_amax; p.wa = d->w_a_h2; p.wb = d->w_b_h2;

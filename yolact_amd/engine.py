@@ -217,6 +217,18 @@ class Packed:
             self._out_gain = g
         return self._out_gain
 
+    def l1_gain(self):
+        """(max_n(|folded BN scale_n| * sum_k |w[n, k]|), max_n |folded shift_n|): |y_n| <= amax(x) * gain + shift_max for every
+        output of this layer before the residual / activation — the rigorous bound csrc/chain2.hip scales its y slices by
+        (ymi_chain_desc.gain_a / bias_max_a)."""
+        if getattr(self, '_l1_gain', None) is None:
+            g = self._wp_host[:self.Cout].detach().cpu().abs().double().sum(dim=1)
+            if self.scale is not None:
+                g = g * self.scale.detach().abs().double().cpu()
+            b = float(self.bias.detach().abs().max().cpu()) if self.bias is not None else 0.0
+            self._l1_gain = (float(g.max()) * (1.0 + 2.0 ** -20), b)       # (a hair above the fp64 sum: fp32 evaluation on the device)
+        return self._l1_gain
+
     def w3(self):
         """[3][CoutPad][Kpad] bf16 planes of the same filters for the bf16x3 tiles (built on first use)."""
         if self._w3 is None:
@@ -547,6 +559,9 @@ class Plan:
             for i, s in enumerate(segs):
                 d.seg[i] = L.ConvSeg(*s)
         self.keepalive.append(pk)
+        if not hasattr(self, '_desc_info'):
+            self._desc_info = {}
+        self._desc_info[C.addressof(d)] = (pk, res.slot if res is not None else None)     # (the chain fusion needs both: l1_gain, res_amax)
         wino = None
         if (self.use_winograd and dcn_offmask is None and out is None and pk.weight_oihw is not None and not wide
                 and wino_eligible(pk, res, segs, act, x.C)):
@@ -1329,23 +1344,34 @@ class Plan:
                 continue
             d3 = p3.contents
             M = d3.B * d3.Ho * d3.Wo
-            if not ((d3.kh, d3.kw, d3.stride, d3.pad, d3.Cin, d3.Cout, d3.nseg) == (1, 1, 1, 0, 64, 256, 1)
+            P_ = d3.Cin
+            if not ((d3.kh, d3.kw, d3.stride, d3.pad, d3.nseg) == (1, 1, 1, 0, 1) and P_ in (64, 128, 256) and d3.Cout == 4 * P_
                     and d3.res_mode == L.RES_ADD and not d3.res_after_act and d3.seg[0].n0 == 0 and d3.seg[0].act <= L.ACT_LEAKY01
                     and d3.w_h2 and d3.x_amax and M * max(d3.seg[0].row_stride, d3.res_ld) < (1 << 29)):
+                continue
+            if P_ > 64 and os.environ.get('YOLACT_AMD_CHAIN2', '1') != '1':       # A/B switch of csrc/chain2.hip (round 6)
                 continue
             pair = False
             if i < len(self.ops) and self.ops[i][0] is lib.ymi_conv2d_nhwc_f32 and self.ops[i][3] == w3 and i not in self.wide_ops:
                 d1 = self.ops[i][1].contents
-                pair = ((d1.kh, d1.kw, d1.stride, d1.pad, d1.Cin, d1.Cout, d1.nseg) == (1, 1, 1, 0, 256, 64, 1)
+                pair = ((d1.kh, d1.kw, d1.stride, d1.pad, d1.Cin, d1.Cout, d1.nseg) == (1, 1, 1, 0, 4 * P_, P_, 1)
                         and d1.res_mode == L.RES_NONE and d1.x == d3.seg[0].ptr and d1.ldx == d3.seg[0].row_stride
                         and d1.seg[0].n0 == 0 and d1.seg[0].act <= L.ACT_LEAKY01 and bool(d1.w_h2))
+            if P_ > 64 and not pair:          # csrc/chain2.hip without its second layer has nothing over the pipelined tiles
+                continue
             cd = L.ChainDesc()
             cd.x, cd.res, cd.y = d3.x, d3.res, d3.seg[0].ptr
             cd.w_a_h2, cd.scale_a_h2, cd.bias_a = d3.w_h2, d3.scale_h2, d3.bias
             cd.x_amax, cd.y_amax = d3.x_amax, d3.y_amax
             cd.M, cd.ldx, cd.res_ld, cd.ldy = M, d3.ldx, d3.res_ld, d3.seg[0].row_stride
-            cd.k_a, cd.n_a, cd.n_b, cd.cout_pad_a, cd.cout_pad_b = 64, 256, 64, 256, 128
+            cd.k_a, cd.n_a, cd.n_b, cd.cout_pad_a, cd.cout_pad_b = P_, 4 * P_, P_, _ceil(4 * P_, 128), _ceil(P_, 128)
             cd.act_a = d3.seg[0].act
+            if P_ > 64:                       # the rigorous bound of y (include/yolact_amd.h, ABI 8)
+                info = getattr(self, '_desc_info', {}).get(C.addressof(d3))
+                if info is None or info[1] is None:
+                    continue
+                cd.gain_a, cd.bias_max_a = info[0].l1_gain()
+                cd.res_amax = self._slot_ptr(info[1])
             name = n3
             if pair:
                 f1, p1, n1, w1 = self.ops[i]
@@ -1367,7 +1393,7 @@ class Plan:
                 if overlap(zs, span(cd.y, cd.ldy)) or overlap(zs, span(cd.res, cd.res_ld)) or (overlap(zs, xs) and not in_place):
                     continue
             cptr = C.pointer(cd)
-            key = ('chain' if pair else 'chain1') + str((d3.B, d3.Ho, d3.Wo)) + self.mode_key
+            key = ('chain' if pair else 'chain1') + str((d3.B, d3.Ho, d3.Wo) + ((P_,) if P_ > 64 else ())) + self.mode_key
             ent = disk.get(key)
             if ent is None:
                 self.tune_misses += 1
@@ -1429,6 +1455,29 @@ class Plan:
             if blocks < 400 and d.Cout % 4 == 0:
                 for S in (2, 3, 4, 5, 6, 8, 9, 12, 16):
                     per = -(-nk // S)                     # chunks per range (the last range may be shorter, never empty)
+                    if per >= 4 and per * (S - 1) < nk and 128 <= blocks * S <= 1100:
+                        out.append(tid + 256 * S)
+        return out
+
+    @staticmethod
+    def pc_candidates(d):
+        """(tile + 256 * split_k) candidates of the producer / consumer kernel (csrc/pcconv.hip) for a descriptor the pipelined kernel
+        takes (_pipe_ok) with more than 32 output channels: every block tile unsplit, and the chunk-aligned K splits that bring a
+        short grid to 0.5 .. 4 blocks per CU.  YOLACT_AMD_PC=0 removes them (A/B switch)."""
+        if os.environ.get('YOLACT_AMD_PC', '1') != '1' or d.Cout <= 32:
+            return []
+        M, nk = d.B * d.Ho * d.Wo, d.Kpad // 32
+        out = []
+        for t, name in sorted(L.PC_TILES.items()):
+            bm, bn = (int(v) for v in name[2:].split('x'))
+            if bn > 128 and d.Cout < 256:
+                continue
+            tid = t | L.TILE_H2 | L.TILE_DCNP
+            out.append(tid)
+            blocks = -(-M // bm) * -(-d.Cout // bn)
+            if blocks < 400 and d.Cout % 4 == 0:
+                for S in (2, 3, 4, 6, 8):
+                    per = -(-nk // S)
                     if per >= 4 and per * (S - 1) < nk and 128 <= blocks * S <= 1100:
                         out.append(tid + 256 * S)
         return out
@@ -1508,6 +1557,7 @@ class Plan:
                     cands = cands + self.dcnp_candidates(d, dcn=True)
                 if not is_dcn and h2_ and self.pipe and self._pipe_ok(d):   # the same pipelined kernel as an ordinary convolution
                     cands = cands + self.dcnp_candidates(d) + self.ws_candidates(d)     # (+ the streaming kernel for narrow outputs)
+                    cands = cands + self.pc_candidates(d)                               # (+ round 6: producer / consumer blocks)
                     if ((d.kh, d.kw, d.stride, d.pad, d.Cin, d.Cout) == (3, 3, 1, 1, 64, 64) and d.res_mode == L.RES_NONE
                             and patch_tile_allowed()):
                         cands = cands + [L.DCNP_PATCH_C64 | L.TILE_H2 | L.TILE_DCNP]    # csrc/patch.hip: the input patch in LDS, filters in registers
