@@ -162,7 +162,12 @@ enum { YMI_DCNP_64x128 = 1, YMI_DCNP_64x128_W8 = 2, YMI_DCNP_64x64 = 3, YMI_DCNP
         * reads + MFMAs only) and four producer waves (row requests, the fp32 -> fp16-plane split, the filter LDS-DMAs), so that a
         * request stalled on the vector-memory pipe no longer holds MFMAs back.  BM x BN = the block tile; results are bit-identical
         * to the pipelined tiles' (same products, same order per accumulator) */
-       YMI_DCNP_PC_128x128 = 29, YMI_DCNP_PC_256x128 = 30, YMI_DCNP_PC_128x256 = 31 };
+       YMI_DCNP_PC_128x128 = 29,
+       /* round 6, csrc/patch2.hip: 3x3 / stride 1 / pad 1, Cin % 32 == 0, Cout >= 64, no residual, up to three dense output segments
+        * with boundaries at multiples of 128 channels: the input patch of a TH x TW pixel tile (256 / 192 pixels; the shape is picked
+        * per map size) lives in LDS one 32-channel chunk at a time, only the filters stream per (chunk, tap) step — the nine taps of a
+        * 3x3 convolution read the same pixels, so the A operand crosses the global -> LDS path once instead of nine times */
+       YMI_DCNP_PATCH2_256 = 30, YMI_DCNP_PATCH2_192 = 31 };
 
 int ymi_abi_version(void);
 const char *ymi_strerror(int code);

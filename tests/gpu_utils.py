@@ -20,7 +20,8 @@ def nchw(x_nhwc):
 
 
 def run_conv(x, weight, bias=None, bn=None, stride=1, pad=0, act=L.ACT_NONE, res=None, res_mode=L.RES_NONE,
-             res_after_act=0, tile=L.TILE_AUTO, cin_pad=None, dcn_offmask=None, planes=True, split_k=0, om_layout=0):
+             res_after_act=0, tile=L.TILE_AUTO, cin_pad=None, dcn_offmask=None, planes=True, split_k=0, om_layout=0, seg_bounds=None,
+             seg_acts=None):
     """x: CPU NCHW tensor. Returns CPU NCHW output of the HIP conv.  `planes`: for bf16x3 tiles also hand the kernel the
     pre-split filter planes (ymi_conv_desc.w_x3); False = both operands are split on the fly."""
     pk = Packed(weight, bias, bn, stride, pad, cin_pad, DEV)
@@ -45,10 +46,18 @@ def run_conv(x, weight, bias=None, bn=None, stride=1, pad=0, act=L.ACT_NONE, res
         d.res, d.res_ld, d.res_H, d.res_W = rd.data_ptr(), rd.shape[3], rd.shape[1], rd.shape[2]
     d.nseg, d.tile = 1, tile
     d.seg[0] = L.ConvSeg(0, pk.Cout, act, pk.Cout, Ho * Wo * pk.Cout, y.data_ptr())
+    ysegs = None
+    if seg_bounds:            # dense output SEGMENTS [b_i, b_i+1) of the channels, each its own tensor / activation / bound slot
+        edges = [0] + list(seg_bounds) + [pk.Cout]
+        ysegs = [torch.full((B, Ho, Wo, edges[i + 1] - edges[i]), float('nan'), device=DEV) for i in range(len(edges) - 1)]
+        d.nseg = len(ysegs)
+        for i, ys in enumerate(ysegs):
+            w_ = edges[i + 1] - edges[i]
+            d.seg[i] = L.ConvSeg(edges[i], edges[i + 1], (seg_acts or [act] * 3)[i], w_, Ho * Wo * w_, ys.data_ptr())
     if (tile & L.TILE_X3) and planes and dcn_offmask is None:
         d.w_x3 = pk.w3().data_ptr()
-    amax = torch.zeros(2 * 1024, device=DEV)          # two magnitude-bound slots (16 sub-slots, 64 floats apart): [0] bound of x
-                                                      # (ymi_amax_f32), [1] what the launch reports for y
+    amax = torch.zeros(4 * 1024, device=DEV)          # magnitude-bound slots (16 sub-slots, 64 floats apart): [0] bound of x
+                                                      # (ymi_amax_f32), [1] what the launch reports for y ([1 .. 3]: per output segment)
     L.check(L.lib().ymi_amax_f32(xd.data_ptr(), xd.numel(), amax.data_ptr(), L.stream_ptr()), 'amax')
     d.x_amax, d.y_amax = amax.data_ptr(), amax.data_ptr() + 4096
     if tile & L.TILE_H2:
@@ -68,7 +77,9 @@ def run_conv(x, weight, bias=None, bn=None, stride=1, pad=0, act=L.ACT_NONE, res
     else:
         L.check(L.lib().ymi_conv2d_nhwc_f32(C.byref(d), s), 'conv')
     torch.cuda.synchronize()
-    run_conv.last_amax = amax.view(2, 1024).amax(1).cpu().tolist()
+    run_conv.last_amax = amax.view(4, 1024).amax(1).cpu().tolist()
+    if ysegs is not None:
+        return [nchw(t.cpu()) for t in ysegs]
     return nchw(y.cpu())
 
 

@@ -32,6 +32,8 @@ def test_conv_plain(shape, tile):
     if (tile & L.TILE_DCNP) and Cout % 4:
         pytest.skip('the pipelined kernel (csrc/dcn.hip) stores float4 rows: Cout % 4 == 0 (an explicit request is refused, see '
                     'test_dcn_pipelined_rejects_what_it_cannot_run)')
+    if (tile & L.TILE_DCNP) and (tile & 31) in L.PATCH2_TILES and (k, s, p, Cout >= 64) != (3, 1, 1, True):
+        pytest.skip('csrc/patch2.hip takes 3x3 / s1 / p1 with Cout >= 64 only (refused with YMI_EARG: test_patch2_kernel_output_segments)')
     if (tile & L.TILE_DCNP) and (tile & 31) == L.DCNP_PATCH_C64:
         pytest.skip('csrc/patch.hip takes exactly one shape (3x3 / s1 / p1, 64 -> 64): tests/test_gpu_round5.py::test_patch_kernel_matches_torch; '
                     'anything else is refused with YMI_EARG (asserted there)')
@@ -322,7 +324,7 @@ def test_pipelined_kernel_as_ordinary_convolution(case, tile):
     assert abs(run_conv.last_amax[1] - ref.abs().max().item()) <= 2e-5 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize('tile', [L.DCNP_64x128_W8, L.DCNP_128x128_W8_R1, L.DCNP_96x256_W12, L.DCNP_128x256_W16, L.DCNP_32x128, 14, 15, 16, 29, 30, 31])
+@pytest.mark.parametrize('tile', [L.DCNP_64x128_W8, L.DCNP_128x128_W8_R1, L.DCNP_96x256_W12, L.DCNP_128x256_W16, L.DCNP_32x128, 14, 15, 16, 29])
 @pytest.mark.parametrize('split', [2, 3, 4, 8])
 def test_pipelined_ordinary_convolution_split_k(tile, split):
     """K ranges on the PLAIN path (1x1, K = 512 -> 16 chunks; 3x3 with a residual): partial sums + the deterministic second pass."""
@@ -460,6 +462,62 @@ def test_pointwise_chain_matches_fp64(M, mode):
         assert torch.equal(y, y2) and torch.equal(z, z2)
     else:
         assert z is None
+
+
+PATCH2_ALL = [t | L.TILE_H2 | L.TILE_DCNP for t in sorted(L.PATCH2_TILES)]          # csrc/patch2.hip: 256- / 192-pixel tiles
+
+
+@pytest.mark.parametrize('tile', PATCH2_ALL)
+@pytest.mark.parametrize('case', [(2, 256, 69, 69, 256, L.ACT_RELU, None), (1, 128, 35, 35, 128, L.ACT_NONE, None), (8, 64, 18, 18, 72, L.ACT_LEAKY01, None),
+                                  (1, 32, 5, 7, 64, L.ACT_RELU, None), (1, 96, 138, 138, 260, L.ACT_RELU, None), (3, 64, 23, 40, 132, L.ACT_NONE, '5x31'),
+                                  (1, 64, 33, 30, 128, L.ACT_RELU, '23x8'), (2, 160, 17, 19, 384, L.ACT_RELU, '4x4')])
+def test_patch2_kernel_matches_torch(case, tile, monkeypatch):
+    """csrc/patch2.hip (3x3 / s1 / p1, the input patch of a pixel tile in LDS one 32-channel chunk at a time, filters streamed through a
+    ring, producer / consumer waves) against torch fp32: the maps of the headline plan and ragged ones, channel counts that are no
+    multiple of the block's 128, one chunk .. eight, every activation, host-picked and forced tile shapes (tiles wider than the map,
+    tiny tiles, tiles that do not fill the block's pixel slots); the magnitude bound; bit-reproducible."""
+    from gpu_utils import run_conv, rel_err
+    B, Cin, H, W, Cout, act, shape = case
+    if shape:
+        th, tw = (int(v) for v in shape.split('x'))
+        if th * tw > (192 if (tile & 31) == L.DCNP_PATCH2_192 else 256):
+            pytest.skip('forced tile shape larger than this block')
+        monkeypatch.setenv('YMI_PATCH2_TILE', shape)
+    else:
+        monkeypatch.delenv('YMI_PATCH2_TILE', raising=False)
+    g = _g(1200 + Cin + Cout + H)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    ref = F.conv2d(x, w, b, 1, 1)
+    ref = torch.relu(ref) if act == L.ACT_RELU else F.leaky_relu(ref, 0.1) if act == L.ACT_LEAKY01 else ref
+    y = run_conv(x, w, b, None, 1, 1, act=act, tile=tile)
+    assert rel_err(y, ref) < 2e-5
+    assert abs(run_conv.last_amax[1] - ref.abs().max().item()) <= 2e-5 * ref.abs().max().item()
+    assert torch.equal(y, run_conv(x, w, b, None, 1, 1, act=act, tile=tile))
+
+
+@pytest.mark.parametrize('tile', PATCH2_ALL)
+def test_patch2_kernel_output_segments(tile):
+    """Two and three dense output segments with boundaries at multiples of 128 channels (head0.upfeature + proto_net[0] in one launch:
+    256 | 256), each with its own tensor, activation and magnitude-bound slot; a boundary off the 128 grid is refused."""
+    from gpu_utils import run_conv, rel_err
+    g = _g(1300)
+    x = torch.randn(2, 64, 21, 26, generator=g)
+    w = torch.randn(448, 64, 3, 3, generator=g) / 24
+    b = torch.randn(448, generator=g) * 0.1
+    ref = F.conv2d(x, w, b, 1, 1)
+    ys = run_conv(x, w, b, None, 1, 1, tile=tile, seg_bounds=[256], seg_acts=[L.ACT_RELU, L.ACT_NONE, 0])
+    assert rel_err(ys[0], torch.relu(ref[:, :256])) < 2e-5 and rel_err(ys[1], ref[:, 256:]) < 2e-5
+    am = run_conv.last_amax
+    assert abs(am[1] - torch.relu(ref[:, :256]).max().item()) <= 2e-5 * am[1] and abs(am[2] - ref[:, 256:].abs().max().item()) <= 2e-5 * am[2]
+    ys = run_conv(x, w, b, None, 1, 1, tile=tile, seg_bounds=[128, 384], seg_acts=[L.ACT_NONE, L.ACT_RELU, L.ACT_LEAKY01])
+    assert rel_err(ys[0], ref[:, :128]) < 2e-5 and rel_err(ys[1], torch.relu(ref[:, 128:384])) < 2e-5
+    assert rel_err(ys[2], F.leaky_relu(ref[:, 384:], 0.1)) < 2e-5
+    with pytest.raises(RuntimeError):
+        run_conv(x, w, b, None, 1, 1, tile=tile, seg_bounds=[200])
+    with pytest.raises(RuntimeError):                                     # stride 2 / 1x1 / residual: not this kernel's
+        run_conv(x, w, b, None, 2, 1, tile=tile)
 
 
 @pytest.mark.parametrize('P', [128, 256])

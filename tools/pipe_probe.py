@@ -93,7 +93,7 @@ def main():
             ref.copy_(ref_src)
         d.seg[0].ptr = yref.data_ptr()
         times, devmax = {}, {}
-        for cand in plan.dcnp_candidates(d) + (plan.ws_candidates(d) if not args.no_ws else []) + plan.pc_candidates(d):
+        for cand in plan.dcnp_candidates(d) + (plan.ws_candidates(d) if not args.no_ws else []) + plan.pc_candidates(d) + plan.patch2_candidates(d):
             if args.tiles and tname(cand) not in args.tiles.split(','):
                 continue
             tile, S = cand & 255, cand >> 8

@@ -50,9 +50,12 @@ DCNP_WS_128x32_W4, DCNP_WS_512x64_W8 = 20, 27
 DCNP_PATCH_C64 = 28                 # csrc/patch.hip: 3x3 / s1 / p1, 64 -> 64, input patch in LDS, filters in registers
 PATCH_TILES = {28: 'patch8x16c64'}
 # csrc/pcconv.hip (round 6): producer / consumer blocks (4 consumer + 4 producer waves); ordinary convolutions
-PC_TILES = {29: 'pc128x128', 30: 'pc256x128', 31: 'pc128x256'}
-DCNP_PC_128x128, DCNP_PC_256x128, DCNP_PC_128x256 = 29, 30, 31
-for _t, _n in list(DCNP_TILES.items()) + list(WS_TILES.items()) + list(PATCH_TILES.items()) + list(PC_TILES.items()):
+PC_TILES = {29: 'pc128x128'}
+DCNP_PC_128x128 = 29
+# csrc/patch2.hip (round 6): 3x3 / s1 / p1, input patch of a 256- / 192-pixel tile in LDS, filters streamed, 128 output channels per block
+PATCH2_TILES = {30: 'patch2p256', 31: 'patch2p192'}
+DCNP_PATCH2_256, DCNP_PATCH2_192 = 30, 31
+for _t, _n in list(DCNP_TILES.items()) + list(WS_TILES.items()) + list(PATCH_TILES.items()) + list(PC_TILES.items()) + list(PATCH2_TILES.items()):
     TILE_NAMES[_t | TILE_H2 | TILE_DCNP] = _n
 WINO_PLANES = 1024                  # tune-table flag on a Winograd GEMM tile id: V written as fp16x2 planes (ymi_wino_desc.v_planes)
 KSPLIT_TILES = (6, 7, 8, 13, 14, 15, 6 | 32, 7 | 32, 8 | 32, 6 | 64, 7 | 64, 8 | 64, 13 | 64, 14 | 64, 15 | 64)   # different (still deterministic) fp32 summation order than the unsplit tiles

@@ -1458,6 +1458,7 @@ int ymi_internal_pipe_conv(const ymi_conv_desc *d, int base_tile, hipStream_t s)
 int ymi_internal_ws_conv(const ymi_conv_desc *d, int base_tile, hipStream_t s);   // csrc/wstat.hip: weight-stationary streaming kernel (Cout <= 64)
 int ymi_internal_patch_conv(const ymi_conv_desc *d, hipStream_t s);               // csrc/patch.hip: 3x3 64 -> 64 from an LDS-resident input patch
 int ymi_internal_pc_conv(const ymi_conv_desc *d, int base_tile, hipStream_t s);   // csrc/pcconv.hip: producer / consumer waves
+int ymi_internal_patch2_conv(const ymi_conv_desc *d, int base_tile, hipStream_t s);   // csrc/patch2.hip: 3x3, input patch in LDS, filters streamed
 
 // internal (csrc/dcn.hip): the second pass of a split-K launch for a dense [M, Cout] output (Cout % 4 == 0, 16-byte aligned rows)
 int ymi_internal_splitk_fixup(const float *part, long gstride, int S, long M, int Cout, int ldy, float *y, const float *scale,
@@ -1487,7 +1488,8 @@ int ymi_conv2d_nhwc_f32(const ymi_conv_desc *d, void *stream) {
     const int rc = validate(d, 0);
     if (rc) return rc;
     if ((d->tile & 31) == YMI_DCNP_PATCH_C64) return ymi_internal_patch_conv(d, (hipStream_t)stream);
-    if ((d->tile & 31) >= YMI_DCNP_PC_128x128) return ymi_internal_pc_conv(d, d->tile & 31, (hipStream_t)stream);
+    if ((d->tile & 31) >= YMI_DCNP_PATCH2_256) return ymi_internal_patch2_conv(d, d->tile & 31, (hipStream_t)stream);
+    if ((d->tile & 31) == YMI_DCNP_PC_128x128) return ymi_internal_pc_conv(d, d->tile & 31, (hipStream_t)stream);
     if ((d->tile & 31) >= YMI_DCNP_WS_128x32_W4) return ymi_internal_ws_conv(d, d->tile & 31, (hipStream_t)stream);
     return ymi_internal_pipe_conv(d, d->tile & 31, (hipStream_t)stream);
   }

@@ -10,7 +10,7 @@
 // their serialisation is.
 //
 // Here the two streams live in different waves.  A block is 8 waves: waves 0 .. 3 — one per SIMD — are CONSUMERS (ds_read_b128
-// fragments + v_mfma_f32_32x32x16_f16 only, a 64 x 64 .. 128 x 64 tile each); waves 4 .. 7 — again one per SIMD — are PRODUCERS:
+// fragments + v_mfma_f32_32x32x16_f16 only, a 64 x 64 tile each; 256 x 128 / 128 x 256 blocks were measured in session r6c and dropped); waves 4 .. 7 — again one per SIMD — are PRODUCERS:
 // they request the fp32 rows of chunk c + 3 into a two-slot register ring, split the rows of chunk c + 1 into the two fp16 planes of
 // the fp16x2 arithmetic (tensor scale from x_amax, exactly as pipe_h2_k) and ds_write them, and issue the LDS-DMAs of the filter planes
 // of chunk c + 2.  A producer that stalls on the memory pipe no longer holds any MFMA back, and the consumers' stream carries half an
@@ -481,8 +481,6 @@ int ymi_internal_pc_conv(const ymi_conv_desc *d, int base_tile, hipStream_t s) {
   const int pr = ymi_internal_prof_begin(flops, base_tile | YMI_TILE_H2 | YMI_TILE_DCNP, 14, s);
   switch (base_tile) {                                   // <consumer waves along M, along N, 32x32 tiles per consumer along M, along N>
     case YMI_DCNP_PC_128x128: rc = (p.flags & 8) ? launch_pc<2, 2, 2, 2, 2>(p, s) : (p.flags & 16) ? launch_pc<2, 2, 2, 2, 3>(p, s) : launch_pc<2, 2, 2, 2, 4>(p, s); break;
-    case YMI_DCNP_PC_256x128: rc = (p.flags & 8) ? launch_pc<2, 2, 4, 2, 2>(p, s) : launch_pc<2, 2, 4, 2, 4>(p, s); break;
-    case YMI_DCNP_PC_128x256: rc = launch_pc<2, 2, 2, 4, 2>(p, s); break;
     default: rc = YMI_EARG; break;
   }
   if (rc == YMI_OK && S > 1)

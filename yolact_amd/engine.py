@@ -1460,11 +1460,33 @@ class Plan:
         return out
 
     @staticmethod
+    def patch2_candidates(d):
+        """Tile ids of csrc/patch2.hip (3x3 / stride 1 / pad 1 with the input patch of a pixel tile in LDS, filters streamed) for a
+        descriptor it takes: Cin % 32 == 0, Cout >= 64 and % 4 == 0, no residual, 1 .. 3 dense segments with boundaries at multiples of 128
+        channels, activation none / ReLU / LeakyReLU.  YOLACT_AMD_PATCH2=0 removes them (A/B switch)."""
+        if os.environ.get('YOLACT_AMD_PATCH2', '1') != '1':
+            return []
+        if not ((d.kh, d.kw, d.stride, d.pad) == (3, 3, 1, 1) and d.Cin % 32 == 0 and d.Kpad == 9 * d.Cin and d.Cout >= 64 and d.Cout % 4 == 0
+                and d.res_mode == L.RES_NONE and 1 <= d.nseg <= 3 and d.w_h2):
+            return []
+        cov = 0
+        for i in range(d.nseg):
+            g = d.seg[i]
+            if (g.n0 != cov or g.n0 % 128 or g.act > L.ACT_LEAKY01 or g.act < 0 or g.row_stride % 4 or g.row_stride < g.n1 - g.n0
+                    or g.batch_stride != d.Ho * d.Wo * g.row_stride):
+                return []
+            cov = g.n1
+        if cov < d.Cout:
+            return []
+        return [t | L.TILE_H2 | L.TILE_DCNP for t in sorted(L.PATCH2_TILES)]
+
+    @staticmethod
     def pc_candidates(d):
         """(tile + 256 * split_k) candidates of the producer / consumer kernel (csrc/pcconv.hip) for a descriptor the pipelined kernel
-        takes (_pipe_ok) with more than 32 output channels: every block tile unsplit, and the chunk-aligned K splits that bring a
-        short grid to 0.5 .. 4 blocks per CU.  YOLACT_AMD_PC=0 removes them (A/B switch)."""
-        if os.environ.get('YOLACT_AMD_PC', '1') != '1' or d.Cout <= 32:
+        takes (_pipe_ok) with more than 32 output channels: the block tile unsplit, and the chunk-aligned K splits that bring a
+        short grid to 0.5 .. 4 blocks per CU.  OPT-IN (YOLACT_AMD_PC=1): measured in sessions r6b / r6c, never in front of the pipelined
+        tiles (profiles/r06_pc_probe.txt) — both are bound by the same global -> LDS rates, not by how the waves share the work."""
+        if os.environ.get('YOLACT_AMD_PC', '0') != '1' or d.Cout <= 32:
             return []
         M, nk = d.B * d.Ho * d.Wo, d.Kpad // 32
         out = []
@@ -1557,7 +1579,9 @@ class Plan:
                     cands = cands + self.dcnp_candidates(d, dcn=True)
                 if not is_dcn and h2_ and self.pipe and self._pipe_ok(d):   # the same pipelined kernel as an ordinary convolution
                     cands = cands + self.dcnp_candidates(d) + self.ws_candidates(d)     # (+ the streaming kernel for narrow outputs)
-                    cands = cands + self.pc_candidates(d)                               # (+ round 6: producer / consumer blocks)
+                    cands = cands + self.pc_candidates(d)                               # (+ round 6: producer / consumer blocks, opt-in)
+                if not is_dcn and h2_ and self.pipe:
+                    cands = cands + self.patch2_candidates(d)                           # (+ round 6: 3x3 with the input patch in LDS)
                     if ((d.kh, d.kw, d.stride, d.pad, d.Cin, d.Cout) == (3, 3, 1, 1, 64, 64) and d.res_mode == L.RES_NONE
                             and patch_tile_allowed()):
                         cands = cands + [L.DCNP_PATCH_C64 | L.TILE_H2 | L.TILE_DCNP]    # csrc/patch.hip: the input patch in LDS, filters in registers
