@@ -728,6 +728,45 @@ def secondary_lines(net, x, size, steps=10, config=CONFIG):
     return out
 
 
+def outlier_plan_line(dev, x, size, config, k_exp=16, steps=10):
+    """VERDICT r5 #3 / #5b: what the step costs when a checkpoint TRIPS the outlier-channel guard.  The same network re-parametrised
+    exactly (utils.synth.plant_outlier_channels: channels of C3 .. C5 and of proto_net[0] scaled by 2^16, their consumers' filters by
+    2^-16 — what BN-folded checkpoints with outlier channels look like): engine.Packed.tiny_columns moves the consuming layers to the
+    bf16x3 tiles, without Winograd and without the fp16x2-only fusions.  Tiles of shapes the shipped table does not hold for that
+    arithmetic are measured in this process (tune_misses says how many)."""
+    import warnings
+    from yolact_amd.utils.synth import plant_outlier_channels, synth_state_dict
+    from yolact_amd.yolact import Yolact
+    import yolact_amd
+    yolact_amd.set_cfg(config)
+    net_o = Yolact()
+    sd0 = synth_state_dict([(k, tuple(v.shape)) for k, v in net_o.state_dict().items()], seed=0, conf_gain=0.04)
+    sd, planted = plant_outlier_channels({k: v.cpu() for k, v in sd0.items()}, k_exp)
+    net_o.load_state_dict_compat(sd)
+    net_o.detect.use_fast_nms = True
+    net_o = net_o.to(dev)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        plan = net_o.plan_for(x)
+
+    def step():
+        net_o.forward_device(x)['count'].tolist()
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    wide = sorted(plan.ops[i][2] for i in plan.wide_ops)
+    return {'value': round(x.shape[0] / dt, 2), 'unit': 'images/s', 'ms_per_step': round(dt * 1e3, 3),
+            'layers_on_bf16x3': len(wide), 'first_layers': wide[:6], 'tune_misses': plan.tune_misses,
+            'what': 'configs[1] step with the 2^%d outlier checkpoint (exact re-parametrisation of the timed network: %s): the '
+                    'outlier-channel guard demotes %d layers to bf16x3 tiles (no Winograd, no fp16x2-only fusions there)'
+                    % (k_exp, ', '.join(n for n, _ in planted), len(wide))}
+
+
 def relaunch_under_torchrun(args):
     """`python bench.py --gpus N` outside a launcher: start the N ranks ourselves (one process per GPU, RCCL rendezvous on
     127.0.0.1) and exit with their status."""
@@ -762,6 +801,11 @@ def main():
     ap.add_argument('--prealloc-gb', type=int, default=0, help='experiment: reserve ONE allocation of this size in torch\'s caching '
                     'allocator before anything else is allocated, so that weights / activations / workspaces are carved from one mapping')
     ap.add_argument('--layers', action='store_true', help='also print the per-layer conv table to stderr')
+    ap.add_argument('--global-batch', type=int, default=0, help='strong scaling: a FIXED global batch split over the ranks '
+                    '(parallel.shard_range; eval.py:630-634 splits one batch the same way).  Default: --batch, i.e. BASELINE '
+                    'configs[1] at 8 GPUs = one image per GPU.  The weak-scaling region (--batch images per GPU) stays the headline value; '
+                    'this second timed region is reported as `strong_scaling`')
+    ap.add_argument('--no-strong', action='store_true', help='skip the strong-scaling region')
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit('--gpus must be >= 1')
@@ -906,6 +950,65 @@ def main():
             torch.cuda.synchronize()
             gather_us = round((time.perf_counter() - tg) / 50 * 1e6, 1)
 
+        # ---- strong scaling: a FIXED global batch G split over the ranks, the reference's own multi-GPU form
+        # (eval.py:630-634,661).  Rank r computes images shard_range(G, r, world) — an empty share enters the same gather — through
+        # parallel.sharded_forward's per-rank-shard form; same barrier / synchronize / MAX-over-ranks timing as the weak region.
+        strong = None
+        if not args.no_strong:
+            G = args.global_batch or args.batch
+            lo_s, hi_s = parallel.shard_range(G, rank, world)
+            xs = synth_images(max(hi_s - lo_s, 1), size, size, seed=4321 + rank).to(dev)[:hi_s - lo_s]
+            sg = parallel.RecordGatherer(0)
+            pinned = [torch.empty(G, dtype=torch.float32, pin_memory=True) for _ in range(2)]
+            st = {'i': 0, 'n': 0}
+
+            def s_launch():
+                # (world 1: the RCCL gather is forced like in the weak region, so both regions pay the same collective)
+                rec, _ = parallel.sharded_forward(net.forward_device, xs, net.mask_dim, sg, 0, n_global=G) if world > 1 else (
+                    sg(parallel.pack_records(net.forward_device(xs)), G, force_collective=have_pg), None)
+                if rec is None:
+                    return None
+                buf = pinned[st['i'] & 1]
+                st['i'] += 1
+                buf[:rec.shape[0]].copy_(rec[:, 0], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                return (buf, ev, int(rec.shape[0]))
+
+            def s_collect(h):
+                if h is not None:
+                    h[1].synchronize()
+                    st['n'] = len(h[0][:h[2]].tolist())
+
+            def s_run(k):
+                prev = None
+                for _ in range(k):
+                    cur = s_launch()
+                    s_collect(prev)
+                    prev = cur
+                s_collect(prev)
+            s_run(args.warmup)
+            if have_pg:
+                dist.barrier()
+            torch.cuda.synchronize()
+            ts0 = time.perf_counter()
+            s_run(args.steps)
+            if have_pg:
+                dist.barrier()
+            torch.cuda.synchronize()
+            dts = time.perf_counter() - ts0
+            if have_pg:
+                tt = torch.tensor([dts], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dts = float(tt.item())
+            if rank == 0:
+                if st['n'] != G:
+                    raise SystemExit('bench.py: strong-scaling region gathered %d records, expected %d' % (st['n'], G))
+                strong = {'global_batch': G, 'images_per_rank': [parallel.shard_range(G, r, world)[1] - parallel.shard_range(G, r, world)[0] for r in range(world)],
+                          'value': round(G * args.steps / dts, 2), 'unit': 'images/s', 'ms_per_step': round(dts / args.steps * 1e3, 3),
+                          'what': 'FIXED global batch of %d images split over %d rank(s) (eval.py:630-634), one gather of the records; the '
+                                  'driver divides the N-GPU value by the 1-GPU value of the SAME key for strong-scaling efficiency' % (G, world)}
+
         result = None
         if rank == 0:
             if got['n'] != args.batch * world:
@@ -942,6 +1045,9 @@ def main():
                 'gather_us': gather_us,                         # the record gather alone, host-paired, 50 back-to-back calls
                 'record_bytes_per_image': 4 * int(parallel.pack_records(net.forward_device(x)).shape[1]),
                 'roofline': rf,
+                # both scaling modes in one line: `value` / `scaling` above = weak (--batch images per GPU);
+                # strong_scaling = a fixed global batch split over the ranks
+                'strong_scaling': strong,
             }
             if rf['engine']['h2_share_of_time'] > 0:
                 result['dtype'] = ('f32 (fp32 in / fp32 accumulate / fp32 out; %.0f %% of the GEMM time on fp16x2 tiles = every fp32 '
@@ -971,6 +1077,8 @@ def main():
                           file=sys.stderr)
             if world == 1 and not args.no_secondary:
                 result['secondary'] = secondary_lines(net, x, size, config=args.config)
+                if is_headline:
+                    result['secondary']['outlier_plan'] = outlier_plan_line(dev, x, size, args.config)
         if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == CONFIG:
             result['cpu_baseline'] = cpu_baseline(sd, size, args.batch)
     if have_pg:

@@ -133,52 +133,7 @@ def test_forced_f4x4_plan_matches_oracle_at_batch8():
                 os.environ[k] = v
 
 
-def _plant_outlier_channels(sd, k_exp, nch=4):
-    """Equivalent re-parametrisation of the network with OUTLIER CHANNELS (what real BN-folded checkpoints have): in
-    stages C3 .. C5 `nch` channels of the stage tensor are scaled by 2^k (every block's bn3 and the projection shortcut's BN), and
-    every consumer of that tensor (the conv1 of the following blocks, the next stage's first conv1 / projection shortcut, the FPN
-    lateral) divides its weights for those input channels by 2^k; likewise four output channels of proto_net.0 against proto_net.2.  Powers of two commute with fp32 rounding (no overflow here), so in exact
-    fp32 arithmetic every product — hence every head tensor — is unchanged; what changes is the dynamic range INSIDE the activation
-    tensors (2^k between channels of one tensor: the fp16x2 tiles use ONE power-of-two scale per tensor) and inside the filter rows
-    (2^-k between columns of one row: one scale per row)."""
-    sd = {k: v.clone() for k, v in sd.items()}
-    f = float(2 ** k_exp)
-    planted = []
-
-    def scale_out(bn, ch):
-        sd[bn + '.weight'][ch] *= f
-        sd[bn + '.bias'][ch] *= f
-
-    def scale_in(conv_w, ch):
-        sd[conv_w][:, ch] /= f
-    nblocks = {}
-    for key in sd:
-        if key.startswith('backbone.layers.') and key.endswith('.bn3.weight'):
-            _, _, li, bi = key.split('.')[:4]
-            nblocks[int(li)] = max(nblocks.get(int(li), 0), int(bi) + 1)
-    nstage = len(nblocks)
-    for li in range(1, nstage):                       # C3, C4, C5 (stage outputs the FPN consumes; backbone.py:126-139, yolact.py:310-341)
-        n = nblocks[li]
-        C = sd['backbone.layers.%d.%d.bn3.weight' % (li, n - 1)].shape[0]
-        ch = torch.arange(nch) * (C // nch) + 3
-        # the stage tensor runs through identity shortcuts (y = relu(bn3(conv3) + x), backbone.py:50-55): the channel must be
-        # scaled in EVERY block's bn3 and in the projection shortcut's BN, and every conv1 that reads the stage tensor divides
-        for bi in range(n):
-            scale_out('backbone.layers.%d.%d.bn3' % (li, bi), ch)
-            if bi > 0:
-                scale_in('backbone.layers.%d.%d.conv1.weight' % (li, bi), ch)
-        scale_out('backbone.layers.%d.0.downsample.1' % li, ch)
-        if li + 1 < nstage:
-            scale_in('backbone.layers.%d.0.conv1.weight' % (li + 1), ch)
-            scale_in('backbone.layers.%d.0.downsample.0.weight' % (li + 1), ch)
-        scale_in('fpn.lat_layers.%d.weight' % (nstage - 1 - li), ch)     # lat_layers are stored top-down (yolact.py:286-289)
-        planted.append(('C%d' % (li + 2), ch.tolist()))
-    ch = torch.tensor([5, 70, 131, 200])
-    sd['proto_net.0.weight'][ch] *= f
-    sd['proto_net.0.bias'][ch] *= f
-    sd['proto_net.2.weight'][:, ch] /= f
-    planted.append(('proto_net.0', ch.tolist()))
-    return sd, planted
+from yolact_amd.utils.synth import plant_outlier_channels as _plant_outlier_channels  # noqa: E402  (shared with bench.py's outlier_plan line)
 
 
 @pytest.mark.parametrize('k_exp', [12, 16, 20])

@@ -341,6 +341,26 @@ def _gloo8_worker(rank, world, port, q):
     lo, hi = parallel.shard_range(B, rank, world)
     assert (hi - lo) == [2, 2, 2, 2, 2, 2, 1, 0][rank]
     assert calls == ([(lo, hi - lo)] * 3 if hi > lo else [])
+    # round 6: the PER-RANK SHARD form (n_global): a rank holds only its own images (rank 7: none) — same records on the root, same
+    # persistent buffer; a shard of the wrong length is refused before any collective is entered
+    rec2, mine2 = parallel.sharded_forward(net.forward_device, x[lo:hi].contiguous(), D, gat, n_global=B)
+    if rank == 0:
+        assert rec2.data_ptr() == ptr and torch.equal(rec2, rec)
+    else:
+        assert rec2 is None
+    assert (mine2 is None) == (hi == lo)
+    try:
+        parallel.sharded_forward(net.forward_device, x[:hi - lo + 1].contiguous(), D, gat, n_global=B)
+        raise SystemExit('a shard of the wrong length was accepted')
+    except ValueError as e:
+        assert 'owns images' in str(e)
+    # strong scaling as BASELINE configs[1] runs on 8 GPUs: a FIXED global batch of 8 -> one image per rank, 8 records on the root
+    x8 = torch.arange(8, dtype=torch.float32).view(8, 1, 1, 1).expand(8, 3, 4, 4).contiguous()
+    lo8, hi8 = parallel.shard_range(8, rank, world)
+    assert hi8 - lo8 == 1
+    rec8, _ = parallel.sharded_forward(net.forward_device, x8[lo8:hi8].contiguous(), D, parallel.RecordGatherer(0), n_global=8)
+    if rank == 0:
+        assert rec8.shape == (8, L_) and torch.equal(rec8[:, 0], full['count'][:8].to(torch.float32))
     if rank == 0:
         dets = parallel.unpack_records(rec, D)
         ok = len(dets) == B

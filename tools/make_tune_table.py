@@ -24,6 +24,7 @@ PLANS = [
     ('configs1_r50_b8', 'yolact_resnet50_config', 8, 550),
     ('r50_b1', 'yolact_resnet50_config', 1, 550),
     ('r50_b2', 'yolact_resnet50_config', 2, 550),
+    ('r50_b4', 'yolact_resnet50_config', 4, 550),          # round 6: the per-rank batch of the strong-scaling region at 2 GPUs (bench.py --global-batch 8)
     ('configs2_r101_b16', 'yolact_base_config', 16, 550),
     ('r101_b1', 'yolact_base_config', 1, 550),
     ('configs4_im700_b8', 'yolact_im700_config', 8, 700),

@@ -111,8 +111,13 @@ def pin_rank_affinity(local_rank: int, local_world: int):
 
 
 def sharded_forward(forward_device, x_global: torch.Tensor, D: int, gatherer: Optional[RecordGatherer] = None, dst: int = 0,
-                    masks_fn=None, mask_gatherer: Optional[RecordGatherer] = None):
-    """Data-parallel forward of one GLOBAL batch (every rank holds the same x_global, or at least its own shard of it):
+                    masks_fn=None, mask_gatherer: Optional[RecordGatherer] = None, n_global: Optional[int] = None):
+    """Data-parallel forward of one GLOBAL batch.  Two calling forms:
+      * n_global None (default): every rank passes the same `x_global` [B, ...] and slices its own share out of it;
+      * n_global = B (round 6): every rank passes ONLY ITS SHARD — images shard_range(B, rank, world) of the global batch, possibly
+        zero of them — so that no rank ever holds the other ranks' images (BASELINE configs[4]: 64 x 700 x 700 images are 376 MB;
+        eval.py:630-634 scatters frames the same way).  The shard's length is checked against shard_range.
+    In both forms
     rank r runs `forward_device` (Yolact.forward_device: forward + Detect, no host sync) on images shard_range(B, r, world)
     and the fixed-size detection records of all images are gathered on `dst` with the ONE collective of the path.  Returns
     (records [B, L] on dst | None elsewhere, this rank's device outputs or None for an empty shard).  The prototypes stay on
@@ -124,8 +129,15 @@ def sharded_forward(forward_device, x_global: torch.Tensor, D: int, gatherer: Op
     returns a third value: the gathered bits [B, cap, W64] on dst, None elsewhere."""
     world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
     rank = dist.get_rank() if world > 1 else 0
-    B = int(x_global.shape[0])
+    B = int(x_global.shape[0]) if n_global is None else int(n_global)
     lo, hi = shard_range(B, rank, world)
+    if n_global is None:
+        x_mine = x_global[lo:hi]
+    else:
+        if int(x_global.shape[0]) != hi - lo:
+            raise ValueError('sharded_forward(n_global=%d): rank %d of %d owns images [%d, %d) = %d, got a shard of %d'
+                             % (B, rank, world, lo, hi, hi - lo, int(x_global.shape[0])))
+        x_mine = x_global
     rows = (B + world - 1) // world
     g = gatherer or RecordGatherer(dst)
     out, allrec, hooked = None, None, False
@@ -133,11 +145,11 @@ def sharded_forward(forward_device, x_global: torch.Tensor, D: int, gatherer: Op
         if _accepts_after_detect(forward_device):
             # the gather is enqueued from INSIDE the forward, right behind Detect on the stream Detect runs on (Yolact.forward_device):
             # the records do not depend on the prototypes, so the collective overlaps the protonet instead of queueing behind it
-            out = forward_device(x_global[lo:hi].contiguous(),
+            out = forward_device(x_mine.contiguous(),
                                  after_detect=lambda o: g(pack_records(o), rows, n_items=B, force_collective=world > 1))
             allrec, hooked = out.pop('after_detect'), True
         else:
-            out = forward_device(x_global[lo:hi].contiguous())
+            out = forward_device(x_mine.contiguous())
     if not hooked:
         if out is not None:
             rec = pack_records(out)

@@ -354,7 +354,7 @@ class Yolact(nn.Module):
         with torch.cuda.device(x.device):
             return self._forward_device_one(x, after_detect=after_detect)
 
-    def forward_sharded(self, x_global, dst=0, masks=None, mask_size=None):
+    def forward_sharded(self, x_global, dst=0, masks=None, mask_size=None, n_global=None):
         """Data-parallel inference of one global batch across the ranks of torch.distributed (one process per GPU, RCCL): this
         rank computes its contiguous share of the images (parallel.shard_range), then ONE gather of the fixed-size detection
         records brings every image's detections to `dst` (eval.py:630-634,661 is batch splitting with a no-op gather; there is
@@ -363,6 +363,9 @@ class Yolact(nn.Module):
         computed itself and None for detections gathered from other ranks (assemble those masks on their own rank: every
         rank can run postprocess_batch on its forward_device output) — and None on the other ranks.  The returned tensors
         are fresh copies: they stay valid across later calls.
+
+        n_global (round 6): when given, `x_global` is THIS RANK'S SHARD only — images parallel.shard_range(n_global, rank, world) of a
+        global batch of n_global images (an empty [0, 3, H, W] tensor on a rank that owns none) — instead of the whole batch.
 
         masks='bits' (round 5; eval.py:630-634,791 moves the frame to the device that holds a detection's prototypes — here the
         MASKS move instead): every rank assembles the final binary masks of its own images at `mask_size` = (h, w) (default: the
@@ -389,15 +392,15 @@ class Yolact(nn.Module):
                     return torch.zeros(0, cap, (hh * ww + 63) // 64, dtype=torch.int64, device=x_global.device)
                 return postprocess_bits_batch(out, ww, hh)['bits']
             rec, mine, bits = parallel.sharded_forward(self.forward_device, x_global, self.mask_dim, self._gatherer, dst,
-                                                       masks_fn=masks_fn, mask_gatherer=self._mask_gatherer)
+                                                       masks_fn=masks_fn, mask_gatherer=self._mask_gatherer, n_global=n_global)
         else:
-            rec, mine = parallel.sharded_forward(self.forward_device, x_global, self.mask_dim, self._gatherer, dst)
+            rec, mine = parallel.sharded_forward(self.forward_device, x_global, self.mask_dim, self._gatherer, dst, n_global=n_global)
         if rec is None:
             return None
         import torch.distributed as dist
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         rank = dist.get_rank() if world > 1 else 0
-        lo, hi = parallel.shard_range(int(x_global.shape[0]), rank, world)
+        lo, hi = parallel.shard_range(int(x_global.shape[0]) if n_global is None else int(n_global), rank, world)
         return parallel.assemble_sharded(rec, mine, lo, hi, self.mask_dim, self, bits=bits,
                                          mask_size=(hh, ww) if masks == 'bits' else None)
 
