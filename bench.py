@@ -728,7 +728,7 @@ def secondary_lines(net, x, size, steps=10, config=CONFIG):
     return out
 
 
-def outlier_plan_line(dev, x, size, config, k_exp=16, steps=10):
+def outlier_plan_line(dev, x, size, config, k_exp=16, steps=10, rebalance=True):
     """VERDICT r5 #3 / #5b: what the step costs when a checkpoint TRIPS the outlier-channel guard.  The same network re-parametrised
     exactly (utils.synth.plant_outlier_channels: channels of C3 .. C5 and of proto_net[0] scaled by 2^16, their consumers' filters by
     2^-16 — what BN-folded checkpoints with outlier channels look like): engine.Packed.tiny_columns moves the consuming layers to the
@@ -745,9 +745,17 @@ def outlier_plan_line(dev, x, size, config, k_exp=16, steps=10):
     net_o.load_state_dict_compat(sd)
     net_o.detect.use_fast_nms = True
     net_o = net_o.to(dev)
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        plan = net_o.plan_for(x)
+    old_rb = os.environ.get('YOLACT_AMD_REBALANCE')
+    os.environ['YOLACT_AMD_REBALANCE'] = '1' if rebalance else '0'
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            plan = net_o.plan_for(x)
+    finally:
+        if old_rb is None:
+            os.environ.pop('YOLACT_AMD_REBALANCE', None)
+        else:
+            os.environ['YOLACT_AMD_REBALANCE'] = old_rb
 
     def step():
         net_o.forward_device(x)['count'].tolist()
@@ -755,16 +763,25 @@ def outlier_plan_line(dev, x, size, config, k_exp=16, steps=10):
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    per = []
     for _ in range(steps):
+        t1 = time.perf_counter()
         step()
+        per.append(round((time.perf_counter() - t1) * 1e3, 3))
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    if os.environ.get('BENCH_DEBUG'):
+        print('outlier_plan_line rebalance=%s per-step ms %s' % (rebalance, per), file=sys.stderr)
     wide = sorted(plan.ops[i][2] for i in plan.wide_ops)
     return {'value': round(x.shape[0] / dt, 2), 'unit': 'images/s', 'ms_per_step': round(dt * 1e3, 3),
             'layers_on_bf16x3': len(wide), 'first_layers': wide[:6], 'tune_misses': plan.tune_misses,
-            'what': 'configs[1] step with the 2^%d outlier checkpoint (exact re-parametrisation of the timed network: %s): the '
-                    'outlier-channel guard demotes %d layers to bf16x3 tiles (no Winograd, no fp16x2-only fusions there)'
-                    % (k_exp, ', '.join(n for n, _ in planted), len(wide))}
+            'rebalanced': [list(r) for r in getattr(plan, 'rebalanced', [])],
+            'what': 'configs[1] step with the 2^%d outlier checkpoint (exact re-parametrisation of the timed network: %s): %s'
+                    % (k_exp, ', '.join(n for n, _ in planted),
+                       'compensated outlier channels rebalanced at pack time (Plan._rebalance_outliers: [tensor, channels, max exponent]), '
+                       'every layer stays on its fp16x2 tile' if rebalance else
+                       'YOLACT_AMD_REBALANCE=0: the outlier-channel guard demotes %d layers to bf16x3 tiles (no Winograd, no fp16x2-only '
+                       'fusions there)' % len(wide))}
 
 
 def relaunch_under_torchrun(args):
@@ -1079,6 +1096,7 @@ def main():
                 result['secondary'] = secondary_lines(net, x, size, config=args.config)
                 if is_headline:
                     result['secondary']['outlier_plan'] = outlier_plan_line(dev, x, size, args.config)
+                    result['secondary']['outlier_plan_guard_only'] = outlier_plan_line(dev, x, size, args.config, rebalance=False)
         if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == CONFIG:
             result['cpu_baseline'] = cpu_baseline(sd, size, args.batch)
     if have_pg:

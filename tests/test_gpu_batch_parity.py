@@ -137,7 +137,27 @@ from yolact_amd.utils.synth import plant_outlier_channels as _plant_outlier_chan
 
 
 @pytest.mark.parametrize('k_exp', [12, 16, 20])
-def test_outlier_channels_end_to_end_at_batch8(k_exp):
+def test_outlier_channels_are_rebalanced_end_to_end_at_batch8(k_exp):
+    """Round 6, the default path for such checkpoints: Plan._rebalance_outliers undoes the compensated re-parametrisation at pack time
+    (producers' folded BN scales x 2^-k, consumers' filters x 2^k: exact), so NOTHING leaves the fp16x2 tiles — same launches, same
+    Winograd / fusion decisions, zero tune misses, the timed plan's speed — and the heads meet the same bars as the clean network."""
+    tag, config, B, size, seed, gain, img_seed = CASES[0]
+    net, sd0 = _build(config, seed, gain)
+    sd, planted = _plant_outlier_channels({k: v.cpu() for k, v in sd0.items()}, k_exp)
+    net.load_state_dict_compat(sd)
+    net._synth_key = (config, seed, gain, 'outliers-rebalanced', k_exp)
+    plan, _, _ = _compare(net, sd, config, B, size, img_seed, 'outlier channels 2^%d %s, rebalanced' % (k_exp, planted))
+    assert not plan.wide_ops and plan.tune_misses == 0
+    assert [r[0] for r in plan.rebalanced] == ['C3', 'C4', 'C5', 'proto_net.0'] and all(k_exp - 2 <= r[2] <= k_exp for r in plan.rebalanced)
+    x = synth_images(B, size, size, seed=img_seed).to(DEV)
+    net.forward_raw(x)
+    bounds = sorted(plan.bound(sl) for sl in range(plan._nslots))
+    print('magnitude bounds of the rebalanced plan\'s tensors: median %.3g, max %.3g' % (bounds[len(bounds) // 2], bounds[-1]))
+    assert bounds[-1] < 2 ** 10 * bounds[len(bounds) // 2]         # no tensor carries the planted range any more
+
+
+@pytest.mark.parametrize('k_exp', [12, 16, 20])
+def test_outlier_channels_end_to_end_at_batch8(k_exp, monkeypatch):
     """fp16x2 carries one power-of-two scale per activation TENSOR (h stays a normal fp16 27 binades below the bound,
     l 15) and one per FILTER ROW; a single-layer test covered 2^14 outliers, nothing did end to end.  Here the R50 network is
     re-parametrised (exactly, see _plant_outlier_channels) so that C3 / C4 / C5 and a protonet tensor carry channels 2^12 .. 2^20 times
@@ -146,6 +166,7 @@ def test_outlier_channels_end_to_end_at_batch8(k_exp):
     errors 9e-6 at 2^12, 3.4e-5 at 2^14, 1.27e-4 at 2^16 — the low fp16 piece of a typical value goes subnormal 15 binades below the
     tensor's bound.  The engine therefore recognises such layers from their FILTERS (input channels weighted >= 2^10 less than the
     typical one: engine.Packed.tiny_columns) and runs them on the bf16x3 tiles, which have no scale."""
+    monkeypatch.setenv('YOLACT_AMD_REBALANCE', '0')      # the guard's path (the default rebalances: test above)
     tag, config, B, size, seed, gain, img_seed = CASES[0]
     net, sd0 = _build(config, seed, gain)
     sd, planted = _plant_outlier_channels({k: v.cpu() for k, v in sd0.items()}, k_exp)

@@ -623,13 +623,14 @@ def test_outlier_guard_needs_an_amplifying_producer_not_just_tiny_columns():
     that its PRODUCER amplifies — the BN-folded outlier signature the stress test plants — and no longer on tiny columns alone, which
     is also what dead (weight-decayed) input channels of real checkpoints look like.  CPU plans, no launches."""
     import warnings
-    from test_gpu_batch_parity import _plant_outlier_channels
     from yolact_amd.engine import Plan
-    from yolact_amd.utils.synth import synth_state_dict
+    from yolact_amd.utils.synth import plant_outlier_channels as _plant_outlier_channels, synth_state_dict
     net = _make_net('yolact_resnet50_config')
     sd = synth_state_dict([(k, tuple(v.shape)) for k, v in net.state_dict().items()], seed=0, conf_gain=0.04)
     old = os.environ.get('YOLACT_AMD_SPLIT')
+    old_rb = os.environ.get('YOLACT_AMD_REBALANCE')
     os.environ['YOLACT_AMD_SPLIT'] = '2'
+    os.environ['YOLACT_AMD_REBALANCE'] = '0'          # the GUARD's behaviour (round 4); the default rebalances instead: test below
     try:
         def wide_layers(state):
             net.load_state_dict_compat(state)
@@ -648,11 +649,37 @@ def test_outlier_guard_needs_an_amplifying_producer_not_just_tiny_columns():
             dead[key][:, [3, 17, 40]] *= 2.0 ** -16                              # dead input channels: tiny columns, ordinary producers
         wide, warned = wide_layers(dead)
         assert wide == [] and not warned
+        # round 6, the default: compensated outlier channels are REBALANCED at pack time (Plan._rebalance_outliers) — the producers'
+        # folded BN scales and the consumers' filters exchange the power of two back, nothing leaves the fp16x2 tiles, nothing is
+        # said; a clean checkpoint and one with dead input channels (no amplifying producer) are left exactly as they are
+        os.environ.pop('YOLACT_AMD_REBALANCE', None)
+
+        def rebalanced(state):
+            net.load_state_dict_compat(state)
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter('always')
+                plan = Plan(net, 2, 550, 550, torch.device('cpu'))
+            return plan, [x for x in w if 'OUTLIER' in str(x.message)]
+        plan, warned = rebalanced(planted)
+        assert plan.wide_layers == [] and not warned
+        # (k = min(producer excess, consumer deficit), floored: the planted 2^12 comes back as 2^10 .. 2^12 per channel — a channel may
+        #  keep a factor <= 4 of its own ordinary spread; what matters is that no tensor carries the planted range any more)
+        assert [r[0] for r in plan.rebalanced] == ['C3', 'C4', 'C5', 'proto_net.0'] and all(r[1] == 4 and 10 <= r[2] <= 12 for r in plan.rebalanced)
+        clean_plan, _ = rebalanced(sd)
+        assert clean_plan.rebalanced == [] and clean_plan.wide_layers == []
+        assert rebalanced(dead)[0].rebalanced == []
+        # the rebalanced producers' gains are back inside the clean checkpoint's spread (x4), channel by channel
+        for pk_p, pk_c in zip(plan.keepalive, clean_plan.keepalive):
+            if hasattr(pk_p, 'out_gain') and pk_p.Cout == pk_c.Cout:
+                gp, gc = pk_p.out_gain(), pk_c.out_gain()
+                ok = gc > 0
+                assert float((gp[ok] / gc[ok]).max()) <= 4.0 + 1e-6 and float((gp[ok] / gc[ok]).min()) >= 0.25 - 1e-6
     finally:
-        if old is None:
-            os.environ.pop('YOLACT_AMD_SPLIT', None)
-        else:
-            os.environ['YOLACT_AMD_SPLIT'] = old
+        for k_, v_ in (('YOLACT_AMD_SPLIT', old), ('YOLACT_AMD_REBALANCE', old_rb)):
+            if v_ is None:
+                os.environ.pop(k_, None)
+            else:
+                os.environ[k_] = v_
 
 
 def test_native_plan_executor_host_side(tmp_path):

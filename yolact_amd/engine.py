@@ -217,6 +217,40 @@ class Packed:
             self._out_gain = g
         return self._out_gain
 
+    def _invalidate(self):
+        self._w3 = self._h2 = None
+        self._out_gain = self._l1_gain = None
+        self._tiny_memo = {}
+
+    def scale_out_channels(self, f: torch.Tensor):
+        """Multiply output channel n of this layer by f[n] (host tensor [Cout], exact powers of two: Plan._rebalance_outliers): the
+        folded scale and shift carry it, the filters are untouched."""
+        f = f.detach().float().cpu()
+        dev = self.w.device
+        sc = self.scale.detach().float().cpu() if self.scale is not None else torch.ones(self.Cout)
+        self.scale = (sc * f).to(dev).contiguous()
+        if self.bias is not None:
+            self.bias = (self.bias.detach().float().cpu() * f).to(dev).contiguous()
+        self._invalidate()
+
+    def scale_in_channels(self, f: torch.Tensor):
+        """Multiply the filters of INPUT channel c (every tap, every filter) by f[c] (host tensor [Cin], exact powers of two)."""
+        f = f.detach().float().cpu()
+        taps = self.kh * self.kw
+        assert self.Kpad == taps * self.Cin and f.numel() == self.Cin
+        wp = self._wp_host.detach().float().cpu().clone()
+        wp.view(self.CoutPad, taps, self.Cin).mul_(f.view(1, 1, -1))
+        self._wp_host = wp
+        self.w = wp.to(self.w.device).contiguous()
+        if self.weight_oihw is not None:
+            self.weight_oihw = self.weight_oihw.detach().float().cpu() * f.view(1, -1, 1, 1)
+        self._invalidate()
+
+    def in_column_max(self):
+        """[Cin] max |w| over filters and taps per input channel (host)."""
+        w = self._wp_host[:self.Cout, :self.kh * self.kw * self.Cin].detach().abs().float().cpu()
+        return w.view(self.Cout, self.kh * self.kw, self.Cin).amax(dim=(0, 1))
+
     def l1_gain(self):
         """(max_n(|folded BN scale_n| * sum_k |w[n, k]|), max_n |folded shift_n|): |y_n| <= amax(x) * gain + shift_max for every
         output of this layer before the residual / activation — the rigorous bound csrc/chain2.hip scales its y slices by
@@ -370,6 +404,28 @@ def out_size(n, k, s, p):
     return (n + 2 * p - k) // s + 1
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    """The side stream of a new plan: one of a FIXED pool of YOLACT_AMD_SIDE_STREAMS (default 3) per device, handed out round robin.
+    HIP folds the streams of a process onto GPU_MAX_HW_QUEUES (4) hardware queues in creation order; with one new torch stream per plan
+    (rounds 1 - 5) the 4th plan of a process got a side stream on the MAIN stream's queue and its two-stream schedule ran 1.5x slower
+    than a single stream (bench.py secondary.outlier_plan, session r6l: 1 180 - 1 260 images/s against 2 050 for the same plan on a
+    stream of the pool).  YOLACT_AMD_SIDE_STREAMS=0: one new stream per plan (A/B switch)."""
+    n = int(os.environ.get('YOLACT_AMD_SIDE_STREAMS', '3'))
+    if n <= 0:
+        return torch.cuda.Stream(device=device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    pool = _SIDE_STREAMS.setdefault(key, {'streams': [], 'next': 0})
+    if len(pool['streams']) < n:
+        pool['streams'].append(torch.cuda.Stream(device=device))
+        return pool['streams'][-1]
+    st = pool['streams'][pool['next'] % n]
+    pool['next'] += 1
+    return st
+
+
 class _OpList(list):
     """The plan's op list: a list that counts its mutations.  The native executor's ymi_plan_op array bakes descriptor addresses and
     op kinds; it is rebuilt whenever `version` moved (round-5 advisor: the earlier key, the ids of the op tuples, could repeat once the
@@ -413,7 +469,11 @@ class Plan:
         # small P4..P7 FPN/head convs and Detect, which are latency-bound and leave most CUs idle when run alone
         # (profiles/r01_layers_v4.txt: 0.7 ms of < 60 TF/s layers + 0.35 ms of Detect per batch-8 step).
         self.two_streams = (device.type == 'cuda' and os.environ.get('YOLACT_AMD_STREAMS', '2') != '1') or dry_two_streams
-        self.stream_b = torch.cuda.Stream(device=device) if self.two_streams and device.type == 'cuda' else None
+        # ONE side stream per device for every plan of the process (round 6): each torch.cuda.Stream() is another HIP stream, HIP folds
+        # streams onto GPU_MAX_HW_QUEUES (4) hardware queues, and the 4th / 5th plan of a process (other batch sizes, a second model)
+        # got a side stream that shared a hardware queue with the main stream — its two-stream schedule then ran 1.5x SLOWER than
+        # one stream (bench.py's outlier_plan line: 5.7 ms against 4.1 single-stream and 3.8 for the same plan built first)
+        self.stream_b = _side_stream(device) if self.two_streams and device.type == 'cuda' else None
         self.overlap = True      # runtime switch: False runs the same op list on ONE stream (serialised kernels), which
                                  # is what per-kernel timing (bench.py's roofline pass) needs
         self.events = {}
@@ -665,7 +725,7 @@ class Plan:
             self.record('latgo%d' % i)
             self.on('B')
             self.wait('latgo%d' % i)
-            raw = self.conv('fpn.lat%d' % i, t, pack_module(self.net.fpn.lat_layers[i], device=self.device))
+            raw = self.conv('fpn.lat%d' % i, t, self._pack(self.net.fpn.lat_layers[i]))
             self.record('lat%d' % i)
             self.on('A')
             self.early_lat[j] = raw
@@ -684,6 +744,91 @@ class Plan:
         if self.two_streams:
             self.ops.append(('wait', ev, ev, self._cur))
 
+    # ---- filters, packed once per plan -----------------------------------------------------------------------------------------
+    def _pack(self, conv, bn=None, cin_pad=None) -> Packed:
+        """pack_module, memoised per (conv, bn): Plan._rebalance_outliers edits the Packed objects of a stage BEFORE the op emitters ask
+        for them."""
+        key = (id(conv), id(bn), cin_pad)
+        pk = self._pk_cache.get(key)
+        if pk is None:
+            pk = self._pk_cache[key] = pack_module(conv, bn, self.device, cin_pad)
+        return pk
+
+    def _rebalance_outliers(self, bb):
+        """COMPENSATED OUTLIER CHANNELS, rebalanced at pack time (round 6).  A BN-folded checkpoint can carry channels whose producers
+        amplify them 2^k over the typical channel (a huge gamma / sigma) while every consumer's filters hold the inverse — exact in fp32,
+        but the fp16x2 tiles give an activation tensor ONE power-of-two scale and a filter row ONE: the typical channels of such a
+        tensor sit k binades below its bound.  Round 4 moved the consuming layers to bf16x3 tiles (Packed.tiny_columns: 18 layers, no
+        Winograd, no fusions; bench.py secondary.outlier_plan: 6.85 ms instead of 3.94 per batch-8 step).  Here the re-parametrisation
+        is UNDONE instead: channel c of a ResNet stage tensor is multiplied by 2^-k in every producer (each block's folded bn3 and the
+        projection shortcut's BN: the identity shortcuts carry the same factor) and by 2^k in every consumer's filters (the conv1 of
+        the following blocks, the next stage's conv1 / projection shortcut, the FPN lateral); likewise proto_net[0] -> proto_net[2].
+        Powers of two commute with fp32 rounding and ReLU, so in fp32 arithmetic every product is unchanged — the network is the same
+        function, with balanced tensors.  k = min(producer excess, consumer deficit) per channel, only where both exceed 2^6: a channel
+        that is merely large (no tiny consumer column) is left alone — moving ITS range into the filter rows would cost them what it
+        saves the tensor.  YOLACT_AMD_REBALANCE=0 keeps the checkpoint's own parametrisation (then the guard of round 4 acts)."""
+        self.rebalanced = []
+        if not (self.h2 and os.environ.get('YOLACT_AMD_REBALANCE', '1') == '1' and isinstance(bb, M.ResNetBackbone)):
+            return
+
+        def exps(gain, cols, thr=6):
+            g = gain.double().clamp_min(0)
+            pos = g[g > 0]
+            if pos.numel() < 8:
+                return None
+            kg = torch.floor(torch.log2((g / pos.median()).clamp_min(2.0 ** -126)))
+            c = cols.double()
+            cpos = c[c > 0]
+            if cpos.numel() < 8:
+                return None
+            kc = torch.floor(torch.log2((cpos.median() / c.clamp_min(2.0 ** -126))))
+            k = torch.minimum(kg, kc).clamp(min=0, max=40)
+            k = torch.where((kg >= thr) & (kc >= thr) & (c > 0), k, torch.zeros_like(k))
+            return k if bool((k > 0).any()) else None
+        layers = list(bb.layers)
+        sel = list(self.net.backbone_selected)
+        fpn = self.net.fpn
+        for li, layer in enumerate(layers):
+            blocks = list(layer)
+            if not blocks or blocks[0].downsample is None:
+                continue
+            prod = [self._pack(b.conv3, b.bn3) for b in blocks] + [self._pack(blocks[0].downsample[0], blocks[0].downsample[1])]
+            cons = [self._pack(b.conv1, b.bn1) for b in blocks[1:]]
+            if li + 1 < len(layers):
+                nb = list(layers[li + 1])[0]
+                cons.append(self._pack(nb.conv1, nb.bn1))
+                if nb.downsample is not None:
+                    cons.append(self._pack(nb.downsample[0], nb.downsample[1]))
+            if li in sel:
+                cons.append(self._pack(fpn.lat_layers[len(sel) - 1 - sel.index(li)]))
+            if not cons or any(pk.Cin != prod[0].Cout or pk.Kpad != pk.kh * pk.kw * pk.Cin for pk in cons):
+                continue
+            gain = torch.stack([pk.out_gain()[:prod[0].Cout] for pk in prod]).amax(0)
+            cols = torch.stack([pk.in_column_max() for pk in cons]).amax(0)
+            k = exps(gain, cols)
+            if k is None:
+                continue
+            down, up = torch.pow(2.0, -k).float(), torch.pow(2.0, k).float()
+            for pk in prod:
+                pk.scale_out_channels(down)
+            for pk in cons:
+                pk.scale_in_channels(up)
+            self.rebalanced.append(('C%d' % (li + 2), int((k > 0).sum()), int(k.max())))
+        # proto_net[0] (3x3 + ReLU) -> proto_net[2]: the same signature one level down the P3 branch
+        pm_ = list(self.net.proto_net)
+        self._proto0_down = None
+        if (len(pm_) > 2 and isinstance(pm_[0], nn.Conv2d) and isinstance(pm_[1], nn.ReLU) and isinstance(pm_[2], nn.Conv2d)
+                and pm_[0].bias is not None):
+            p0, p2 = self._pack(pm_[0]), self._pack(pm_[2])
+            if p2.Cin == p0.Cout and p2.Kpad == p2.kh * p2.kw * p2.Cin:
+                k = exps(p0.out_gain(), p2.in_column_max())
+                if k is not None:
+                    down, up = torch.pow(2.0, -k).float(), torch.pow(2.0, k).float()
+                    p0.scale_out_channels(down)
+                    p2.scale_in_channels(up)
+                    self._proto0_down = down
+                    self.rebalanced.append(('proto_net.0', int((k > 0).sum()), int(k.max())))
+
     # ---- graph construction --------------------------------------------------------------------
     def _build(self):
         net, B, H, W, dev = self.net, self.B, self.H, self.W, self.device
@@ -694,6 +839,8 @@ class Plan:
         self.early_lat, self._pending_lat = {}, []
         self._early_lat_on = self.two_streams and os.environ.get('YOLACT_AMD_EARLY_LAT', '0') == '1'
         bb = net.backbone
+        self._pk_cache = {}
+        self._rebalance_outliers(bb)
         # ResNet stem (fp16x2 plans): layout change + 7x7/2 conv + BN + ReLU + 3x3/2 max-pool in ONE launch straight from the NCHW
         # input (csrc/stem.hip: 0.107 vs 0.168 ms for the three launches at batch 8, 0.020 vs 0.035 at batch 1, bit-identical (see the test for the exact statement)
         # output; profiles/r03_stem_probe.txt).  YOLACT_AMD_FUSED_STEM=0 keeps the separate launches.
@@ -725,7 +872,7 @@ class Plan:
         prev = None
         for i in range(n):
             j = n - 1 - i
-            pk = pack_module(fpn.lat_layers[i], device=dev)
+            pk = self._pack(fpn.lat_layers[i])
             if j in self.early_lat and prev is not None:
                 raw = self.early_lat[j]                 # lat(C_j), computed on B long ago; the sum happens here, in place
                 self.wait('lat%d' % i)
@@ -809,6 +956,8 @@ class Plan:
                 u = self._new(f.B, f.H, f.W, cu.out_channels)
                 t0 = self._new(f.B, f.H, f.W, cp.out_channels)
                 pkm = Packed(torch.cat([cu.weight, cp.weight], 0), torch.cat([cu.bias, cp.bias], 0), None, 1, 1, None, dev)
+                if getattr(self, '_proto0_down', None) is not None:      # (the proto_net[0] half of the merged launch: _rebalance_outliers)
+                    pkm.scale_out_channels(torch.cat([torch.ones(cu.out_channels), self._proto0_down]))
                 hw = f.H * f.W
                 self.conv('head0.up0+proto.0', f, pkm, segs=[
                     (0, cu.out_channels, L.ACT_RELU, cu.out_channels, hw * cu.out_channels, u.ptr),
@@ -891,7 +1040,7 @@ class Plan:
                     assert not has_relu
                 else:
                     a = L.ACT_RELU if has_relu else L.ACT_NONE
-                pk = pack_module(m, device=dev)
+                pk = self._pack(m)
                 if last:
                     Ho, Wo = out_size(t.H, pk.kh, pk.stride, pk.pad), out_size(t.W, pk.kw, pk.stride, pk.pad)
                     self.proto_shape = (B, Ho, Wo, pk.Cout)
@@ -968,10 +1117,10 @@ class Plan:
                     self.record(nm + '.in')
                     self.on('B')
                     self.wait(nm + '.in')
-                    res = self.conv(nm + '.down', x, pack_module(blk.downsample[0], blk.downsample[1], dev))
+                    res = self.conv(nm + '.down', x, self._pack(blk.downsample[0], blk.downsample[1]))
                     self.record(nm + '.down')
                     self.on('A')
-                o1 = self.conv(nm + '.conv1', x, pack_module(blk.conv1, blk.bn1, dev), act=L.ACT_RELU)
+                o1 = self.conv(nm + '.conv1', x, self._pack(blk.conv1, blk.bn1), act=L.ACT_RELU)
                 if blk.use_dcn:
                     dcn = blk.conv2
                     om = self.conv(nm + '.offmask', o1, pack_offmask(dcn.conv_offset_mask, dev, self.om_interleave) if self.om_pad
@@ -985,10 +1134,10 @@ class Plan:
                 if side_down:
                     self.wait(nm + '.down')
                 elif blk.downsample is not None:
-                    res = self.conv(nm + '.down', x, pack_module(blk.downsample[0], blk.downsample[1], dev))
+                    res = self.conv(nm + '.down', x, self._pack(blk.downsample[0], blk.downsample[1]))
                 else:
                     res = x
-                y = self.conv(nm + '.conv3', o2, pack_module(blk.conv3, blk.bn3, dev), act=L.ACT_RELU, res=res,
+                y = self.conv(nm + '.conv3', o2, self._pack(blk.conv3, blk.bn3), act=L.ACT_RELU, res=res,
                               res_mode=L.RES_ADD)
                 ar.free(o2)
                 if side_down:
@@ -1349,7 +1498,7 @@ class Plan:
                     and d3.res_mode == L.RES_ADD and not d3.res_after_act and d3.seg[0].n0 == 0 and d3.seg[0].act <= L.ACT_LEAKY01
                     and d3.w_h2 and d3.x_amax and M * max(d3.seg[0].row_stride, d3.res_ld) < (1 << 29)):
                 continue
-            if P_ > 64 and os.environ.get('YOLACT_AMD_CHAIN2', '1') != '1':       # A/B switch of csrc/chain2.hip (round 6)
+            if P_ > 64 and os.environ.get('YOLACT_AMD_CHAIN2', '0') != '1':       # csrc/chain2.hip is OPT-IN: measured 0.80x of the two launches it replaces (profiles/r06_chain2_probe.txt)
                 continue
             pair = False
             if i < len(self.ops) and self.ops[i][0] is lib.ymi_conv2d_nhwc_f32 and self.ops[i][3] == w3 and i not in self.wide_ops:
