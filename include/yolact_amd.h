@@ -113,6 +113,10 @@ enum { YMI_TILE_AUTO = 0, YMI_TILE_128x128 = 1, YMI_TILE_128x64 = 2, YMI_TILE_64
        /* one block per CU, deep LDS-DMA pipeline (96 - 144 KB of stages): the regime the bf16x3 variants need, whose K
         * step is too short to hide a DMA round trip behind one or two co-resident blocks */
        YMI_TILE_128x128_S3 = 19, YMI_TILE_128x128_W8_S3 = 20, YMI_TILE_256x128_W8_S3 = 21, YMI_TILE_128x128_W8_S4 = 22,
+       /* round 6, ymi_conv3x3_winograd_f32 only (`| YMI_TILE_H2`, v_planes = 1): the grouped GEMM of the Winograd path as ONE persistent
+        * producer / consumer launch over (component, 128-row tile, 256-column block) work items whose chunk stream does not stop at item
+        * boundaries (csrc/wgemm.hip); M is bit-identical to the 128 x 128 tile's */
+       YMI_TILE_WG_128x256 = 23,
        /* tile | YMI_TILE_X3: the same block tile computed as "bf16x3" — every fp32 operand split exactly into three bf16
         * pieces BY TRUNCATION (24 mantissa bits), 6 of the 9 piece products on v_mfma_f32_32x32x16_bf16 with fp32
         * accumulation; the dropped terms (m*l, l*m, l*l) are < 2^-21 |a b| in the worst case (|m| < 2^-7 |a|, |l| < 2^-15 |a|;

@@ -32,6 +32,9 @@ def test_conv_plain(shape, tile):
     if (tile & L.TILE_DCNP) and Cout % 4:
         pytest.skip('the pipelined kernel (csrc/dcn.hip) stores float4 rows: Cout % 4 == 0 (an explicit request is refused, see '
                     'test_dcn_pipelined_rejects_what_it_cannot_run)')
+    if not (tile & L.TILE_DCNP) and (tile & 31) == L.TILE_WG_128x256:
+        pytest.skip('csrc/wgemm.hip is the grouped GEMM of the Winograd path only (ymi_conv3x3_winograd_f32; refused by the conv engine: '
+                    'test_winograd_persistent_grouped_gemm)')
     if (tile & L.TILE_DCNP) and (tile & 31) in L.PATCH2_TILES and (k, s, p, Cout >= 64) != (3, 1, 1, True):
         pytest.skip('csrc/patch2.hip takes 3x3 / s1 / p1 with Cout >= 64 only (refused with YMI_EARG: test_patch2_kernel_output_segments)')
     if (tile & L.TILE_DCNP) and (tile & 31) == L.DCNP_PATCH_C64:
@@ -970,6 +973,33 @@ def test_winograd_fp16x2(shape, tile, m, v_planes):
     assert rel_err(y, ref) < (2e-5 if m == 2 else 5e-5)
     assert rel_err(y, y_fp32) < (1e-5 if m == 2 else 3e-5)          # same algorithm, exact-fp32 MFMA GEMM
     assert run_wino.last_amax[1] == y_fp32.abs().max().item() or abs(run_wino.last_amax[1] - y_fp32.abs().max().item()) < 1e-3
+
+
+@pytest.mark.parametrize('m', [2, 4])
+@pytest.mark.parametrize('shape', [(8, 256, 69, 69, 256), (2, 256, 35, 35, 360), (1, 64, 21, 30, 128), (3, 512, 18, 18, 512), (1, 128, 9, 7, 36),
+                                   (2, 96, 40, 33, 260)])
+def test_winograd_persistent_grouped_gemm(shape, m):
+    """csrc/wgemm.hip (tile YMI_TILE_WG_128x256 | YMI_TILE_H2, V as fp16 planes): the grouped GEMM of the Winograd path as one persistent
+    producer / consumer launch — work items that outnumber the CUs and fewer items than CUs, ragged row tiles, column counts that are
+    no multiple of 256 / 128 / 32, K = 64 .. 512, F(2x2) and F(4x4) — BIT-IDENTICAL to the 128 x 128 fp16x2 tile on the same planes
+    (same products, same K order), and against torch fp32; an ordinary convolution or fp32 V is refused."""
+    from gpu_utils import run_wino, run_conv, rel_err
+    B, Cin, H, W, Cout = shape
+    g = _g(B * 100 + Cin + Cout + H + m + 7)
+    x = torch.randn(B, Cin, H, W, generator=g) * torch.exp(torch.randn(B, Cin, 1, 1, generator=g))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    ref = F.relu(F.conv2d(x, w, b, 1, 1))
+    t = L.TILE_WG_128x256 | L.TILE_H2
+    y = run_wino(x, w, b, None, L.ACT_RELU, t, m, v_planes=True)
+    y0 = run_wino(x, w, b, None, L.ACT_RELU, L.TILE_128x128 | L.TILE_H2, m, v_planes=True)
+    assert torch.equal(y, y0)
+    assert rel_err(y, ref) < (2e-5 if m == 2 else 5e-5)
+    assert torch.equal(y, run_wino(x, w, b, None, L.ACT_RELU, t, m, v_planes=True))
+    with pytest.raises(RuntimeError):                                     # V not written as planes
+        run_wino(x, w, b, None, L.ACT_RELU, t, m, v_planes=False)
+    with pytest.raises(RuntimeError):                                     # not a tile of the conv engine
+        run_conv(x, w, b, None, 1, 1, tile=t)
 
 
 @pytest.mark.parametrize('B,H,W', [(2, 61, 77), (1, 550, 550)])

@@ -78,7 +78,7 @@ def main():
                         else:
                             gem += ms.value; gfl = fl.value
                     lay /= args.reps; gem /= args.reps
-                    key = '%s F(%dx%d) %s %s' % (name, m, m, L.TILE_NAMES[base], label)
+                    key = '%s F(%dx%d) %s %s' % (name, m, m, L.TILE_NAMES.get(base, L.TILE_NAMES.get(base | L.TILE_H2, 'tile%d' % base)), label)
                     out[key] = {'layer_ms': round(lay, 4), 'gemm_ms': round(gem, 4), 'transforms_ms': round(lay - gem, 4),
                                 'gemm_tflops_executed': round(gfl / gem / 1e9, 1), 'layer_tflops_algorithmic': round(alg / lay / 1e9, 1)}
                     print('%-52s layer %.4f ms  gemm %.4f (%6.1f TF/s executed)  transforms %.4f  alg %6.1f TF/s' % (

@@ -23,6 +23,7 @@ TILE_NAMES = {1: '128x128', 2: '128x64', 3: '64x64', 4: '128x32', 5: '64x128', 6
               22: '128x128w8s4'}
 TILE_128x128_W8, TILE_256x128_W8, TILE_128x256_W8 = 16, 17, 18
 TILE_128x128_S3, TILE_128x128_W8_S3, TILE_256x128_W8_S3, TILE_128x128_W8_S4 = 19, 20, 21, 22
+TILE_WG_128x256 = 23                # csrc/wgemm.hip (round 6): persistent producer / consumer grouped GEMM, Winograd path only (| TILE_H2, planes)
 TILE_X3 = 32                        # tile | TILE_X3: bf16x3 split-precision variant of the same block tile (include/yolact_amd.h)
 X3_BASE_TILES = (1, 2, 3, 5, 6, 7, 8, 9, 11, 12, 16, 17, 19, 20, 21, 22)
 for _t in X3_BASE_TILES:
@@ -33,6 +34,7 @@ H2_BASE_TILES = X3_BASE_TILES + (18, 13, 14, 15)   # + 128x256w8: one column blo
                                                   # + the deeper-pipelined K-split tiles (batch 1: ~23 % of the kernel time sat in 32x32k4)
 for _t in H2_BASE_TILES:
     TILE_NAMES[_t | TILE_H2] = TILE_NAMES[_t] + 'h2'
+TILE_NAMES[TILE_WG_128x256 | TILE_H2] = 'wg128x256h2'
 TILE_DCNP = 128                     # TILE_H2 | TILE_DCNP | DCNP_*: the pipelined DCNv2 gather-GEMM (csrc/dcn.hip); the low bits are ITS tile enum
 DCNP_64x128, DCNP_64x128_W8, DCNP_64x64, DCNP_128x128_W8, DCNP_128x64_W8, DCNP_32x128 = 1, 2, 3, 4, 5, 6
 DCNP_96x128_W6, DCNP_128x128_W8_R1, DCNP_160x128_W10, DCNP_192x128_W12, DCNP_64x256_W8, DCNP_96x256_W12, DCNP_128x256_W16 = range(7, 14)

@@ -15,6 +15,8 @@
 int ymi_internal_grouped_gemm(const ymi_conv_desc *d, int groups, long x_gs, long w_gs, long y_gs, double prof_flops,
                               int prof_kind, hipStream_t s, const void *a2 = nullptr, unsigned a2_plane = 0, long a2_gs = 0,
                               unsigned sc_gs = 0);
+int ymi_internal_wgemm(const void *v, const void *u, const float *uinv, const float *x_amax, float amax_mul, float *m, int G, long T,
+                       int C, int Ng, int cout_pad, double prof_flops, int prof_kind, hipStream_t s);      // csrc/wgemm.hip
 int ymi_internal_prof_begin(double flops, int tile, int kind, hipStream_t s);
 void ymi_internal_prof_end(int idx, hipStream_t s);
 
@@ -711,7 +713,11 @@ extern "C" int ymi_conv3x3_winograd_f32(const ymi_wino_desc *d, void *stream) {
   g.seg[0].n0 = 0; g.seg[0].n1 = Ng; g.seg[0].act = YMI_ACT_NONE; g.seg[0].row_stride = Ng;
   g.seg[0].batch_stride = T * Ng; g.seg[0].ptr = d->M;
   const long cout_pad = ((long)d->Cout + 127) / 128 * 128;
-  if (planes)      // V = [G][2][T][C] fp16: both GEMM operands arrive pre-split (conv_igemm PREC 4)
+  if ((d->tile & 31) == YMI_TILE_WG_128x256) {     // the persistent producer / consumer grouped GEMM (csrc/wgemm.hip): planes only
+    if (!planes || (d->tile & YMI_TILE_X3)) return YMI_EARG;
+    rc = ymi_internal_wgemm(d->V, d->u_h2, d->uinv_h2, d->x_amax, mt == 4 ? 100.f : 4.f, d->M, ng, T, d->C, Ng, (int)cout_pad, exe,
+                            mt == 4 ? 6 : 5, s);
+  } else if (planes)      // V = [G][2][T][C] fp16: both GEMM operands arrive pre-split (conv_igemm PREC 4)
     rc = ymi_internal_grouped_gemm(&g, ng, T * d->C, cout_pad * d->C, T * Ng, exe, mt == 4 ? 6 : 5, s, d->V,
                                    (unsigned)(T * d->C * 2), 2L * T * d->C * 2, (unsigned)cout_pad);
   else

@@ -1785,6 +1785,8 @@ class Plan:
         if self.h2:     # fp16x2 GEMM tiles, V either fp32 (split on the fly) or written as fp16 planes by the input transform
             hb = wtiles + [L.TILE_128x256_W8]
             wtiles = wtiles + [t | L.TILE_H2 for t in hb] + [t | L.TILE_H2 | L.WINO_PLANES for t in hb]
+            if os.environ.get('YOLACT_AMD_WGEMM', '1') == '1':       # round 6: the persistent producer / consumer grouped GEMM (planes only)
+                wtiles = wtiles + [L.TILE_WG_128x256 | L.TILE_H2 | L.WINO_PLANES]
         memo = {}
         for idx, alts in sorted(self.wino_alt.items()):
             fn, dptr, name, where = self.ops[idx]
