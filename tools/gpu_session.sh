@@ -150,6 +150,11 @@ PY
       timeout 600 python tools/patch2_trace.py ${arg//+/ } > $O/patch2_trace.txt 2>&1
       (cd yolact_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC *.o -o ../libyolact_amd.so) >> $O/patch2trace_build.log 2>&1
       grep -vE "^\\[W|amdgpu.ids" $O/patch2_trace.txt | tail -30 ;;
+    wgemmtrace) # diagnostics build of csrc/wgemm.hip, then tools/wgemm_trace.py; the product object is linked back
+      (cd yolact_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-value -Wno-c++20-extensions -I../../include -DYMI_DIAGNOSTICS=1 -c wgemm.hip -o /tmp/wgemm_diag.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls *.o | grep -v '^wgemm.o$') /tmp/wgemm_diag.o -o ../libyolact_amd.so) > $O/wgemmtrace_build.log 2>&1; tail -2 $O/wgemmtrace_build.log
+      timeout 600 python tools/wgemm_trace.py > $O/wgemm_trace.txt 2>&1
+      (cd yolact_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC *.o -o ../libyolact_amd.so) >> $O/wgemmtrace_build.log 2>&1
+      grep -vE "^\\[W|amdgpu.ids" $O/wgemm_trace.txt | tail -20 ;;
     pipeabl) # diagnostics build of csrc/dcn.hip, then the ablation of the pipelined kernel as an ordinary convolution on representative layers
       (cd yolact_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-value -I../../include -DYMI_DIAGNOSTICS=1 -c dcn.hip -o /tmp/dcn_diag.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls *.o | grep -v '^dcn.o$') /tmp/dcn_diag.o -o ../libyolact_amd.so) > $O/pipeabl_build.log 2>&1; tail -2 $O/pipeabl_build.log
       timeout 600 python tools/pipe_probe.py --layers ${arg:-proto.8,proto.2,layer1.1.conv2,layer1.1.conv1,layer2.1.conv1,layer3.0.conv1,layer2.1.conv3} --ablate 1,2,3,4,8,12,16,15,31 > $O/pipe_ablation.txt 2>&1; grep -E "abl=|pipelined" $O/pipe_ablation.txt | cut -c1-330 ;;

@@ -44,6 +44,8 @@ struct WgParams {
   int G, T, C, Ng, cout_pad, tiles_m, tiles_n, nitems;
   float amax_mul;
   unsigned long long *trace;
+  int abl;                                 // diagnostics build (env YMI_WGEMM_ABLATE): bit0 no M stores, bit1 V requests out of bounds (no access), bit2 U requests
+                                           // out of bounds, bit3 no MFMAs, bit4 non-temporal M stores — wrong results by design (except bit4)
 };
 
 __global__ __launch_bounds__(512, 2) void wgemm_k(const WgParams p) {
@@ -104,12 +106,12 @@ __global__ __launch_bounds__(512, 2) void wgemm_k(const WgParams p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = tm * BM + a_row[i];
-        a_vo[i] = (live && row < p.T) ? a_ko[i] + (unsigned)(row * p.C) * 2u : OOB;
+        a_vo[i] = (live && row < p.T && !(p.abl & 2)) ? a_ko[i] + (unsigned)(row * p.C) * 2u : OOB;
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int row = tn * BN + b_row[i];
-        b_vo[i] = (live && row < p.cout_pad) ? b_ko[i] + (unsigned)(row * p.C) * 2u : OOB;
+        b_vo[i] = (live && row < p.cout_pad && !(p.abl & 4)) ? b_ko[i] + (unsigned)(row * p.C) * 2u : OOB;
       }
       // the item's 256 inverse filter scales: ONE 1 KB piece (every producer wave issues it — same bytes, same place — so that the
       // waves' vmcnt stay in step); columns past cout_pad: zeros
@@ -199,6 +201,9 @@ __global__ __launch_bounds__(512, 2) void wgemm_k(const WgParams p) {
             for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
               for (int j = 0; j < 2; ++j)
+#ifdef YMI_DIAGNOSTICS
+                if (!(p.abl & 8))
+#endif
                 acc[2 * ip + ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 0 ? ul[ii] : uh[ii], pr == 1 ? vl[j] : vh[j], acc[2 * ip + ii][j], 0, 0, 0);
         }
       }
@@ -225,6 +230,10 @@ __global__ __launch_bounds__(512, 2) void wgemm_k(const WgParams p) {
               f32x4 v;
 #pragma unroll
               for (int e = 0; e < 4; ++e) { v[e] = acc[i][j][4 * gq + e] * (s4[e] * invA); acc[i][j][4 * gq + e] = 0.f; }
+#ifdef YMI_DIAGNOSTICS
+              if (p.abl & 1) continue;
+              if (p.abl & 16) { if (rok && n < p.Ng) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(mg + (size_t)row * p.Ng + n)); continue; }
+#endif
               if (rok && n < p.Ng) *reinterpret_cast<f32x4 *>(mg + (size_t)row * p.Ng + n) = v;
             }
         }
@@ -276,8 +285,9 @@ int ymi_internal_wgemm(const void *v, const void *u, const float *uinv, const fl
   p.G = G; p.T = (int)T; p.C = C; p.Ng = Ng; p.cout_pad = cout_pad;
   p.tiles_m = (int)((T + BM - 1) / BM); p.tiles_n = (Ng + BN - 1) / BN; p.nitems = G * p.tiles_m * p.tiles_n;
   p.amax_mul = amax_mul;
-  p.trace = nullptr;
+  p.trace = nullptr; p.abl = 0;
 #ifdef YMI_DIAGNOSTICS
+  { const char *e = getenv("YMI_WGEMM_ABLATE"); p.abl = e ? atoi(e) : 0; }
   { const char *e = getenv("YMI_WGEMM_TRACE"); p.trace = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }
 #endif
   int dev = 0, cus = 256;
