@@ -22,6 +22,9 @@
 #   boxinfo      tools/box_info.sh: driver / firmware / partition / clock facts of THIS box (to tell the pool's boxes apart)
 #   exab         same-box A/B: record gather enqueued behind Detect on its stream (default) against behind the whole forward
 #   allocab      same-box A/B: one 16 GiB device mapping for every buffer / expandable segments against the default allocator
+#   pipetrace / pctrace / chain2trace / patch2trace / wgemmtrace   (round 6) diagnostics build of ONE kernel source, then its in-kernel
+#                s_memtime phase stamps (tools/pipe_trace.py, pc_trace.py, chain2_trace.py, patch2_trace.py, wgemm_trace.py); the product
+#                object is linked back afterwards
 O=gpurun_out/$1; shift; mkdir -p $O
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
