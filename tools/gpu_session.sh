@@ -158,6 +158,20 @@ PY
       timeout 600 python tools/wgemm_trace.py > $O/wgemm_trace.txt 2>&1
       (cd yolact_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC *.o -o ../libyolact_amd.so) >> $O/wgemmtrace_build.log 2>&1
       grep -vE "^\\[W|amdgpu.ids" $O/wgemm_trace.txt | tail -20 ;;
+    auxab) # A/B of the cache policy of pipe_h2_k's activation requests: product build (default policy) against -DYMI_A_AUX=<arg, default 2 = nt>,
+           # the plan's own pipelined launches timed by tools/pipe_probe.py, then the bench, alternating twice; the product object is linked back
+      AUX=${arg:-2}
+      LAY="layer1.,layer2.,layer3.,fpn.lat"
+      for rep in 1 2; do
+        (cd yolact_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC *.o -o ../libyolact_amd.so) > $O/auxab_build.log 2>&1
+        timeout 300 python tools/pipe_probe.py --layers $LAY --plan-only --reps 10 2>/dev/null | grep -E "^layer|^fpn|TOTAL" | awk -v t="aux=0 rep$rep" '{print t, $0}' >> $O/aux_ab_layers.txt
+        timeout 300 python bench.py --steps 30 --no-cpu-baseline --no-secondary --no-calibration --no-strong 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('aux=0', d['value'], d['ms_per_step'])" | tee -a $O/aux_ab.txt
+        (cd yolact_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-value -Wno-c++20-extensions -I../../include -DYMI_A_AUX=$AUX -c dcn.hip -o /tmp/dcn_aux.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls *.o | grep -v '^dcn.o$') /tmp/dcn_aux.o -o ../libyolact_amd.so) >> $O/auxab_build.log 2>&1
+        timeout 300 python tools/pipe_probe.py --layers $LAY --plan-only --reps 10 2>/dev/null | grep -E "^layer|^fpn|TOTAL" | awk -v t="aux=$AUX rep$rep" '{print t, $0}' >> $O/aux_ab_layers.txt
+        timeout 300 python bench.py --steps 30 --no-cpu-baseline --no-secondary --no-calibration --no-strong 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('aux=$AUX', d['value'], d['ms_per_step'])" | tee -a $O/aux_ab.txt
+      done
+      (cd yolact_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC *.o -o ../libyolact_amd.so) >> $O/auxab_build.log 2>&1
+      grep TOTAL $O/aux_ab_layers.txt | cut -c1-200 ;;
     pipeabl) # diagnostics build of csrc/dcn.hip, then the ablation of the pipelined kernel as an ordinary convolution on representative layers
       (cd yolact_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-value -I../../include -DYMI_DIAGNOSTICS=1 -c dcn.hip -o /tmp/dcn_diag.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls *.o | grep -v '^dcn.o$') /tmp/dcn_diag.o -o ../libyolact_amd.so) > $O/pipeabl_build.log 2>&1; tail -2 $O/pipeabl_build.log
       timeout 600 python tools/pipe_probe.py --layers ${arg:-proto.8,proto.2,layer1.1.conv2,layer1.1.conv1,layer2.1.conv1,layer3.0.conv1,layer2.1.conv3} --ablate 1,2,3,4,8,12,16,15,31 > $O/pipe_ablation.txt 2>&1; grep -E "abl=|pipelined" $O/pipe_ablation.txt | cut -c1-330 ;;

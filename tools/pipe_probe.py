@@ -27,6 +27,7 @@ def main():
     ap.add_argument('--all-cands', action='store_true', help='print every candidate, not only the best')
     ap.add_argument('--ablate', default='', help='comma list of YMI_DCN_ABLATE masks (diagnostics build): the best candidate is re-timed per mask')
     ap.add_argument('--tiles', default='', help='restrict the pipelined candidates to these names (e.g. dcnp128x256w16,dcnp160x128w10/k2)')
+    ap.add_argument('--plan-only', action='store_true', help='time the plan\'s own op of every eligible layer and nothing else (A/B of a rebuilt library)')
     args = ap.parse_args()
     import yolact_amd
     from yolact_amd import _lib as L
@@ -76,6 +77,11 @@ def main():
             continue
         fl = lib.ymi_conv_flops(C.byref(d0))
         t_plan = timed(fn, arg)
+        if args.plan_only:
+            tot_plan += t_plan; tot_best += t_plan; tot_fl += fl
+            print('%-22s B%d %3dx%-3d s%d k%d %4d>%-4d %6.2f GF | plan %-34s %.4f ms %6.1f TF/s' % (
+                base, d0.B, d0.H, d0.W, d0.stride, d0.kh, d0.Cin, d0.Cout, fl / 1e9, name[-34:], t_plan, fl / t_plan / 1e9), flush=True)
+            continue
         # a private copy of the direct descriptor writing to a scratch output
         d = L.ConvDesc.from_buffer_copy(d0)
         M = d.B * d.Ho * d.Wo

@@ -32,6 +32,12 @@
 int ymi_internal_prof_begin(double flops, int tile, int kind, hipStream_t s);
 void ymi_internal_prof_end(int idx, hipStream_t s);
 
+// cache policy of the A-operand requests (the activation rows, read once or twice per launch from beyond L2): 0 = default, 2 = nt
+// (non-temporal).  A/B'd in session r6r (stage `auxab` of tools/gpu_session.sh): see profiles/r06_aux_ab.txt
+#ifndef YMI_A_AUX
+#define YMI_A_AUX 0
+#endif
+
 namespace {
 
 constexpr int BK = 32;
@@ -264,9 +270,9 @@ void pipe_h2_k(const DcnParams p) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
 #ifdef YMI_DIAGNOSTICS
-      ring[S][i][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (p.abl & 1) ? OOB : gq[i][c], so, 0));
+      ring[S][i][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (p.abl & 1) ? OOB : gq[i][c], so, YMI_A_AUX));
 #else
-      ring[S][i][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, gq[i][c], so, 0));
+      ring[S][i][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, gq[i][c], so, YMI_A_AUX));
 #endif
     }
     if constexpr (!PLAIN) {
