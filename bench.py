@@ -382,7 +382,7 @@ def traffic_from_profiles(kernel):
     inside this process, so the figure is STATIC: the committed summary of separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
     passes over this very command (FETCH_SIZE doubled per MI355X_MICROARCH.md; `tools/gpu_session.sh <name> traffic`).
     It is only reported when that summary was measured with the tile table this run uses (`tune_sha`), else null."""
-    for fn in ('r05_traffic.json', 'r04_traffic.json', 'r03_traffic.json', 'r02_traffic.json'):
+    for fn in ('r06_traffic.json', 'r05_traffic.json', 'r04_traffic.json', 'r03_traffic.json', 'r02_traffic.json'):
         path = os.path.join(ROOT, 'profiles', fn)
         if os.path.exists(path):
             with open(path) as f:
@@ -823,6 +823,9 @@ def main():
                     'configs[1] at 8 GPUs = one image per GPU.  The weak-scaling region (--batch images per GPU) stays the headline value; '
                     'this second timed region is reported as `strong_scaling`')
     ap.add_argument('--no-strong', action='store_true', help='skip the strong-scaling region')
+    ap.add_argument('--step-overlap', type=int, default=int(os.environ.get('YOLACT_AMD_STEP_OVERLAP', '1')), choices=(1, 2),
+                    help='2: consecutive steps alternate between two plan instances (Yolact.forward_device(slot=)) on two HIP streams, so '
+                         'that batch i + 1 starts while batch i is still in its tail; 1: one plan, one stream (every step behind the last)')
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit('--gpus must be >= 1')
@@ -886,8 +889,13 @@ def main():
         host_counts = [torch.empty(args.batch * world, dtype=torch.float32, pin_memory=True) for _ in range(2)]
         turn = {'i': 0}
         gatherer = parallel.RecordGatherer(0)        # persistent receive buffers: no allocation, no torch.cat per step
+        # --step-overlap 2: a second plan instance (slot 1) with its own gather buffers, driven on its own stream
+        gatherers = [gatherer, parallel.RecordGatherer(0)]
+        step_streams = [torch.cuda.current_stream(dev), torch.cuda.Stream(device=dev)] if args.step_overlap == 2 else None
+        lane = {'k': 0, 'n': 0}
 
         def exchange(out):
+            gatherer = gatherers[lane['k']]
             # (called by forward_device right behind Detect, on the stream Detect runs on — the way Yolact.forward_sharded /
             #  parallel.sharded_forward enqueue it: the records do not depend on the prototypes)
             # pack_records = the record tensor the Detect selection kernel wrote itself (no torch op)
@@ -901,16 +909,25 @@ def main():
             ev.record()
             return (buf, ev, int(rec.shape[0]))
 
-        def launch():
+        def launch_on(slot):
+            lane['k'] = slot
             if args.exchange_after_join:
-                out = net.forward_device(x)
+                out = net.forward_device(x, slot=slot)
                 handle = exchange(out)
             else:
-                out = net.forward_device(x, after_detect=exchange)
+                out = net.forward_device(x, after_detect=exchange, slot=slot)
                 handle = out.pop('after_detect')
             if args.with_postprocess:
                 postprocess_batch(out, size, size)
             return handle
+
+        def launch():
+            if step_streams is None:
+                return launch_on(0)
+            slot = lane['n'] & 1
+            lane['n'] += 1
+            with torch.cuda.stream(step_streams[slot]):
+                return launch_on(slot)
 
         def collect(handle):
             if handle is not None:
@@ -935,6 +952,8 @@ def main():
             collect(prev)
 
         net.plan_for(x)                          # plan build (weight packing, table look-ups) is set-up, not a step
+        if args.step_overlap == 2:
+            net.plan_for(x, 1)
         calib = box_calibration(dev) if (rank == 0 and not args.no_calibration) else None
         run_steps(args.warmup)
         if have_pg:
@@ -1046,6 +1065,8 @@ def main():
                                        % ('configs[1]: ' if is_headline else '', args.config, size, size, args.batch),
                            'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
                            'postprocess_in_step': bool(args.with_postprocess),
+                           'step_overlap': ('2: consecutive batches alternate between two plan instances on two HIP streams' if args.step_overlap == 2
+                                            else '1: every step is issued behind the previous one on one stream'),
                            'host_read': ('blocking, every step' if args.no_pipeline else
                                          'every step, asynchronous D2H copy collected after the next step is launched (depth 2)'),
                            'plan': {'source': 'shipped tune table yolact_amd/tune/gfx950.json' if plan.tune_misses == 0

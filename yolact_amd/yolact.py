@@ -340,7 +340,7 @@ class Yolact(nn.Module):
             plan.mark_done()                                     # the clones read the graph's static outputs
             return res
 
-    def forward_device(self, x, after_detect=None):
+    def forward_device(self, x, after_detect=None, slot=0):
         """Forward + Detect with NO host synchronisation: fixed-capacity device tensors
         (count [B], box [B,cap,4], score, cls, coef, prior) + 'proto'. Used by the data-parallel path
         (yolact_amd.parallel) and by throughput runs that keep results on the GPU.
@@ -348,11 +348,16 @@ class Yolact(nn.Module):
         after_detect (optional): `after_detect(out)` is called with Detect's outputs (everything but 'proto') as soon as Detect's
         kernels are enqueued, with the stream they run on as torch's current stream; what it returns is out['after_detect'].  The
         data-parallel path hands its record gather in here: the records do not depend on the prototypes, and the protonet is the
-        tail of the step."""
+        tail of the step.
+
+        slot (round 6): which of the model's plan instances for this input shape runs the batch.  Every slot owns its activation arena,
+        head buffers, Winograd workspaces and Detect workspaces, so two batches issued on DIFFERENT HIP streams with different slots may
+        overlap on the device — a throughput server alternating slot 0 / 1 on two streams fills the CUs a batch's under-filled launches
+        (the 35 x 35 / 18 x 18 stages, Detect, the launch boundaries) leave idle with the next batch's work (bench.py --step-overlap)."""
         L.require_cuda(x, 'input batch')
         x = x.detach().to(torch.float32).contiguous()
         with torch.cuda.device(x.device):
-            return self._forward_device_one(x, after_detect=after_detect)
+            return self._forward_device_one(x, slot=int(slot), after_detect=after_detect)
 
     def forward_sharded(self, x_global, dst=0, masks=None, mask_size=None, n_global=None):
         """Data-parallel inference of one global batch across the ranks of torch.distributed (one process per GPU, RCCL): this
