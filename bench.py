@@ -37,6 +37,11 @@ max(FLOPs / tile peak, algorithmic bytes / 8 TB/s), `per_kernel` = every instant
 L2-resident read stream), the host's cost per C-ABI call / kernel launch, and what rocm-smi reports — so that two runs can be
 attributed to the box or to the code.  `host_issue_ms_per_step`: host time to issue one step (far below ms_per_step = GPU-bound).
 DESIGN.md 3.5 / 6.
+Round 6: `--step-overlap N` (default 2; `config.step_overlap`): consecutive steps rotate over N plan instances of the model
+(Yolact.forward_device(slot=): own arena, head buffers, workspaces) on N HIP streams, so that batch i + 1 starts while batch i is in its
+tail — the reference's own throughput mode pipelines frames the same way (eval.py evalvideo: a thread pool keeps several frames in
+flight).  Every step is still one full pass over one batch, every step's counts still reach the host inside the timed region;
+`strong_scaling` (one plan, one stream) is the serial figure in the same line.
 """
 import argparse
 import ctypes as C
@@ -823,8 +828,8 @@ def main():
                     'configs[1] at 8 GPUs = one image per GPU.  The weak-scaling region (--batch images per GPU) stays the headline value; '
                     'this second timed region is reported as `strong_scaling`')
     ap.add_argument('--no-strong', action='store_true', help='skip the strong-scaling region')
-    ap.add_argument('--step-overlap', type=int, default=int(os.environ.get('YOLACT_AMD_STEP_OVERLAP', '1')), choices=(1, 2),
-                    help='2: consecutive steps alternate between two plan instances (Yolact.forward_device(slot=)) on two HIP streams, so '
+    ap.add_argument('--step-overlap', type=int, default=int(os.environ.get('YOLACT_AMD_STEP_OVERLAP', '2')), choices=(1, 2, 3, 4, 5, 6, 8),
+                    help='N > 1: consecutive steps rotate over N plan instances (Yolact.forward_device(slot=)) on N HIP streams, so '
                          'that batch i + 1 starts while batch i is still in its tail; 1: one plan, one stream (every step behind the last)')
     args = ap.parse_args()
     if args.gpus < 1:
@@ -886,12 +891,13 @@ def main():
         # COLLECTED after step i+1 has been launched (depth-2 software pipeline, two pinned buffers), so the GPU does not
         # idle while the host turns around; every step's counts still reach the host, in order, inside the timed region.
         # --no-pipeline restores the launch / blocking read / launch sequence.
-        host_counts = [torch.empty(args.batch * world, dtype=torch.float32, pin_memory=True) for _ in range(2)]
+        host_counts = [torch.empty(args.batch * world, dtype=torch.float32, pin_memory=True) for _ in range(2 * max(1, args.step_overlap))]
         turn = {'i': 0}
         gatherer = parallel.RecordGatherer(0)        # persistent receive buffers: no allocation, no torch.cat per step
         # --step-overlap 2: a second plan instance (slot 1) with its own gather buffers, driven on its own stream
-        gatherers = [gatherer, parallel.RecordGatherer(0)]
-        step_streams = [torch.cuda.current_stream(dev), torch.cuda.Stream(device=dev)] if args.step_overlap == 2 else None
+        NOV = args.step_overlap
+        gatherers = [gatherer] + [parallel.RecordGatherer(0) for _ in range(NOV - 1)]
+        step_streams = ([torch.cuda.current_stream(dev)] + [torch.cuda.Stream(device=dev) for _ in range(NOV - 1)]) if NOV > 1 else None
         lane = {'k': 0, 'n': 0}
 
         def exchange(out):
@@ -902,7 +908,7 @@ def main():
             rec = gatherer(parallel.pack_records(out), args.batch, force_collective=have_pg)
             if rec is None:
                 return None
-            buf = host_counts[turn['i'] & 1]
+            buf = host_counts[turn['i'] % len(host_counts)]
             turn['i'] += 1
             buf[:rec.shape[0]].copy_(rec[:, 0], non_blocking=True)
             ev = torch.cuda.Event()
@@ -924,7 +930,7 @@ def main():
         def launch():
             if step_streams is None:
                 return launch_on(0)
-            slot = lane['n'] & 1
+            slot = lane['n'] % NOV
             lane['n'] += 1
             with torch.cuda.stream(step_streams[slot]):
                 return launch_on(slot)
@@ -939,7 +945,9 @@ def main():
         issue_s = []                                    # host time to ISSUE one step (launch loop + gather + copy request), per step
 
         def run_steps(k):
-            prev = None
+            # the host reads of the last `depth - 1` steps are still outstanding while the next step is issued
+            # (depth 2 with one plan; with N plan instances in rotation N steps may be in flight on the device)
+            depth, pend = max(2, args.step_overlap), []
             for _ in range(k):
                 t_is = time.perf_counter()
                 cur = launch()
@@ -947,13 +955,15 @@ def main():
                 if args.no_pipeline:
                     collect(cur)
                 else:
-                    collect(prev)
-                    prev = cur
-            collect(prev)
+                    pend.append(cur)
+                    if len(pend) >= depth:
+                        collect(pend.pop(0))
+            for h in pend:
+                collect(h)
 
         net.plan_for(x)                          # plan build (weight packing, table look-ups) is set-up, not a step
-        if args.step_overlap == 2:
-            net.plan_for(x, 1)
+        for sl_ in range(1, args.step_overlap):
+            net.plan_for(x, sl_)
         calib = box_calibration(dev) if (rank == 0 and not args.no_calibration) else None
         run_steps(args.warmup)
         if have_pg:
@@ -1065,10 +1075,11 @@ def main():
                                        % ('configs[1]: ' if is_headline else '', args.config, size, size, args.batch),
                            'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
                            'postprocess_in_step': bool(args.with_postprocess),
-                           'step_overlap': ('2: consecutive batches alternate between two plan instances on two HIP streams' if args.step_overlap == 2
+                           'step_overlap': ('%d: consecutive batches rotate over %d plan instances on %d HIP streams (Yolact.forward_device(slot=))'
+                                            % (args.step_overlap, args.step_overlap, args.step_overlap) if args.step_overlap > 1
                                             else '1: every step is issued behind the previous one on one stream'),
                            'host_read': ('blocking, every step' if args.no_pipeline else
-                                         'every step, asynchronous D2H copy collected after the next step is launched (depth 2)'),
+                                         'every step, asynchronous D2H copy collected after the next step(s) are launched (depth %d)' % max(2, args.step_overlap)),
                            'plan': {'source': 'shipped tune table yolact_amd/tune/gfx950.json' if plan.tune_misses == 0
                                     else 'tune table + %d shapes measured in this process' % plan.tune_misses,
                                     'tune_misses': plan.tune_misses}},
