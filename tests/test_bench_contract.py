@@ -1,4 +1,4 @@
-"""The bench.py output contract, checked on the committed result of the last GPU session (profiles/r05_bench.json): the
+"""The bench.py output contract, checked on the committed result of the last GPU session (profiles/r06_bench.json): the
 keys the driver and the judge read, their types, and the internal consistency of the roofline and calibration blocks."""
 import json
 import os
@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _load():
-    with open(os.path.join(ROOT, 'profiles', 'r05_bench.json')) as f:
+    with open(os.path.join(ROOT, 'profiles', 'r06_bench.json')) as f:
         return json.loads(f.read())
 
 
@@ -29,7 +29,14 @@ def test_top_level_fields():
     # the exchange step really ran on RCCL and every image's record arrived
     assert b['rccl_ranks'] == b['n_gpus'] and b['gathered_records'] == b['config']['global_batch']
     assert b['config']['plan']['tune_misses'] == 0           # the timed plan is the shipped (deterministic) one
+    # round 6: both scaling modes in one line — `value` = weak (batch per GPU, consecutive batches overlapped on two plan instances),
+    # strong_scaling = a fixed global batch split over the ranks on ONE plan / stream (= the serial figure at one GPU)
+    ss = b['strong_scaling']
+    assert ss['global_batch'] == 8 and sum(ss['images_per_rank']) == 8 and ss['unit'] == 'images/s' and ss['value'] > 0
+    assert b['config']['step_overlap'].startswith('2:') and ss['value'] < b['value']
     sec = b['secondary']
+    assert sec['outlier_plan']['layers_on_bf16x3'] == 0 and sec['outlier_plan']['rebalanced'] and sec['outlier_plan_guard_only']['layers_on_bf16x3'] >= 10
+    assert sec['outlier_plan']['value'] > sec['outlier_plan_guard_only']['value']
     assert sec['batch_with_postprocess']['value'] > 0 and sec['reference_fps_definition_batch1']['value'] > 0
     assert sec['sparse_regime']['value'] > 0 and 50 < sec['sparse_regime']['candidate_priors_per_image'] < 600
 

@@ -408,19 +408,23 @@ _SIDE_STREAMS = {}
 
 
 def _side_stream(device):
-    """The side stream of a new plan: one of a FIXED pool of YOLACT_AMD_SIDE_STREAMS (default 3) per device, handed out round robin.
+    """The side stream of a new plan: one of a FIXED pool of YOLACT_AMD_SIDE_STREAMS (default 2) per device, handed out round robin (two: a
+    caller that overlaps batches on a second main stream — bench.py --step-overlap 2 — then uses four streams in all; the FIFTH stream of a
+    process was measured on the main stream's hardware queue again, session r6w).
     HIP folds the streams of a process onto GPU_MAX_HW_QUEUES (4) hardware queues in creation order; with one new torch stream per plan
     (rounds 1 - 5) the 4th plan of a process got a side stream on the MAIN stream's queue and its two-stream schedule ran 1.5x slower
     than a single stream (bench.py secondary.outlier_plan, session r6l: 1 180 - 1 260 images/s against 2 050 for the same plan on a
     stream of the pool).  YOLACT_AMD_SIDE_STREAMS=0: one new stream per plan (A/B switch)."""
-    n = int(os.environ.get('YOLACT_AMD_SIDE_STREAMS', '3'))
+    n = int(os.environ.get('YOLACT_AMD_SIDE_STREAMS', '2'))
     if n <= 0:
         return torch.cuda.Stream(device=device)
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
-    pool = _SIDE_STREAMS.setdefault(key, {'streams': [], 'next': 0})
-    if len(pool['streams']) < n:
-        pool['streams'].append(torch.cuda.Stream(device=device))
-        return pool['streams'][-1]
+    pool = _SIDE_STREAMS.get(key)
+    if pool is None:
+        # ALL streams of the pool are created at the first request, back to back: a stream created later — after RCCL or the caller
+        # have created theirs — can land on the main stream's hardware queue again (session r6w: the third pool stream, created lazily
+        # behind bench.py's second step stream and RCCL's, made the batch-1 plan 2.3x slower)
+        pool = _SIDE_STREAMS[key] = {'streams': [torch.cuda.Stream(device=device) for _ in range(n)], 'next': 0}
     st = pool['streams'][pool['next'] % n]
     pool['next'] += 1
     return st
