@@ -897,8 +897,9 @@ def main():
         # --step-overlap 2: a second plan instance (slot 1) with its own gather buffers, driven on its own stream
         NOV = args.step_overlap
         gatherers = [gatherer] + [parallel.RecordGatherer(0) for _ in range(NOV - 1)]
-        step_streams = ([torch.cuda.current_stream(dev)] + [torch.cuda.Stream(device=dev) for _ in range(NOV - 1)]) if NOV > 1 else None
-        lane = {'k': 0, 'n': 0}
+        from yolact_amd.pipeline import BatchPipeline
+        pipeline = BatchPipeline(net, NOV, dev) if NOV > 1 else None      # the product's throughput mode (yolact_amd/pipeline.py)
+        lane = {'k': 0}
 
         def exchange(out):
             gatherer = gatherers[lane['k']]
@@ -928,12 +929,15 @@ def main():
             return handle
 
         def launch():
-            if step_streams is None:
+            if pipeline is None:
                 return launch_on(0)
-            slot = lane['n'] % NOV
-            lane['n'] += 1
-            with torch.cuda.stream(step_streams[slot]):
-                return launch_on(slot)
+            if args.exchange_after_join or args.with_postprocess:       # (these variants consume the outputs on the slot's stream)
+                slot = pipeline._n % NOV
+                pipeline._n += 1
+                with torch.cuda.stream(pipeline.streams[slot]):
+                    return launch_on(slot)
+            lane['k'] = pipeline._n % NOV
+            return pipeline.submit(x, after_detect=exchange).pop('after_detect')
 
         def collect(handle):
             if handle is not None:
@@ -962,8 +966,8 @@ def main():
                 collect(h)
 
         net.plan_for(x)                          # plan build (weight packing, table look-ups) is set-up, not a step
-        for sl_ in range(1, args.step_overlap):
-            net.plan_for(x, sl_)
+        if pipeline is not None:
+            pipeline.warm(x)
         calib = box_calibration(dev) if (rank == 0 and not args.no_calibration) else None
         run_steps(args.warmup)
         if have_pg:

@@ -38,6 +38,33 @@ def test_two_plan_slots_overlap_on_two_streams_and_agree():
     assert p0.stream_b is not p1.stream_b                      # the pool hands different side streams to consecutive plans ...
 
 
+def test_batch_pipeline_matches_the_single_plan_path():
+    """yolact_amd.pipeline.BatchPipeline (what bench.py times by default): submit() rotates plan slots / streams; every batch's records
+    equal the single-plan path's, `done` events order the host against each batch, after_detect runs once per batch with the slot set."""
+    from yolact_amd import parallel
+    from yolact_amd.pipeline import BatchPipeline
+    from yolact_amd.utils.synth import synth_images
+    net, _ = _build_cached()
+    xs = [synth_images(2, 550, 550, seed=500 + i).to(DEV) for i in range(5)]
+    with torch.no_grad():
+        ref = [parallel.pack_records(net.forward_device(x)).clone() for x in xs]
+        torch.cuda.synchronize()
+        pipe = BatchPipeline(net, 2)
+        pipe.warm(xs[0])
+        seen = []
+        outs = [pipe.submit(x, after_detect=lambda o: seen.append(pipe.current_slot)) for x in xs]
+        recs = []
+        for o in outs:
+            o['done'].synchronize()
+            recs.append(parallel.pack_records(o).clone())
+        pipe.synchronize()
+    assert seen == [0, 1, 0, 1, 0] and [o['slot'] for o in outs] == seen
+    for r, q in zip(recs, ref):
+        assert torch.equal(r, q)
+    with pytest.raises(ValueError):
+        BatchPipeline(net, 0)
+
+
 def test_side_stream_pool_is_bounded():
     """engine._side_stream: at most YOLACT_AMD_SIDE_STREAMS (2) side streams per device however many plans a process builds (the 4th
     plan of a process used to get a stream on the main stream's hardware queue and ran 1.5x slower than one stream)."""
