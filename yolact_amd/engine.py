@@ -1502,7 +1502,7 @@ class Plan:
                     and d3.res_mode == L.RES_ADD and not d3.res_after_act and d3.seg[0].n0 == 0 and d3.seg[0].act <= L.ACT_LEAKY01
                     and d3.w_h2 and d3.x_amax and M * max(d3.seg[0].row_stride, d3.res_ld) < (1 << 29)):
                 continue
-            if P_ > 64 and os.environ.get('YOLACT_AMD_CHAIN2', '0') != '1':       # csrc/chain2.hip is OPT-IN: measured 0.80x of the two launches it replaces (profiles/r06_chain2_probe.txt)
+            if P_ > 64 and os.environ.get('YOLACT_AMD_CHAIN2', '0') not in ('1', 'force'):       # csrc/chain2.hip is OPT-IN: measured 0.80x of the two launches it replaces (profiles/r06_chain2_probe.txt)
                 continue
             pair = False
             if i < len(self.ops) and self.ops[i][0] is lib.ymi_conv2d_nhwc_f32 and self.ops[i][3] == w3 and i not in self.wide_ops:
@@ -1548,6 +1548,8 @@ class Plan:
             cptr = C.pointer(cd)
             key = ('chain' if pair else 'chain1') + str((d3.B, d3.Ho, d3.Wo) + ((P_,) if P_ > 64 else ())) + self.mode_key
             ent = disk.get(key)
+            if P_ > 64 and os.environ.get('YOLACT_AMD_CHAIN2') == 'force':     # (A/B switch: install it whatever its isolated time says)
+                ent = [1, 0.0, 0.0]
             if ent is None:
                 self.tune_misses += 1
                 if not measure or lib.ymi_pointwise_chain_f32(cptr, s) != 0:
