@@ -30,6 +30,7 @@ def main():
     ap.add_argument('--rounds', type=int, default=7)
     ap.add_argument('--steps', type=int, default=40)
     ap.add_argument('--max-margin', type=float, default=0.70, help='only keys whose isolated wino/direct time ratio exceeds this')
+    ap.add_argument('--overlap', type=int, default=1, help='batches in flight (yolact_amd.pipeline.BatchPipeline depth): the regime bench.py times by default is 2')
     ap.add_argument('--write', action='store_true', help='persist the decisions in yolact_amd/tune/gfx950.json')
     args = ap.parse_args()
     import torch
@@ -47,8 +48,27 @@ def main():
     x = synth_images(args.batch, size, size, seed=1234).to(dev)
     with torch.no_grad():
         plan = net.plan_for(x)
+        plans = [net.plan_for(x, k) for k in range(args.overlap)]
+        from yolact_amd.pipeline import BatchPipeline
+        pipe = BatchPipeline(net, args.overlap) if args.overlap > 1 else None
+
+        def set_all(key, on):
+            for p_ in plans:
+                p_.set_winograd(key, on)
 
         def step_ms(n):
+            if pipe is not None:             # n batches through the pipeline, the host two batches ahead like bench.py
+                for _ in range(4):
+                    pipe.submit(x)
+                pipe.synchronize()
+                t0 = time.perf_counter()
+                pend = []
+                for _ in range(n):
+                    pend.append(pipe.submit(x))
+                    if len(pend) > args.overlap:
+                        pend.pop(0)['done'].synchronize()
+                pipe.synchronize()
+                return (time.perf_counter() - t0) / n * 1e3
             for _ in range(3):
                 net.forward_device(x)
             torch.cuda.synchronize()
@@ -73,11 +93,11 @@ def main():
                 continue
             tw, td = [], []
             for r in range(args.rounds):
-                plan.set_winograd(key, True)
+                set_all(key, True)
                 tw.append(step_ms(args.steps))
-                plan.set_winograd(key, False)
+                set_all(key, False)
                 td.append(step_ms(args.steps))
-            plan.set_winograd(key, True)
+            set_all(key, True)
             mw, md = statistics.median(tw), statistics.median(td)
             # direct must win by more than the spread of the rounds
             spread = max(statistics.pstdev(tw), statistics.pstdev(td))
@@ -87,10 +107,10 @@ def main():
             print('%-60s %d layers  isolated %.2f | step: winograd %.4f ms, direct %.4f ms (spread %.4f) -> %s'
                   % (key[:60], len(lst), ratio, mw, md, spread, 'DIRECT' if win else 'winograd'), flush=True)
             if win:
-                plan.set_winograd(key, False)           # later keys are judged on top of the decisions already taken
+                set_all(key, False)           # later keys are judged on top of the decisions already taken
         final = statistics.median(step_ms(args.steps) for _ in range(3))
         print('step after the decisions: %.3f ms (was %.3f)' % (final, base))
-    print(json.dumps({'config': args.config, 'batch': args.batch, 'base_ms': round(base, 4), 'final_ms': round(final, 4), 'keys': out}))
+    print(json.dumps({'config': args.config, 'batch': args.batch, 'overlap': args.overlap, 'base_ms': round(base, 4), 'final_ms': round(final, 4), 'keys': out}))
     if args.write and any(v['direct_wins_the_step'] for v in out.values()):
         path = os.path.join(engine.TUNE_DIR, 'gfx950.json')
         entries = engine._read_table_file(path)

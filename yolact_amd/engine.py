@@ -1686,6 +1686,50 @@ class Plan:
                     break
         return out
 
+    def direct_candidates(self, fn, d, wide=False):
+        """(tile + 256 * split_k) values _tune_direct measures for one convolution descriptor (also tools/overlap_tune.py)."""
+        is_dcn = fn is self.lib.ymi_dcn_v2_forward_f32
+        h2_, split_ = self.h2 and not wide, self.split or (wide and not is_dcn)
+        if is_dcn:                   # DCN gather loader: basic tiles; the bf16x3 arithmetic does not exist for it
+            cands = [t for t in L.BASIC_TILES if t != L.TILE_128x32]
+        elif d.Cin % 32 != 0:        # stem loader: basic tiles only
+            cands = [L.TILE_128x64, L.TILE_64x64] if d.Cout <= 64 else list(L.BASIC_TILES)
+        elif d.Cout <= 32:
+            cands = [L.TILE_128x32, L.TILE_64x64, L.TILE_64x64_S3, L.TILE_32x32_K4, L.TILE_32x32_K4_S4,
+                     L.TILE_64x32_K2, L.TILE_64x32_K2_S3]
+        elif d.Cout <= 64:
+            cands = [L.TILE_128x64, L.TILE_128x64_S3, L.TILE_64x64, L.TILE_64x64_S3, L.TILE_64x64_S4,
+                     L.TILE_32x32_K4, L.TILE_32x32_K4_S4, L.TILE_64x32_K2, L.TILE_64x32_K2_S3,
+                     L.TILE_32x64_K2, L.TILE_32x64_K2_S3]
+        else:
+            cands = [t for t in sorted(L.TILE_NAMES) if t != L.TILE_128x32 and not (t & (L.TILE_X3 | L.TILE_H2))]
+            if d.Cout < 256:
+                cands = [t for t in cands if t != L.TILE_128x256_W8]
+        spflag = (L.TILE_X3 if split_ else L.TILE_H2 if h2_ else 0) if not (is_dcn and split_) else 0
+        if spflag:      # (the Cin = 4 stem loader has the basic tiles only)
+            base_ok = L.H2_BASE_TILES if spflag == L.TILE_H2 else L.X3_BASE_TILES
+            cands = cands + [t | spflag for t in cands if t in base_ok
+                             and (d.Cin % 32 == 0 or t in L.BASIC_TILES)]
+        if is_dcn and h2_:           # the pipelined gather-GEMM of csrc/dcn.hip (fp16x2 plans)
+            cands = cands + self.dcnp_candidates(d, dcn=True)
+        if not is_dcn and h2_ and self.pipe and self._pipe_ok(d):   # the same pipelined kernel as an ordinary convolution
+            cands = cands + self.dcnp_candidates(d) + self.ws_candidates(d)     # (+ the streaming kernel for narrow outputs)
+            cands = cands + self.pc_candidates(d)                               # (+ round 6: producer / consumer blocks, opt-in)
+        if not is_dcn and h2_ and self.pipe:
+            cands = cands + self.patch2_candidates(d)                           # (+ round 6: 3x3 with the input patch in LDS)
+            if ((d.kh, d.kw, d.stride, d.pad, d.Cin, d.Cout) == (3, 3, 1, 1, 64, 64) and d.res_mode == L.RES_NONE
+                    and patch_tile_allowed()):
+                cands = cands + [L.DCNP_PATCH_C64 | L.TILE_H2 | L.TILE_DCNP]    # csrc/patch.hip: the input patch in LDS, filters in registers
+        if not is_dcn and self._splitk_ok(d) and self.splitk:
+            # split-K candidates: big tiles whose grid alone cannot fill the chip, K cut 2 / 4 ways
+            x3 = spflag
+            for S in (2, 4):
+                if (d.Kpad // 32) % S == 0 and d.Kpad // S >= 128:
+                    cands += [(t | x3) + 256 * S for t in (L.TILE_128x128, L.TILE_64x128, L.TILE_128x64, L.TILE_64x64,
+                                                          L.TILE_256x128_W8)]
+
+        return cands
+
     def _tune_direct(self, e0, e1, s, reps, disk, measure):
         cache = {}
         for opi, (fn, dptr, name, where) in enumerate(self.ops):
@@ -1710,44 +1754,7 @@ class Plan:
                     cache[key] = L.TILE_AUTO
                     d.tile, d.split_k = L.TILE_AUTO, 0
                     continue
-                if is_dcn:                   # DCN gather loader: basic tiles; the bf16x3 arithmetic does not exist for it
-                    cands = [t for t in L.BASIC_TILES if t != L.TILE_128x32]
-                elif d.Cin % 32 != 0:        # stem loader: basic tiles only
-                    cands = [L.TILE_128x64, L.TILE_64x64] if d.Cout <= 64 else list(L.BASIC_TILES)
-                elif d.Cout <= 32:
-                    cands = [L.TILE_128x32, L.TILE_64x64, L.TILE_64x64_S3, L.TILE_32x32_K4, L.TILE_32x32_K4_S4,
-                             L.TILE_64x32_K2, L.TILE_64x32_K2_S3]
-                elif d.Cout <= 64:
-                    cands = [L.TILE_128x64, L.TILE_128x64_S3, L.TILE_64x64, L.TILE_64x64_S3, L.TILE_64x64_S4,
-                             L.TILE_32x32_K4, L.TILE_32x32_K4_S4, L.TILE_64x32_K2, L.TILE_64x32_K2_S3,
-                             L.TILE_32x64_K2, L.TILE_32x64_K2_S3]
-                else:
-                    cands = [t for t in sorted(L.TILE_NAMES) if t != L.TILE_128x32 and not (t & (L.TILE_X3 | L.TILE_H2))]
-                    if d.Cout < 256:
-                        cands = [t for t in cands if t != L.TILE_128x256_W8]
-                spflag = (L.TILE_X3 if split_ else L.TILE_H2 if h2_ else 0) if not (is_dcn and split_) else 0
-                if spflag:      # (the Cin = 4 stem loader has the basic tiles only)
-                    base_ok = L.H2_BASE_TILES if spflag == L.TILE_H2 else L.X3_BASE_TILES
-                    cands = cands + [t | spflag for t in cands if t in base_ok
-                                     and (d.Cin % 32 == 0 or t in L.BASIC_TILES)]
-                if is_dcn and h2_:           # the pipelined gather-GEMM of csrc/dcn.hip (fp16x2 plans)
-                    cands = cands + self.dcnp_candidates(d, dcn=True)
-                if not is_dcn and h2_ and self.pipe and self._pipe_ok(d):   # the same pipelined kernel as an ordinary convolution
-                    cands = cands + self.dcnp_candidates(d) + self.ws_candidates(d)     # (+ the streaming kernel for narrow outputs)
-                    cands = cands + self.pc_candidates(d)                               # (+ round 6: producer / consumer blocks, opt-in)
-                if not is_dcn and h2_ and self.pipe:
-                    cands = cands + self.patch2_candidates(d)                           # (+ round 6: 3x3 with the input patch in LDS)
-                    if ((d.kh, d.kw, d.stride, d.pad, d.Cin, d.Cout) == (3, 3, 1, 1, 64, 64) and d.res_mode == L.RES_NONE
-                            and patch_tile_allowed()):
-                        cands = cands + [L.DCNP_PATCH_C64 | L.TILE_H2 | L.TILE_DCNP]    # csrc/patch.hip: the input patch in LDS, filters in registers
-                if not is_dcn and self._splitk_ok(d) and self.splitk:
-                    # split-K candidates: big tiles whose grid alone cannot fill the chip, K cut 2 / 4 ways
-                    x3 = spflag
-                    for S in (2, 4):
-                        if (d.Kpad // 32) % S == 0 and d.Kpad // S >= 128:
-                            cands += [(t | x3) + 256 * S for t in (L.TILE_128x128, L.TILE_64x128, L.TILE_128x64, L.TILE_64x64,
-                                                                  L.TILE_256x128_W8)]
-
+                cands = self.direct_candidates(fn, d, wide)
                 def cname(v):
                     return L.TILE_NAMES[v & 255] + ('/k%d' % (v >> 8) if v >> 8 else '')
                 best, best_ms, times = None, 1e30, {}
