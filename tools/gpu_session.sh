@@ -64,7 +64,7 @@ for st in "$@"; do
       for m in 2 1 0 2 1; do YOLACT_AMD_SPLIT=$m timeout 300 python bench.py --steps 30 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('SPLIT=$m', d['value'], d['ms_per_step'], d['config']['plan']['tune_misses'])"; done | tee $O/ab.txt ;;
     stats)
       (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $R/$O/stats2 -- bash -c "cd $R && $BENCH" > $R/$O/stats2.log 2>&1)
-      (cd /tmp && YOLACT_AMD_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $R/$O/stats1 -- bash -c "cd $R && $BENCH" > $R/$O/stats1.log 2>&1)
+      (cd /tmp && YOLACT_AMD_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $R/$O/stats1 -- bash -c "cd $R && $BENCH --step-overlap 1" > $R/$O/stats1.log 2>&1)   # one batch in flight, one stream: a kernel's own duration (what bench.py's per-kernel pass measures)
       for v in 1 2; do python - $O/stats$v > $O/kernel_stats_streams$v.txt <<'PY'
 import csv, glob, sys
 fs = glob.glob(sys.argv[1] + '/**/*kernel_stats.csv', recursive=True)
@@ -84,13 +84,13 @@ for r in (csv.DictReader(open(fs[0])) if fs else []):
 PY
       grep -E "conv_direct|global_maxpool|lincomb|upsample|kernel " $O/kernel_stats_plus_with_postprocess.txt | cut -c1-200 ;;
     traffic)
-      CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-calibration"
+      CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-calibration --step-overlap 1"
       (cd /tmp && YOLACT_AMD_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex "conv_igemm|pipe_h2_k|wgemm_k" -f csv -d $R/$O/fetch -- bash -c "cd $R && $CMD" > $R/$O/fetch.log 2>&1)
       (cd /tmp && YOLACT_AMD_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --kernel-include-regex "conv_igemm|pipe_h2_k|wgemm_k" -f csv -d $R/$O/write -- bash -c "cd $R && $CMD" > $R/$O/write.log 2>&1)
       python tools/traffic_summary.py $O/fetch $O/write > $O/traffic.json 2> $O/traffic.err; head -c 600 $O/traffic.json
       find $O -name "*counter_collection.csv" -size +4M -delete ;;
     pmc)
-      (cd /tmp && YOLACT_AMD_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --kernel-include-regex "conv_igemm|pipe_h2_k|wino|stem_pool|wgemm_k|chain_h2_k|patch3x3" -f csv -d $R/$O/pmc1 -- bash -c "cd $R && python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-calibration" > $R/$O/pmc1.log 2>&1)
+      (cd /tmp && YOLACT_AMD_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --kernel-include-regex "conv_igemm|pipe_h2_k|wino|stem_pool|wgemm_k|chain_h2_k|patch3x3" -f csv -d $R/$O/pmc1 -- bash -c "cd $R && python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-calibration --step-overlap 1" > $R/$O/pmc1.log 2>&1)
       python tools/pmc_summary.py $O/pmc1 > $O/pmc_plan_p1.tsv 2> $O/pmc.err; head -20 $O/pmc_plan_p1.tsv | cut -c1-200
       find $O -name "*counter_collection.csv" -size +4M -delete ;;
     pmcw) # wave-level counters of the Winograd GEMM variants on proto.8 (one pass, counters only)
