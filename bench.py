@@ -47,6 +47,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -644,14 +645,19 @@ def secondary_lines(net, x, size, steps=10, config=CONFIG):
     out = {}
 
     def timed(fn, n):
+        # median of three groups of n: the pool's boxes stall for 15 - 40 ms now and then (profiles/r06_overlap_stability.txt), which is
+        # +1.5 ms per step on a single group of 10
         for _ in range(3):
             fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            fn()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / n
+        groups = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            groups.append((time.perf_counter() - t0) / n)
+        return statistics.median(groups)
 
     B = x.shape[0]
 
@@ -766,15 +772,17 @@ def outlier_plan_line(dev, x, size, config, k_exp=16, steps=10, rebalance=True):
         net_o.forward_device(x)['count'].tolist()
     for _ in range(3):
         step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    per = []
-    for _ in range(steps):
-        t1 = time.perf_counter()
-        step()
-        per.append(round((time.perf_counter() - t1) * 1e3, 3))
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    per, groups = [], []
+    for _ in range(3):                      # median of three groups (see secondary_lines.timed)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            t1 = time.perf_counter()
+            step()
+            per.append(round((time.perf_counter() - t1) * 1e3, 3))
+        torch.cuda.synchronize()
+        groups.append((time.perf_counter() - t0) / steps)
+    dt = statistics.median(groups)
     if os.environ.get('BENCH_DEBUG'):
         print('outlier_plan_line rebalance=%s per-step ms %s' % (rebalance, per), file=sys.stderr)
     wide = sorted(plan.ops[i][2] for i in plan.wide_ops)
