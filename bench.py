@@ -37,9 +37,10 @@ max(FLOPs / tile peak, algorithmic bytes / 8 TB/s), `per_kernel` = every instant
 L2-resident read stream), the host's cost per C-ABI call / kernel launch, and what rocm-smi reports — so that two runs can be
 attributed to the box or to the code.  `host_issue_ms_per_step`: host time to issue one step (far below ms_per_step = GPU-bound).
 DESIGN.md 3.5 / 6.
-Round 6: `--step-overlap N` (default 2; `config.step_overlap`): consecutive steps rotate over N plan instances of the model
-(Yolact.forward_device(slot=): own arena, head buffers, workspaces) on N HIP streams, so that batch i + 1 starts while batch i is in its
-tail — the reference's own throughput mode pipelines frames the same way (eval.py evalvideo: a thread pool keeps several frames in
+Round 6: `--step-overlap N` (default 4; `config.step_overlap`): consecutive steps rotate over N plan instances of the model
+(yolact_amd.pipeline.BatchPipeline over Yolact.forward_device(slot=): own arena, head buffers, workspaces) on N HIP streams — N = 2: each
+plan also forks its side stream; N = 3, 4: one stream per plan (four busy streams is what a process has hardware queues for) —, so that
+batch i + 1 starts while batch i is in its tail — the reference's own throughput mode pipelines frames the same way (eval.py evalvideo: a thread pool keeps several frames in
 flight).  Every step is still one full pass over one batch, every step's counts still reach the host inside the timed region;
 `strong_scaling` (one plan, one stream) is the serial figure in the same line.
 """
@@ -836,9 +837,10 @@ def main():
                     'configs[1] at 8 GPUs = one image per GPU.  The weak-scaling region (--batch images per GPU) stays the headline value; '
                     'this second timed region is reported as `strong_scaling`')
     ap.add_argument('--no-strong', action='store_true', help='skip the strong-scaling region')
-    ap.add_argument('--step-overlap', type=int, default=int(os.environ.get('YOLACT_AMD_STEP_OVERLAP', '2')), choices=(1, 2, 3, 4, 5, 6, 8),
-                    help='N > 1: consecutive steps rotate over N plan instances (Yolact.forward_device(slot=)) on N HIP streams, so '
-                         'that batch i + 1 starts while batch i is still in its tail; 1: one plan, one stream (every step behind the last)')
+    ap.add_argument('--step-overlap', type=int, default=int(os.environ.get('YOLACT_AMD_STEP_OVERLAP', '4')), choices=(1, 2, 3, 4),
+                    help='N > 1: consecutive steps rotate over N plan instances (yolact_amd.pipeline.BatchPipeline) on N HIP streams, so '
+                         'that batch i + 1 starts while batch i is still in its tail (2: every plan also forks its side stream; 3, 4: one '
+                         'stream per plan); 1: one plan (every step behind the last)')
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit('--gpus must be >= 1')
@@ -940,10 +942,7 @@ def main():
             if pipeline is None:
                 return launch_on(0)
             if args.exchange_after_join or args.with_postprocess:       # (these variants consume the outputs on the slot's stream)
-                slot = pipeline._n % NOV
-                pipeline._n += 1
-                with torch.cuda.stream(pipeline.streams[slot]):
-                    return launch_on(slot)
+                return pipeline.run_in_slot(x, launch_on)[1]
             lane['k'] = pipeline._n % NOV
             return pipeline.submit(x, after_detect=exchange).pop('after_detect')
 
@@ -1087,8 +1086,9 @@ def main():
                                        % ('configs[1]: ' if is_headline else '', args.config, size, size, args.batch),
                            'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
                            'postprocess_in_step': bool(args.with_postprocess),
-                           'step_overlap': ('%d: consecutive batches rotate over %d plan instances on %d HIP streams (Yolact.forward_device(slot=))'
-                                            % (args.step_overlap, args.step_overlap, args.step_overlap) if args.step_overlap > 1
+                           'step_overlap': ('%d: consecutive batches rotate over %d plan instances on %d HIP streams (yolact_amd.pipeline.BatchPipeline, %s)'
+                                            % (args.step_overlap, args.step_overlap, args.step_overlap,
+                                               'every plan forks its side stream' if pipeline.fork else 'one stream per plan') if args.step_overlap > 1
                                             else '1: every step is issued behind the previous one on one stream'),
                            'host_read': ('blocking, every step' if args.no_pipeline else
                                          'every step, asynchronous D2H copy collected after the next step(s) are launched (depth %d)' % max(2, args.step_overlap)),

@@ -29,11 +29,11 @@ def test_top_level_fields():
     # the exchange step really ran on RCCL and every image's record arrived
     assert b['rccl_ranks'] == b['n_gpus'] and b['gathered_records'] == b['config']['global_batch']
     assert b['config']['plan']['tune_misses'] == 0           # the timed plan is the shipped (deterministic) one
-    # round 6: both scaling modes in one line — `value` = weak (batch per GPU, consecutive batches overlapped on two plan instances),
+    # round 6: both scaling modes in one line — `value` = weak (batch per GPU, consecutive batches overlapped on four plan instances),
     # strong_scaling = a fixed global batch split over the ranks on ONE plan / stream (= the serial figure at one GPU)
     ss = b['strong_scaling']
     assert ss['global_batch'] == 8 and sum(ss['images_per_rank']) == 8 and ss['unit'] == 'images/s' and ss['value'] > 0
-    assert b['config']['step_overlap'].startswith('2:') and ss['value'] < b['value']
+    assert b['config']['step_overlap'].startswith('4:') and ss['value'] < b['value']
     sec = b['secondary']
     assert sec['outlier_plan']['layers_on_bf16x3'] == 0 and sec['outlier_plan']['rebalanced'] and sec['outlier_plan_guard_only']['layers_on_bf16x3'] >= 10
     assert sec['outlier_plan']['value'] > sec['outlier_plan_guard_only']['value']

@@ -49,20 +49,25 @@ def test_batch_pipeline_matches_the_single_plan_path():
     with torch.no_grad():
         ref = [parallel.pack_records(net.forward_device(x)).clone() for x in xs]
         torch.cuda.synchronize()
-        pipe = BatchPipeline(net, 2)
-        pipe.warm(xs[0])
-        seen = []
-        outs = [pipe.submit(x, after_detect=lambda o: seen.append(pipe.current_slot)) for x in xs]
-        recs = []
-        for o in outs:
-            o['done'].synchronize()
-            recs.append(parallel.pack_records(o).clone())
-        pipe.synchronize()
-    assert seen == [0, 1, 0, 1, 0] and [o['slot'] for o in outs] == seen
-    for r, q in zip(recs, ref):
-        assert torch.equal(r, q)
-    with pytest.raises(ValueError):
-        BatchPipeline(net, 0)
+        for depth, fork, slots in ((2, True, [0, 1, 0, 1, 0]), (4, False, [0, 1, 2, 3, 0]), (3, False, [0, 1, 2, 0, 1])):
+            pipe = BatchPipeline(net, depth)        # depth 2: every plan forks its side stream; 3, 4: un-forked plans, one stream each
+            assert pipe.fork is fork and len(set(s.cuda_stream for s in pipe.streams)) == depth
+            pipe.warm(xs[0])
+            seen = []
+            outs = [pipe.submit(x, after_detect=lambda o: seen.append(pipe.current_slot)) for x in xs]
+            recs = []
+            for o in outs:
+                o['done'].synchronize()
+                recs.append(parallel.pack_records(o).clone())
+            pipe.synchronize()
+            assert seen == slots and [o['slot'] for o in outs] == seen
+            for r, q in zip(recs, ref):
+                assert torch.equal(r, q)
+            assert all(net.plan_for(xs[0], k).overlap for k in range(depth))       # the fork switch is restored after every submit
+        assert BatchPipeline(net).depth == 4 and BatchPipeline(net).fork is False
+    for bad in ((0, None), (5, None), (3, True)):     # more than four busy streams: measured slower than depth 1, refused
+        with pytest.raises(ValueError):
+            BatchPipeline(net, bad[0], fork=bad[1])
 
 
 def test_side_stream_pool_is_bounded():

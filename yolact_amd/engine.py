@@ -418,6 +418,13 @@ def _side_stream(device):
     n = int(os.environ.get('YOLACT_AMD_SIDE_STREAMS', '2'))
     if n <= 0:
         return torch.cuda.Stream(device=device)
+    pool = _side_pool(device, n)
+    st = pool['streams'][pool['next'] % n]
+    pool['next'] += 1
+    return st
+
+
+def _side_pool(device, n):
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
     pool = _SIDE_STREAMS.get(key)
     if pool is None:
@@ -425,9 +432,15 @@ def _side_stream(device):
         # have created theirs — can land on the main stream's hardware queue again (session r6w: the third pool stream, created lazily
         # behind bench.py's second step stream and RCCL's, made the batch-1 plan 2.3x slower)
         pool = _SIDE_STREAMS[key] = {'streams': [torch.cuda.Stream(device=device) for _ in range(n)], 'next': 0}
-    st = pool['streams'][pool['next'] % n]
-    pool['next'] += 1
-    return st
+    return pool
+
+
+def side_stream_pool(device):
+    """The pooled side streams of a device (created on first use; () with YOLACT_AMD_SIDE_STREAMS=0).  yolact_amd.pipeline.BatchPipeline
+    runs its un-forked plan slots on them: a plan that does not fork leaves its side stream idle, and a process should not keep more than
+    four streams busy (_side_stream)."""
+    n = int(os.environ.get('YOLACT_AMD_SIDE_STREAMS', '2'))
+    return tuple(_side_pool(device, n)['streams']) if n > 0 else ()
 
 
 class _OpList(list):
