@@ -480,7 +480,10 @@ int ymi_internal_pc_conv(const ymi_conv_desc *d, int base_tile, hipStream_t s) {
   int rc;
   const int pr = ymi_internal_prof_begin(flops, base_tile | YMI_TILE_H2 | YMI_TILE_DCNP, 14, s);
   switch (base_tile) {                                   // <consumer waves along M, along N, 32x32 tiles per consumer along M, along N>
-    case YMI_DCNP_PC_128x128: rc = (p.flags & 8) ? launch_pc<2, 2, 2, 2, 2>(p, s) : (p.flags & 16) ? launch_pc<2, 2, 2, 2, 3>(p, s) : launch_pc<2, 2, 2, 2, 4>(p, s); break;
+    case YMI_DCNP_PC_128x128:
+      if (p.flags & 32) { rc = (p.flags & 8) ? launch_pc<1, 4, 1, 1, 2>(p, s) : (p.flags & 16) ? launch_pc<1, 4, 1, 1, 3>(p, s) : launch_pc<1, 4, 1, 1, 4>(p, s); break; }   // experiment (session r6q): a 32 x 128 block behind the same id
+      if (p.flags & 64) { rc = (p.flags & 8) ? launch_pc<2, 2, 1, 2, 2>(p, s) : launch_pc<2, 2, 1, 2, 4>(p, s); break; }                                                      // ... and 64 x 128
+      rc = (p.flags & 8) ? launch_pc<2, 2, 2, 2, 2>(p, s) : (p.flags & 16) ? launch_pc<2, 2, 2, 2, 3>(p, s) : launch_pc<2, 2, 2, 2, 4>(p, s); break;
     default: rc = YMI_EARG; break;
   }
   if (rc == YMI_OK && S > 1)

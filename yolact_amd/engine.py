@@ -1659,14 +1659,14 @@ class Plan:
         M, nk = d.B * d.Ho * d.Wo, d.Kpad // 32
         out = []
         for t, name in sorted(L.PC_TILES.items()):
-            bm, bn = (int(v) for v in name[2:].split('x'))
-            if bn > 128 and d.Cout < 256:
+            bm, bn = (int(v) for v in os.environ.get('YOLACT_AMD_PC_SHAPE', name[2:]).split('x'))     # (YMI_PC_FLAGS 32 / 64 experiments: the
+            if bn > 128 and d.Cout < 256:                                                              #  block behind the id is 32 / 64 x 128)
                 continue
             tid = t | L.TILE_H2 | L.TILE_DCNP
             out.append(tid)
             blocks = -(-M // bm) * -(-d.Cout // bn)
             if blocks < 400 and d.Cout % 4 == 0:
-                for S in (2, 3, 4, 6, 8):
+                for S in (2, 3, 4, 5, 6, 8, 9, 12, 16):
                     per = -(-nk // S)
                     if per >= 4 and per * (S - 1) < nk and 128 <= blocks * S <= 1100:
                         out.append(tid + 256 * S)
