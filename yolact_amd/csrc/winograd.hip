@@ -687,6 +687,11 @@ extern "C" int ymi_conv3x3_winograd_f32(const ymi_wino_desc *d, void *stream) {
   const bool h2 = (d->tile & YMI_TILE_H2) != 0;
   if (h2 && (!d->u_h2 || !d->uinv_h2 || !d->x_amax)) return YMI_ENULL;
   const bool planes = h2 && d->v_planes != 0;
+#ifdef YMI_DIAGNOSTICS   // diagnostics build only (env YMI_WINO_ABLATE bit0): no input-transform launch — V keeps the previous run's values, every
+                         // other launch of the step is unchanged: the measured ceiling of fusing the input transform away (wrong results by design)
+  static const int wabl = [] { const char *e = getenv("YMI_WINO_ABLATE"); return e ? atoi(e) : 0; }();
+  if (!(wabl & 1)) {
+#endif
   if (mt == 4) {
     if (d->x_up) {
       if (planes) hipLaunchKernelGGL((wino43_in_k<true, true>), dim3(grid_for(T * C4)), dim3(256), 0, s, d->x_up, d->V, d->H, d->W, C4, th, tw, T, T * C4, d->x_amax, d->up_relu);
@@ -697,6 +702,9 @@ extern "C" int ymi_conv3x3_winograd_f32(const ymi_wino_desc *d, void *stream) {
     if (planes) hipLaunchKernelGGL(wino_in_k<true>, dim3(grid_for(T * C4)), dim3(256), 0, s, d->x, d->V, d->H, d->W, C4, th, tw, T, T * C4, d->x_amax);
     else hipLaunchKernelGGL(wino_in_k<false>, dim3(grid_for(T * C4)), dim3(256), 0, s, d->x, d->V, d->H, d->W, C4, th, tw, T, T * C4, d->x_amax);
   }
+#ifdef YMI_DIAGNOSTICS
+  }
+#endif
   int rc = ymi_launch_status();
   if (rc) return rc;
   ymi_conv_desc g = {};
